@@ -1,0 +1,287 @@
+"""ctypes front-end of the CPU oracle + NumPy restatement of the reference's host-side glue.
+
+TEST INFRASTRUCTURE ONLY.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+import this module; nothing under haghighatshoarmuir2024_amd/ does.
+
+Reference citations (relative to /root/reference/):
+  stht_kernel        micloc/snn_beamformer.py:48-53
+  bandpass           micloc/snn_beamformer.py:68-72
+  robust_width       micloc/snn_beamformer.py:75-76
+  neuron_kernel      micloc/snn_beamformer.py:342-361
+  delays             micloc/array_geometry.py:40-57
+  synth_template     micloc/snn_beamformer.py:239-267
+  add_noise          micloc/snn_beamformer.py:270-275
+  doa_error          paper_plots/target_snn_localization.py:466
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libmicloc_oracle.so")
+_lib = None
+
+_dp = ctypes.POINTER(ctypes.c_double)
+_ip = ctypes.POINTER(ctypes.c_int)
+_bp = ctypes.POINTER(ctypes.c_byte)
+_ubp = ctypes.POINTER(ctypes.c_ubyte)
+
+
+def build(force=False):
+    """Compile oracle/_build/libmicloc_oracle.so with gcc (a few hundred ms)."""
+    src = os.path.join(_HERE, "micloc_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "_build/libmicloc_oracle.so"])
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = ctypes.CDLL(_SO)
+        L.oracle_stht.argtypes = [_dp, ctypes.c_int, ctypes.c_int, _dp, ctypes.c_int, _dp, _dp]
+        L.oracle_iir_df2t.argtypes = [_dp, _dp, ctypes.c_int, _dp, ctypes.c_int, ctypes.c_int, _dp, ctypes.c_int]
+        L.oracle_local_maxima.argtypes = [_dp, ctypes.c_int, _ip]
+        L.oracle_local_maxima.restype = ctypes.c_int
+        L.oracle_select_by_distance.argtypes = [_ip, _dp, ctypes.c_int, ctypes.c_int, _ubp]
+        L.oracle_rzcc.argtypes = [_dp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _bp]
+        L.oracle_lif_fir.argtypes = [_bp, ctypes.c_int, ctypes.c_int, _dp, ctypes.c_int, _dp]
+        L.oracle_beamform.argtypes = [_dp, ctypes.c_int, ctypes.c_int, _dp, ctypes.c_int, _dp]
+        L.oracle_power_argmax.argtypes = [_dp, ctypes.c_int, ctypes.c_int, _dp]
+        L.oracle_power_argmax.restype = ctypes.c_int
+        L.oracle_snn_chain.argtypes = [_dp, ctypes.c_int, ctypes.c_int, _dp, ctypes.c_int, _dp, _dp, ctypes.c_int,
+                                       ctypes.c_int, ctypes.c_int, _dp, ctypes.c_int, _dp, ctypes.c_int,
+                                       _dp, _bp, _dp, _dp, _dp]
+        L.oracle_snn_chain.restype = ctypes.c_int
+        L.oracle_beamformer_chain.argtypes = [_dp, ctypes.c_int, ctypes.c_int, _dp, ctypes.c_int, _dp, _dp, ctypes.c_int,
+                                              _dp, _dp, ctypes.c_int, _dp, _dp, _dp, _dp]
+        L.oracle_beamformer_chain.restype = ctypes.c_int
+        L.oracle_snn_chain_batch.argtypes = [_dp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _dp, ctypes.c_int, _dp, _dp,
+                                             ctypes.c_int, ctypes.c_int, ctypes.c_int, _dp, ctypes.c_int, _dp,
+                                             ctypes.c_int, _dp, _ip]
+        _lib = L
+    return _lib
+
+
+def _d(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(_dp)
+
+
+def _pad_ba(b, a):
+    b = np.atleast_1d(np.asarray(b, dtype=np.float64))
+    a = np.atleast_1d(np.asarray(a, dtype=np.float64))
+    n = max(len(b), len(a))
+    bb = np.zeros(n)
+    aa = np.zeros(n)
+    bb[: len(b)] = b / a[0]
+    aa[: len(a)] = a / a[0]
+    return bb, aa, n
+
+
+# ------------------------------------------------------------------------------------------------
+# C oracle wrappers (single trial, reference layout T x M / T x C row-major)
+# ------------------------------------------------------------------------------------------------
+def stht(x, kernel):
+    x, xp = _d(x)
+    k, kp = _d(kernel)
+    T, M = x.shape
+    re = np.empty((T, M))
+    im = np.empty((T, M))
+    lib().oracle_stht(xp, T, M, kp, len(k), re.ctypes.data_as(_dp), im.ctypes.data_as(_dp))
+    return re, im
+
+
+def iir(b, a, x):
+    """lfilter(b, a, x, axis=0) for real x of shape (T, C)."""
+    x, _ = _d(x)
+    T, C = x.shape
+    bb, aa, n = _pad_ba(b, a)
+    y = np.empty_like(x)
+    for c in range(C):
+        lib().oracle_iir_df2t(bb.ctypes.data_as(_dp), aa.ctypes.data_as(_dp), n,
+                              x[:, c:].ctypes.data_as(_dp), T, C, y[:, c:].ctypes.data_as(_dp), C)
+    return y
+
+
+def rzcc(r, robust_width, bipolar):
+    r, rp = _d(r)
+    if r.ndim == 1:
+        r = r.reshape(-1, 1)
+    T, C = r.shape
+    s = np.zeros((T, C), dtype=np.int8)
+    if T > 0 and C > 0:
+        lib().oracle_rzcc(r.ctypes.data_as(_dp), T, C, int(robust_width), int(bool(bipolar)), s.ctypes.data_as(_bp))
+    return s
+
+
+def lif_fir(spikes, nir):
+    s = np.ascontiguousarray(spikes, dtype=np.int8)
+    T, C = s.shape
+    k, kp = _d(nir)
+    v = np.empty((T, C))
+    lib().oracle_lif_fir(s.ctypes.data_as(_bp), T, C, kp, len(k), v.ctypes.data_as(_dp))
+    return v
+
+
+def beamform(v, W):
+    v, vp = _d(v)
+    W, wp = _d(W)
+    T, C = v.shape
+    G = W.shape[1]
+    y = np.empty((T, G))
+    lib().oracle_beamform(vp, T, C, wp, G, y.ctypes.data_as(_dp))
+    return y
+
+
+def snn_chain(x, kernel, b, a, robust_width, bipolar, nir, W, want=("pre_enc", "spikes", "vmem", "y", "power")):
+    """SNNBeamformer.apply_to_signal + power/argmax for one trial.  Returns a dict."""
+    x, xp = _d(x)
+    T, M = x.shape
+    C = 2 * M
+    k, kp = _d(kernel)
+    bb, aa, n = _pad_ba(b, a)
+    nir, nirp = _d(nir)
+    W, wp = _d(W)
+    assert W.shape[0] == C
+    G = W.shape[1]
+    out = {}
+    pre = np.empty((T, C)) if "pre_enc" in want else None
+    spk = np.zeros((T, C), dtype=np.int8) if "spikes" in want else None
+    vm = np.empty((T, C)) if "vmem" in want else None
+    y = np.empty((T, G)) if "y" in want else None
+    pw = np.empty(G)
+    null_d = ctypes.cast(None, _dp)
+    am = lib().oracle_snn_chain(
+        xp, T, M, kp, len(k), bb.ctypes.data_as(_dp), aa.ctypes.data_as(_dp), n, int(robust_width), int(bool(bipolar)),
+        nirp, len(nir), wp, G,
+        pre.ctypes.data_as(_dp) if pre is not None else null_d,
+        spk.ctypes.data_as(_bp) if spk is not None else ctypes.cast(None, _bp),
+        vm.ctypes.data_as(_dp) if vm is not None else null_d,
+        y.ctypes.data_as(_dp) if y is not None else null_d,
+        pw.ctypes.data_as(_dp),
+    )
+    out.update(pre_enc=pre, spikes=spk, vmem=vm, y=y, power=pw, argmax=int(am))
+    return out
+
+
+def snn_chain_batch(x, kernel, b, a, robust_width, bipolar, nir, W):
+    """B trials -> (power [B,G], argmax [B]); the loop bench.py times as the CPU baseline."""
+    x, xp = _d(x)
+    B, T, M = x.shape
+    k, kp = _d(kernel)
+    bb, aa, n = _pad_ba(b, a)
+    nir, nirp = _d(nir)
+    W, wp = _d(W)
+    G = W.shape[1]
+    pw = np.empty((B, G))
+    am = np.empty(B, dtype=np.int32)
+    lib().oracle_snn_chain_batch(xp, B, T, M, kp, len(k), bb.ctypes.data_as(_dp), aa.ctypes.data_as(_dp), n,
+                                 int(robust_width), int(bool(bipolar)), nirp, len(nir), wp, G,
+                                 pw.ctypes.data_as(_dp), am.ctypes.data_as(_ip))
+    return pw, am
+
+
+def beamformer_chain(x, kernel, b, a, W, want_y=True):
+    """Beamformer.apply_to_signal (complex W of shape M x G) + power/argmax."""
+    x, xp = _d(x)
+    T, M = x.shape
+    k, kp = _d(kernel)
+    bb, aa, n = _pad_ba(b, a)
+    Wre, wrp = _d(np.real(W))
+    Wim, wip = _d(np.imag(W))
+    G = Wre.shape[1]
+    pre = np.empty((T, 2 * M))
+    yre = np.empty((T, G)) if want_y else None
+    yim = np.empty((T, G)) if want_y else None
+    pw = np.empty(G)
+    null_d = ctypes.cast(None, _dp)
+    am = lib().oracle_beamformer_chain(xp, T, M, kp, len(k), bb.ctypes.data_as(_dp), aa.ctypes.data_as(_dp), n, wrp, wip, G,
+                                       pre.ctypes.data_as(_dp),
+                                       yre.ctypes.data_as(_dp) if want_y else null_d,
+                                       yim.ctypes.data_as(_dp) if want_y else null_d,
+                                       pw.ctypes.data_as(_dp))
+    return dict(pre=pre, y=(yre + 1j * yim) if want_y else None, power=pw, argmax=int(am))
+
+
+# ------------------------------------------------------------------------------------------------
+# NumPy restatement of the host-side parameter builders and of the synthesis (small, O(T) work)
+# ------------------------------------------------------------------------------------------------
+def stht_kernel(fs, kernel_duration):
+    """fftshift(imag(hilbert(delta_L))) in closed form: for even L, imag(hilbert(delta))[n] =
+    (2/L) cot(pi n / L) for odd n and 0 for even n; scipy builds it with an FFT, so the
+    closed form agrees to ~1e-16, not bit for bit -- the product code calls scipy like the reference."""
+    from scipy.signal import hilbert
+
+    L = int(fs * kernel_duration)
+    imp = np.zeros(L)
+    imp[0] = 1
+    return np.fft.fftshift(np.imag(hilbert(imp)))
+
+
+def bandpass(fs, freq_range, order=2):
+    from scipy.signal import butter
+
+    return butter(order, freq_range, btype="bandpass", analog=False, output="ba", fs=fs)
+
+
+def robust_width(fs, f_high):
+    return int(fs / f_high) // 2
+
+
+def neuron_kernel(time_vec, tau_vec):
+    tau_syn, tau_mem = tau_vec[0], tau_vec[1]
+    if tau_syn != tau_mem:
+        raise ValueError("only tau_syn == tau_mem is supported (the reference's other branch trips its own assert)")
+    t = np.asarray(time_vec) - time_vec[0]
+    h = (t / tau_syn) * np.exp(-t / tau_syn)
+    h = h / np.sum(h)
+    n = int(np.sum(np.cumsum(h) < 0.999))
+    return h[:n]
+
+
+def delays(r_vec, theta_vec, theta, normalized=True, speed=340):
+    d = -np.asarray(r_vec) * np.cos(np.asarray(theta_vec) - theta) / speed
+    if normalized:
+        d = d - np.min(d)
+    return d
+
+
+def center_circular(radius, num_mic):
+    r_vec = np.array([*list(radius * np.ones(num_mic - 1)), 0.0])
+    theta_vec = np.array([*list(np.linspace(0, 2 * np.pi, num_mic - 1)), 0.0])
+    return r_vec, theta_vec
+
+
+def synth_template(r_vec, theta_vec, time_temp, sig_temp, doa_temp, fs, speed=340):
+    """Noise-free array signal of SNNBeamformer.apply_to_template; returns (time[T], sig[T,M])."""
+    time_temp = np.asarray(time_temp, dtype=np.float64)
+    sig_temp = np.asarray(sig_temp, dtype=np.float64)
+    if np.isscalar(doa_temp) or np.ndim(doa_temp) == 0:
+        doa_temp = float(doa_temp) * np.ones_like(sig_temp)
+    time_in = np.arange(time_temp.min(), time_temp.max(), step=1 / fs)
+    sig_in = np.interp(time_in, time_temp, sig_temp)
+    doa_in = np.interp(time_in, time_temp, doa_temp)
+    # delays[m, t] = -r_m cos(theta_m - doa_t) / c   (vectorised form of the reference's list-comp)
+    d = -np.asarray(r_vec).reshape(-1, 1) * np.cos(np.asarray(theta_vec).reshape(-1, 1) - doa_in.reshape(1, -1)) / speed
+    d = d - d.min()
+    time_delayed = time_in.reshape(1, -1) - d
+    time_delayed[time_delayed < time_in.min()] = time_in.min()
+    sig = np.interp(time_delayed.ravel(), time_in, sig_in).reshape(time_delayed.shape).T
+    return time_in, np.ascontiguousarray(sig)
+
+
+def add_noise(sig, snr_db, randn=None):
+    """In-place AWGN exactly like snn_beamformer.py:270-275 (global legacy NumPy stream by default)."""
+    randn = randn or np.random.randn
+    snr = 10 ** (snr_db / 10)
+    noise = np.sqrt(np.mean(sig**2)) / np.sqrt(snr) * randn(*sig.shape)
+    sig += noise
+    return sig
+
+
+def doa_error(doa_est, doa_true):
+    return np.arcsin(np.abs(np.sin(doa_est - doa_true)))

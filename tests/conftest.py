@@ -1,0 +1,37 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def golden(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+@pytest.fixture(scope="session")
+def cfg2():
+    """Parameters of BASELINE config 2 (paper_plots/target_snn_localization.py:319-342) from golden data."""
+    k = golden("kat_init.npz")
+    bf = golden("bf_mat_chirp449_bipolar.npz")
+    return dict(
+        fs=48_000,
+        kernel=k["kernel_48k"],
+        b=k["b_48k"],
+        a=k["a_48k"],
+        robust_width=int(k["robust_width_48k"]),
+        nir=k["nir_48k"],
+        bf_mat=bf["bf_mat"],
+        doa_list=bf["doa_list"],
+        r_vec=k["ccirc_r"],
+        theta_vec=k["ccirc_theta"],
+    )

@@ -1,0 +1,540 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors in tests/golden/ by running the *real* reference.
+
+Run in the build container only (the reference lives at /root/reference, which does not exist on the
+GPU box):
+
+    python tests/golden/make_golden.py            # all fixtures
+    python tests/golden/make_golden.py rzcc_edge  # one fixture
+
+Only *data* (inputs and the reference's outputs) is written; no reference source travels.
+Every fixture records the seed / parameters that produced it so it can be regenerated.
+
+Reference entry points exercised (paths relative to /root/reference):
+  micloc/snn_beamformer.py   SNNBeamformer.__init__/design_from_template/apply_to_template/apply_to_signal
+  micloc/beamformer.py       Beamformer.__init__/design_from_template/apply_to_template/apply_to_signal
+  micloc/spike_encoder.py    ZeroCrossingSpikeEncoder.evolve
+  micloc/array_geometry.py   CenterCircularArray / CircularArray / LinearArray / Random2DArray .delays
+  micloc/utils.py            find_peak_location, Envelope
+  micloc/filterbank.py       ButterworthFilterbank.evolve
+and the Monte-Carlo loop of paper_plots/target_snn_localization.py:435-467 (restated here because the
+script itself needs cvxpy/soundfile, which are not installed).
+"""
+import os
+import sys
+import io
+import contextlib
+
+REF = "/root/reference"
+if not os.path.isdir(REF):
+    sys.exit("reference not present: golden vectors can only be regenerated in the build container")
+sys.path.insert(0, REF)
+# make sure the in-repo drop-in `micloc` shim does not shadow the reference package
+sys.path = [p for p in sys.path if os.path.abspath(p or ".") != os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))]
+
+import numpy as np  # noqa: E402
+
+import micloc  # noqa: E402
+
+assert os.path.abspath(micloc.__file__ if micloc.__file__ else list(micloc.__path__)[0]).startswith(REF), micloc
+
+from micloc.array_geometry import (  # noqa: E402
+    CenterCircularArray,
+    CircularArray,
+    LinearArray,
+    Random2DArray,
+)
+from micloc.snn_beamformer import SNNBeamformer  # noqa: E402
+from micloc.beamformer import Beamformer  # noqa: E402
+from micloc.spike_encoder import ZeroCrossingSpikeEncoder  # noqa: E402
+from micloc.utils import find_peak_location, Envelope  # noqa: E402
+from micloc.filterbank import ButterworthFilterbank  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+        return fn(*a, **k)
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name)
+    np.savez_compressed(path, **arrays)
+    print(f"wrote {name}  ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
+# --------------------------------------------------------------------------------------------------
+def cfg2_beamformer(bipolar=True):
+    """paper_plots/target_snn_localization.py:319-342"""
+    radius, num_mic, fs = 4.5e-2, 7, 48_000
+    freq_design = 2_000
+    freq_range = [0.5 * freq_design, freq_design]
+    geometry = CenterCircularArray(radius=radius, num_mic=num_mic)
+    tau = 1.0 / (2 * np.pi * freq_design)
+    beamf = SNNBeamformer(
+        geometry=geometry,
+        kernel_duration=10.0e-3,
+        tau_vec=np.asarray([tau, tau]),
+        freq_range=freq_range,
+        fs=fs,
+        bipolar_spikes=bipolar,
+    )
+    return beamf, geometry, fs, freq_design, freq_range
+
+
+def chirp_template(fs, freq_range, duration=1000e-3):
+    """paper_plots/target_snn_localization.py:345-356"""
+    time_temp = np.arange(0, duration, step=1 / fs)
+    f_min, f_max = freq_range
+    period = time_temp[-1]
+    freq_inst = f_min + (f_max - f_min) * (time_temp % period) / period
+    phase_inst = 2 * np.pi * np.cumsum(freq_inst) * 1 / fs
+    return time_temp, np.sin(phase_inst)
+
+
+def capture_chain(beamf, bf_mat, time_vec, sig):
+    """run apply_to_signal and capture pre-encoder signal + spikes by wrapping the encoder."""
+    cap = {}
+    enc = beamf.spk_encoder
+    orig = enc.evolve
+
+    def wrapped(x):
+        cap["pre_enc"] = np.array(x, copy=True)
+        s = orig(x)
+        cap["spikes"] = np.array(s, copy=True)
+        return s
+
+    enc.evolve = wrapped
+    try:
+        y = beamf.apply_to_signal(bf_mat=bf_mat, sig_in_vec=(time_vec, sig))
+    finally:
+        del enc.evolve
+    cap["y"] = y
+    return cap
+
+
+# --------------------------------------------------------------------------------------------------
+def gen_kat_init():
+    out = {}
+    for tag, fs, fr in [("48k", 48_000, [1000.0, 2000.0]), ("96k", 96_000, [1000.0, 2000.0]), ("48k_4k", 48_000, [2000.0, 4000.0])]:
+        geometry = CenterCircularArray(radius=4.5e-2, num_mic=7)
+        tau = 1.0 / (2 * np.pi * fr[1])
+        bf = SNNBeamformer(geometry, 10.0e-3, fr, np.asarray([tau, tau]), bipolar_spikes=True, fs=fs)
+        b, a = bf.bandpass_filter
+        out[f"kernel_{tag}"] = bf.kernel
+        out[f"b_{tag}"] = b
+        out[f"a_{tag}"] = a
+        out[f"robust_width_{tag}"] = np.int64(bf.spk_encoder.robust_width)
+        out[f"kernel_length_{tag}"] = np.int64(bf.kernel_length)
+        # neuron kernel exactly as apply_to_signal builds it (snn_beamformer.py:342-361), T = 0.1 s
+        T = len(np.arange(0, 100e-3, step=1 / fs)) - 1
+        time_vec = np.arange(T) / fs
+        t = time_vec - time_vec[0]
+        h = (t / tau) * np.exp(-t / tau)
+        h = h / np.sum(h)
+        n = int(np.sum(np.cumsum(h) < 0.999))
+        out[f"nir_{tag}"] = h[:n]
+        out[f"nir_T_{tag}"] = np.int64(T)
+    # geometries
+    g = CenterCircularArray(4.5e-2, 7)
+    out["ccirc_r"], out["ccirc_theta"] = g.r_vec, g.theta_vec
+    g = CircularArray(4.5e-2, 7)
+    out["circ_r"], out["circ_theta"] = g.r_vec, g.theta_vec
+    g = LinearArray(spacing=0.02, num_mic=8, radius=0.07)
+    out["lin_r"], out["lin_theta"] = g.r_vec, g.theta_vec
+    np.random.seed(1)
+    g = Random2DArray(radius=0.2, num_mic=16)
+    out["rand_r"], out["rand_theta"] = g.r_vec, g.theta_vec
+    thetas = np.array([-3.0, -1.0, 0.0, 0.7, 2.5])
+    for nm, geo in [("ccirc", CenterCircularArray(4.5e-2, 7)), ("lin", LinearArray(0.02, 8, 0.07))]:
+        out[f"{nm}_delays_norm"] = np.stack([geo.delays(th, True) for th in thetas])
+        out[f"{nm}_delays_raw"] = np.stack([geo.delays(th, False) for th in thetas])
+    out["thetas"] = thetas
+    # utils.find_peak_location
+    rng = np.random.RandomState(7)
+    p = rng.rand(449)
+    out["fpl_in"] = p
+    out["fpl_out"] = np.array([find_peak_location(p, 15), find_peak_location(p, 1), find_peak_location(p, 15, periodic=False)])
+    env = Envelope(rise_time=1e-3, fall_time=20e-3, fs=48_000)
+    x = rng.randn(300, 3)
+    out["env_in"] = x
+    out["env_out"] = env.evolve(x)
+    save("kat_init.npz", **out)
+
+
+def gen_bf_mat_chirp():
+    beamf, geometry, fs, fd, fr = cfg2_beamformer(True)
+    t, s = chirp_template(fs, fr)
+    doa_list = np.linspace(-np.pi, np.pi, 64 * 7 + 1)
+    # capture the complex covariances fed to SVD (for design parity up to phase)
+    covs = []
+    orig_svd = np.linalg.svd
+
+    def svd_spy(mat, *a, **k):
+        covs.append(np.array(mat, copy=True))
+        return orig_svd(mat, *a, **k)
+
+    np.linalg.svd = svd_spy
+    try:
+        bf_mat = quiet(beamf.design_from_template, template=(t, s), doa_list=doa_list)
+    finally:
+        np.linalg.svd = orig_svd
+    covs = np.asarray(covs)
+    sel = np.arange(0, 449, 32)
+    save("bf_mat_chirp449_bipolar.npz", bf_mat=bf_mat, doa_list=doa_list, cov_sel=covs[sel], cov_idx=sel)
+
+
+def gen_bf_mat_unipolar():
+    """paper_plots/array_resolution_snn.py:100-164 (config 1)"""
+    out = {}
+    for f in (1000, 2000, 4000):
+        geometry = CenterCircularArray(radius=4.5e-2, num_mic=7)
+        fs = 48_000
+        tau = 1 / (2 * np.pi * f)
+        beamf = SNNBeamformer(geometry, 10e-3, [0.5 * f, 2 * f], np.asarray([tau, tau]), bipolar_spikes=False, fs=fs)
+        time_temp = np.arange(0, 0.4, step=1 / fs)
+        sig_temp = np.sin(2 * np.pi * f * time_temp)
+        doa_list = np.linspace(-np.pi, np.pi, 32 * 7 + 1)
+        covs = []
+        orig_svd = np.linalg.svd
+
+        def svd_spy(mat, *a, **k):
+            covs.append(np.array(mat, copy=True))
+            return orig_svd(mat, *a, **k)
+
+        np.linalg.svd = svd_spy
+        try:
+            bf_mat = quiet(beamf.design_from_template, template=(time_temp, sig_temp), doa_list=doa_list)
+        finally:
+            np.linalg.svd = orig_svd
+        out[f"bf_mat_f{f}"] = bf_mat
+        sel = np.arange(0, 225, 32)
+        out[f"cov_sel_f{f}"] = np.asarray(covs)[sel]
+        out["cov_idx"] = sel
+        out["doa_list"] = doa_list
+    save("bf_mat_sin225_unipolar.npz", **out)
+
+
+def gen_trials_cfg2():
+    beamf, geometry, fs, fd, fr = cfg2_beamformer(True)
+    z = np.load(os.path.join(OUT, "bf_mat_chirp449_bipolar.npz"))
+    bf_mat, doa_list = z["bf_mat"], z["doa_list"]
+    time_test = np.arange(0, 100e-3, step=1 / fs)
+    sig_test = np.sin(2 * np.pi * fd * time_test)
+    snr_db = 0 - 10 * np.log10((fs / 2) / (fr[1] - fr[0]))
+    np.random.seed(1234)
+    doas, sigs, spikes, powers, argmaxes, yrows = [], [], [], [], [], []
+    pre0 = None
+    row_idx = np.array([0, 1, 100, 239, 240, 241, 1000, 4798])
+    # capture the noisy array signal by wrapping apply_to_signal
+    for trial in range(3):
+        doa = np.random.rand(1)[0] * 2 * np.pi
+        cap_in = {}
+        orig_apply = beamf.apply_to_signal
+
+        def spy(bf_mat, sig_in_vec):
+            cap_in["time"] = np.array(sig_in_vec[0], copy=True)
+            cap_in["sig"] = np.array(sig_in_vec[1], copy=True)
+            return capture_chain_inner(bf_mat, sig_in_vec)
+
+        def capture_chain_inner(bf_mat_, sig_in_vec_):
+            cap = capture_chain_cls(beamf, orig_apply, bf_mat_, sig_in_vec_)
+            cap_in.update(cap)
+            return cap["y"]
+
+        beamf.apply_to_signal = spy
+        try:
+            y = beamf.apply_to_template(bf_mat=bf_mat, template=(time_test, sig_test, doa), snr_db=snr_db)
+        finally:
+            del beamf.apply_to_signal
+        power = np.mean(np.abs(y) ** 2, axis=0)
+        doas.append(doa)
+        sigs.append(cap_in["sig"])
+        spikes.append(cap_in["spikes"].astype(np.int8))
+        powers.append(power)
+        argmaxes.append(int(np.argmax(power)))
+        yrows.append(y[row_idx])
+        if trial == 0:
+            pre0 = cap_in["pre_enc"]
+            time0 = cap_in["time"]
+    save(
+        "trials_cfg2.npz",
+        seed=np.int64(1234),
+        snr_db=np.float64(snr_db),
+        doa=np.asarray(doas),
+        sig_in=np.asarray(sigs),
+        spikes=np.asarray(spikes),
+        power=np.asarray(powers),
+        argmax=np.asarray(argmaxes),
+        y_rows=np.asarray(yrows),
+        row_idx=row_idx,
+        pre_enc0_head=pre0[:1200],
+        pre_enc0_tail=pre0[-300:],
+        time0=time0,
+    )
+
+
+def capture_chain_cls(beamf, apply_fn, bf_mat, sig_in_vec):
+    cap = {}
+    enc = beamf.spk_encoder
+    orig = enc.evolve
+
+    def wrapped(x):
+        cap["pre_enc"] = np.array(x, copy=True)
+        s = orig(x)
+        cap["spikes"] = np.array(s, copy=True)
+        return s
+
+    enc.evolve = wrapped
+    try:
+        cap["y"] = apply_fn(bf_mat=bf_mat, sig_in_vec=sig_in_vec)
+    finally:
+        del enc.evolve
+    return cap
+
+
+def gen_sweep_seed0():
+    """paper_plots/target_snn_localization.py:435-467 with 3 of the 11 SNRs."""
+    beamf, geometry, fs, fd, fr = cfg2_beamformer(True)
+    z = np.load(os.path.join(OUT, "bf_mat_chirp449_bipolar.npz"))
+    bf_mat, doa_list = z["bf_mat"], z["doa_list"]
+    snr_gain = (fs / 2) / (fr[1] - fr[0])
+    snr_db_vec = np.array([-10.0, 5.0, 20.0])
+    num_sim = 100
+    time_test = np.arange(0, 100e-3, step=1 / fs)
+    sig_test = np.sin(2 * np.pi * fd * time_test)
+    np.random.seed(0)
+    doa = np.zeros((3, num_sim))
+    amax = np.zeros((3, num_sim), dtype=np.int64)
+    err = np.zeros((3, num_sim))
+    pmax = np.zeros((3, num_sim))
+    for i, snr_db in enumerate(snr_db_vec):
+        snr_t = snr_db - 10 * np.log10(snr_gain)
+        for sim in range(num_sim):
+            d = np.random.rand(1)[0] * 2 * np.pi
+            y = beamf.apply_to_template(bf_mat=bf_mat, template=(time_test, sig_test, d), snr_db=snr_t)
+            power = np.mean(np.abs(y) ** 2, axis=0)
+            k = int(np.argmax(power))
+            doa[i, sim], amax[i, sim], pmax[i, sim] = d, k, power[k]
+            err[i, sim] = np.arcsin(np.abs(np.sin(doa_list[k] - d)))
+    save("sweep_seed0.npz", seed=np.int64(0), snr_db_vec=snr_db_vec, doa=doa, argmax=amax, err=err, pmax=pmax,
+         mae_deg=np.mean(err, axis=1) * 180 / np.pi)
+
+
+def gen_rzcc_edge():
+    rng = np.random.RandomState(42)
+    cases = {}
+
+    def add(name, x, w, bipolar):
+        x = np.asarray(x, dtype=np.float64)
+        if x.ndim == 1:
+            x = x.reshape(-1, 1)
+        enc = ZeroCrossingSpikeEncoder(fs=48_000, robust_width=w, bipolar=bipolar)
+        s = enc.evolve(x)
+        cases[f"{name}__in"] = x
+        cases[f"{name}__w"] = np.int64(w)
+        cases[f"{name}__bip"] = np.int64(bipolar)
+        cases[f"{name}__out"] = s.astype(np.int8)
+
+    t = np.arange(600)
+    add("sine_w12_bip", np.sin(2 * np.pi * t / 31.7), 12, True)
+    add("sine_w12_uni", np.sin(2 * np.pi * t / 31.7), 12, False)
+    add("noise_w1_bip", rng.randn(500, 3), 1, True)
+    add("noise_w2_bip", rng.randn(500, 3), 2, True)
+    add("noise_w12_bip", rng.randn(800, 4), 12, True)
+    add("noise_w24_uni", rng.randn(800, 2), 24, False)
+    add("noise_w200_bip", rng.randn(700, 2), 200, True)
+    # exact zeros at the start (design path: clamped interpolation repeats s[0] = 0) -> plateaus
+    x = np.concatenate([np.zeros(40), np.sin(2 * np.pi * np.arange(400) / 29.3)])
+    add("leading_zeros", x, 12, True)
+    # integer-valued input -> exact ties in the cumsum priorities and flat plateaus
+    add("int_ties", rng.randint(-2, 3, size=(600, 3)).astype(float), 5, True)
+    add("int_ties_w12", rng.randint(-1, 2, size=(900, 2)).astype(float), 12, True)
+    # alternating sign: a peak every 2 samples, one huge cluster
+    add("alternating", np.where(np.arange(300) % 2 == 0, 1.0, -1.0), 12, True)
+    add("alternating_drift_up", np.where(np.arange(400) % 2 == 0, 1.5, -1.0), 12, True)
+    add("alternating_drift_dn", np.where(np.arange(400) % 2 == 0, 1.0, -1.5), 7, True)
+    # peaks exactly `distance` apart: period-8 square pattern with w = 8 and w = 9
+    sq = np.tile(np.array([1, 1, 1, 1, -1, -1, -1, -1.0]), 40)
+    add("period8_w8", sq, 8, True)
+    add("period8_w9", sq, 9, True)
+    # tiny inputs
+    add("len1", np.array([1.0]), 3, True)
+    add("len2", np.array([1.0, -1.0]), 3, True)
+    add("len3", np.array([1.0, -1.0, 1.0]), 3, True)
+    add("len4", np.array([1.0, -1.0, -1.0, 2.0]), 1, True)
+    add("all_zero", np.zeros((50, 2)), 12, True)
+    add("const_pos", np.ones(64), 12, True)
+    # plateau reaching the last sample, plateau in the middle
+    add("plateau_end", np.array([1, 1, 0, 0, 0, 0.0]), 2, True)
+    add("plateau_mid", np.array([1, 1, 0, 0, 0, -1, -1, 1, 0, 0, 1, -3, 0, 0, 0, 0, 2.0]), 2, True)
+    # absorbed increments: |x| < ulp(cumsum)/2 makes plateaus although x != 0
+    x = np.array([1e16, 1.0, 1.0, -4.0, 1.0, 1.0, 3.0, -1e16, 5.0, -1.0, -1.0])
+    add("absorbed", x, 1, True)
+    # random walk with drift (long increasing chains of close peaks)
+    add("drift_noise", 0.3 + rng.randn(1500, 2), 12, True)
+    add("drift_noise_neg", -0.3 + rng.randn(1500, 2), 6, True)
+    save("rzcc_edge.npz", **cases)
+
+
+def gen_beamformer_c128():
+    """paper_plots/target_localization.py:310-372 (G = 8*7+1 = 57) and one noisy trial."""
+    radius, num_mic, fs = 4.5e-2, 7, 48_000
+    freq_design = 2_000
+    freq_range = [0.5 * freq_design, freq_design]
+    geometry = CenterCircularArray(radius=radius, num_mic=num_mic)
+    beamf = Beamformer(geometry=geometry, kernel_duration=10.0e-3, freq_range=freq_range, fs=fs)
+    t, s = chirp_template(fs, freq_range)
+    doa_list = np.linspace(-np.pi, np.pi, 8 * num_mic + 1)
+    bf_mat, cov_list = quiet(beamf.design_from_template, template=(t, s), doa_list=doa_list)
+    time_test = np.arange(0, 100e-3, step=1 / fs)
+    sig_test = np.sin(2 * np.pi * freq_design * time_test)
+    np.random.seed(99)
+    doa = np.random.rand(1)[0] * 2 * np.pi
+    cap = {}
+    orig = beamf.apply_to_signal
+
+    def spy(bf_mat, sig_in):
+        cap["sig"] = np.array(sig_in, copy=True)
+        return orig(bf_mat=bf_mat, sig_in=sig_in)
+
+    beamf.apply_to_signal = spy
+    try:
+        y = beamf.apply_to_template(bf_mat=bf_mat, template=(time_test, sig_test, doa), snr_db=3.0)
+    finally:
+        del beamf.apply_to_signal
+    power = np.mean(np.abs(y) ** 2, axis=0)
+    row_idx = np.array([0, 1, 239, 240, 241, 1000, 4798])
+    # interference-removal design on a small grid as well
+    bf_mat_ir, _ = quiet(beamf.design_from_template, template=(t[:9600], s[:9600]), doa_list=doa_list[::4], interference_removal=True)
+    save("beamformer_c128.npz", bf_mat=bf_mat, cov_list=np.asarray(cov_list), doa_list=doa_list, doa=np.float64(doa), sig_in=cap["sig"],
+         y_rows=y[row_idx], row_idx=row_idx, power=power, argmax=np.int64(np.argmax(power)), snr_db=np.float64(3.0),
+         bf_mat_ir=bf_mat_ir)
+
+
+def gen_wide_case():
+    """Generic-shape case: 16-mic random array, 96 kHz (L = 960, w = 24), G = 90, T = 2000."""
+    np.random.seed(1)
+    geometry = Random2DArray(radius=0.2, num_mic=16)
+    fs = 96_000
+    fr = [1000.0, 2000.0]
+    tau = 1 / (2 * np.pi * fr[1])
+    beamf = SNNBeamformer(geometry, 10e-3, fr, [tau, tau], bipolar_spikes=True, fs=fs)
+    rng = np.random.RandomState(5)
+    G = 90
+    bf_mat = rng.randn(32, G)
+    bf_mat /= np.linalg.norm(bf_mat, axis=0, keepdims=True)
+    T = 2000
+    time_vec = np.arange(T) / fs
+    d = geometry.delays(1.234, normalized=True)
+    sig = np.sin(2 * np.pi * 1500 * (time_vec.reshape(-1, 1) - d.reshape(1, -1))) + 0.5 * rng.randn(T, 16)
+    cap = capture_chain(beamf, bf_mat, time_vec, sig)
+    y = cap["y"]
+    power = np.mean(np.abs(y) ** 2, axis=0)
+    row_idx = np.array([0, 479, 480, 481, 1999])
+    save("wide_case.npz", r_vec=geometry.r_vec, theta_vec=geometry.theta_vec, bf_mat=bf_mat, sig_in=sig, time_vec=time_vec,
+         spikes=cap["spikes"].astype(np.int8), pre_enc_head=cap["pre_enc"][:1100], power=power, argmax=np.int64(np.argmax(power)),
+         y_rows=y[row_idx], row_idx=row_idx, fs=np.int64(fs))
+
+
+def gen_unipolar_trial():
+    f = 2000
+    geometry = CenterCircularArray(radius=4.5e-2, num_mic=7)
+    fs = 48_000
+    tau = 1 / (2 * np.pi * f)
+    beamf = SNNBeamformer(geometry, 10e-3, [0.5 * f, 2 * f], np.asarray([tau, tau]), bipolar_spikes=False, fs=fs)
+    z = np.load(os.path.join(OUT, "bf_mat_sin225_unipolar.npz"))
+    bf_mat = z["bf_mat_f2000"]
+    time_test = np.arange(0, 50e-3, step=1 / fs)
+    sig_test = np.sin(2 * np.pi * f * time_test)
+    np.random.seed(77)
+    doa = 0.4321
+    cap_in = {}
+    orig_apply = beamf.apply_to_signal
+
+    def spy(bf_mat, sig_in_vec):
+        cap_in["sig"] = np.array(sig_in_vec[1], copy=True)
+        cap = capture_chain_cls(beamf, orig_apply, bf_mat, sig_in_vec)
+        cap_in.update(cap)
+        return cap["y"]
+
+    beamf.apply_to_signal = spy
+    try:
+        y = beamf.apply_to_template(bf_mat=bf_mat, template=(time_test, sig_test, doa), snr_db=10.0)
+    finally:
+        del beamf.apply_to_signal
+    power = np.mean(np.abs(y) ** 2, axis=0)
+    save("unipolar_trial.npz", doa=np.float64(doa), snr_db=np.float64(10.0), seed=np.int64(77), sig_in=cap_in["sig"],
+         spikes=cap_in["spikes"].astype(np.int8), power=power, argmax=np.int64(np.argmax(power)))
+
+
+def gen_synth():
+    """Noise-free synthesis (snn_beamformer.py:239-267, beamformer.py:220-245) incl. a moving DoA."""
+    beamf, geometry, fs, fd, fr = cfg2_beamformer(True)
+    time_test = np.arange(0, 20e-3, step=1 / fs)
+    sig_test = np.sin(2 * np.pi * fd * time_test) * np.hanning(len(time_test))
+    out = {}
+    for name, doa in [("fixed", 1.2345), ("moving", np.linspace(0.2, 2.9, len(time_test)))]:
+        cap = {}
+
+        def spy(bf_mat, sig_in_vec):
+            cap["time"] = np.array(sig_in_vec[0], copy=True)
+            cap["sig"] = np.array(sig_in_vec[1], copy=True)
+            return np.zeros((1, 1))
+
+        beamf.apply_to_signal = spy
+        try:
+            # snr_db = +inf dB is not possible; use 300 dB (noise 1e-15 relative) and fixed seed
+            np.random.seed(3)
+            beamf.apply_to_template(bf_mat=np.zeros((14, 3)), template=(time_test, sig_test, doa), snr_db=3000.0)
+        finally:
+            del beamf.apply_to_signal
+        out[f"{name}_sig"] = cap["sig"]
+        out[f"{name}_time"] = cap["time"]
+        out[f"{name}_doa"] = np.asarray(doa, dtype=np.float64)
+    out["time_test"] = time_test
+    out["sig_test"] = sig_test
+    save("synth.npz", **out)
+
+
+def gen_filterbank():
+    """ButterworthFilterbank(order=1) + STHT + RZCC as in Demo.spike_encoding
+    (micloc/xylo_snn_localization.py:315-356), restated from the reference's own components because
+    that module cannot be imported here (rockpool is not installed)."""
+    beamf, geometry, fs, fd, fr = cfg2_beamformer(True)
+    fb = ButterworthFilterbank(freq_bands=[[1000, 2000]], order=1, fs=fs)
+    rng = np.random.RandomState(11)
+    T = 3000
+    sig = np.sin(2 * np.pi * 1600 * np.arange(T).reshape(-1, 1) / fs + np.arange(7).reshape(1, -1)) + 0.3 * rng.randn(T, 7)
+    from scipy.signal import lfilter
+
+    sig_h = np.roll(sig, beamf.kernel_length // 2, axis=0) + 1j * lfilter(beamf.kernel, [1], sig, axis=0)
+    sig_real = np.hstack([np.real(sig_h), np.imag(sig_h)])
+    filt = fb.evolve(sig_real)[0]
+    spikes = beamf.spk_encoder.evolve(filt).astype(np.int64)
+    pos = (spikes > 0).astype(np.int64)
+    neg = (spikes < 0).astype(np.int64)
+    spikes_in = np.hstack([pos, neg])
+    b, a = fb.ba_list[0]
+    save("filterbank.npz", sig_in=sig, b=b, a=a, filt_head=filt[:800], spikes_in=spikes_in.astype(np.int8))
+
+
+GENS = {
+    "kat_init": gen_kat_init,
+    "bf_mat_chirp": gen_bf_mat_chirp,
+    "bf_mat_unipolar": gen_bf_mat_unipolar,
+    "trials_cfg2": gen_trials_cfg2,
+    "sweep_seed0": gen_sweep_seed0,
+    "rzcc_edge": gen_rzcc_edge,
+    "beamformer_c128": gen_beamformer_c128,
+    "wide_case": gen_wide_case,
+    "unipolar_trial": gen_unipolar_trial,
+    "synth": gen_synth,
+    "filterbank": gen_filterbank,
+}
+
+if __name__ == "__main__":
+    names = sys.argv[1:] or list(GENS)
+    for n in names:
+        GENS[n]()
