@@ -1,0 +1,98 @@
+"""ctypes binding of libmicloc_hip.so (the C-ABI declared in include/micloc_hip.h).
+
+There is deliberately NO fallback: if the HIP library is missing or a call fails, this module raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmicloc_hip.so")
+
+MICLOC_OK = 0
+MICLOC_ERR_INVALID = -1
+MICLOC_ERR_SHAPE = -2
+MICLOC_ERR_WORKSPACE = -3
+MICLOC_ERR_NOT_SET = -4
+MICLOC_ERR_HIP = -5
+MICLOC_ERR_NO_DEVICE = -6
+MICLOC_MAX_IIR = 9
+
+c_double_p = ctypes.POINTER(ctypes.c_double)
+c_void_p = ctypes.c_void_p
+c_int = ctypes.c_int
+c_size_t = ctypes.c_size_t
+
+
+class MiclocConfig(ctypes.Structure):
+    _fields_ = [
+        ("device", c_int),
+        ("num_mic", c_int),
+        ("stht_len", c_int),
+        ("stht_kernel", c_double_p),
+        ("iir_len", c_int),
+        ("iir_b", c_double_p),
+        ("iir_a", c_double_p),
+        ("robust_width", c_int),
+        ("bipolar", c_int),
+    ]
+
+
+# every symbol include/micloc_hip.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "micloc_plan_create": (c_int, [ctypes.POINTER(MiclocConfig), ctypes.POINTER(c_void_p)]),
+    "micloc_plan_destroy": (None, [c_void_p]),
+    "micloc_plan_set_neuron_kernel": (c_int, [c_void_p, c_double_p, c_int]),
+    "micloc_plan_set_bf_mat": (c_int, [c_void_p, c_double_p, c_int, c_int]),
+    "micloc_plan_set_bf_mat_c128": (c_int, [c_void_p, c_double_p, c_double_p, c_int, c_int]),
+    "micloc_padded_T": (c_int, [c_int]),
+    "micloc_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),
+    "micloc_stht_f64": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "micloc_bandpass_rzcc_f64": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "micloc_lif_beamform_f64": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "micloc_beamform_c128_f64": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "micloc_snn_pipeline_f64": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "micloc_beamformer_pipeline_f64": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "micloc_rzcc_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "micloc_rzcc_encode_f64": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "micloc_lfilter_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "micloc_lfilter_f64": (c_int, [c_double_p, c_double_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "micloc_abi_version": (c_int, []),
+    "micloc_status_string": (ctypes.c_char_p, [c_int]),
+    "micloc_last_hip_error": (c_int, []),
+}
+
+_lib = None
+
+
+class MiclocError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libmicloc_hip.so; raises if it has not been built (python __graft_entry__.py build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MiclocError(
+                f"{LIB_PATH} not found: build it with `make -C haghighatshoarmuir2024_amd/csrc` "
+                "(or __graft_entry__.build()); there is no CPU fallback"
+            )
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(status, what=""):
+    if status == MICLOC_OK:
+        return
+    lib = load()
+    msg = lib.micloc_status_string(status).decode()
+    if status == MICLOC_ERR_HIP:
+        msg += f" [hipError_t {lib.micloc_last_hip_error()}]"
+    if status == MICLOC_ERR_SHAPE:
+        raise ValueError(f"micloc {what}: {msg}")
+    raise MiclocError(f"micloc {what}: {msg} (status {status})")

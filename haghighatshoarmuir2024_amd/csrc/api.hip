@@ -1,0 +1,463 @@
+// C-ABI of libmicloc_hip.so (see include/micloc_hip.h for the contract and reference citations).
+#include <math.h>
+#include <string.h>
+
+#include <new>
+#include <vector>
+
+#include "micloc_internal.h"
+
+using namespace micloc;
+
+static thread_local int g_last_hip = 0;
+
+#define HIP_TRY(expr)                   \
+    do {                                \
+        hipError_t _e = (expr);         \
+        if (_e != hipSuccess) {         \
+            g_last_hip = (int)_e;       \
+            return MICLOC_ERR_HIP;      \
+        }                               \
+    } while (0)
+
+static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+struct micloc_plan {
+    int device = 0;
+    int M = 0, C = 0, L = 0;
+    int robust_width = 1, bipolar = 0;
+    IirCoef iir{};
+    // STHT taps
+    double *d_taps = nullptr;
+    SthtTaps taps{};
+    // neuron kernel
+    double *d_ntab = nullptr;
+    NeuronTab ntab{};
+    // beamforming matrices
+    double *d_W = nullptr;
+    BeamformW W{};
+    int W_is_complex = 0;
+    int G_out = 0;  // DoA grid size seen by the caller
+};
+
+namespace {
+
+struct DeviceGuard {
+    int prev = -1;
+    bool changed = false;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) == hipSuccess && prev != dev) {
+            changed = hipSetDevice(dev) == hipSuccess;
+        }
+    }
+    ~DeviceGuard()
+    {
+        if (changed) (void)hipSetDevice(prev);
+    }
+};
+
+int upload(double **dptr, const std::vector<double> &host)
+{
+    if (*dptr) {
+        HIP_TRY(hipFree(*dptr));
+        *dptr = nullptr;
+    }
+    const size_t bytes = (host.empty() ? 1 : host.size()) * sizeof(double);
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(dptr), bytes));
+    if (!host.empty()) HIP_TRY(hipMemcpy(*dptr, host.data(), host.size() * sizeof(double), hipMemcpyHostToDevice));
+    return MICLOC_OK;
+}
+
+int pad_ct(int C)
+{
+    int ct = (C + 15) / 16;
+    if (ct > 4 && ct <= 8) ct = 8;
+    return ct;
+}
+
+struct WsLayout {
+    size_t h, pre, scratch, spikes, partial, total;
+};
+
+WsLayout ws_layout(const micloc_plan *p, int B, int T)
+{
+    WsLayout w{};
+    const size_t Ts = (size_t)micloc_padded_T(T);
+    const size_t planar = align256((size_t)B * p->C * Ts * sizeof(double));
+    int Gp = p->W.GT > 0 ? 16 * p->W.GT : 16;
+    size_t off = 0;
+    w.h = off;
+    off += planar;
+    w.pre = off;
+    off += planar;
+    w.scratch = off;
+    off += rzcc_scratch_bytes(B * p->C, T);
+    w.spikes = off;
+    off += align256((size_t)B * T * p->C);
+    w.partial = off;
+    off += beamform_partial_bytes(B, T, Gp);
+    w.total = off;
+    return w;
+}
+
+bool bad_ws(const void *ws, size_t have, size_t need)
+{
+    return ws == nullptr || have < need || (reinterpret_cast<uintptr_t>(ws) & 255) != 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int micloc_abi_version(void) { return MICLOC_ABI_VERSION; }
+
+int micloc_last_hip_error(void) { return g_last_hip; }
+
+const char *micloc_status_string(int status)
+{
+    switch (status) {
+        case MICLOC_OK: return "ok";
+        case MICLOC_ERR_INVALID: return "invalid argument";
+        case MICLOC_ERR_SHAPE: return "shape mismatch";
+        case MICLOC_ERR_WORKSPACE: return "workspace too small or misaligned (256-byte alignment required)";
+        case MICLOC_ERR_NOT_SET: return "neuron kernel or beamforming matrix not set on the plan";
+        case MICLOC_ERR_HIP: return "HIP runtime error (see micloc_last_hip_error)";
+        case MICLOC_ERR_NO_DEVICE: return "no usable HIP device";
+        default: return "unknown status";
+    }
+}
+
+int micloc_padded_T(int T) { return T <= 0 ? 8 : (T + 7) & ~7; }
+
+int micloc_plan_create(const micloc_config *cfg, micloc_plan **out)
+{
+    if (!cfg || !out) return MICLOC_ERR_INVALID;
+    *out = nullptr;
+    if (cfg->num_mic <= 0 || cfg->stht_len <= 0 || !cfg->stht_kernel) return MICLOC_ERR_INVALID;
+    if (cfg->iir_len < 1 || cfg->iir_len > MICLOC_MAX_IIR || !cfg->iir_b || !cfg->iir_a) return MICLOC_ERR_INVALID;
+    if (cfg->iir_a[0] == 0.0 || cfg->robust_width < 1) return MICLOC_ERR_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev)
+        return MICLOC_ERR_NO_DEVICE;
+
+    micloc_plan *p = new (std::nothrow) micloc_plan();
+    if (!p) return MICLOC_ERR_INVALID;
+    p->device = cfg->device;
+    p->M = cfg->num_mic;
+    p->C = 2 * cfg->num_mic;
+    p->L = cfg->stht_len;
+    p->robust_width = cfg->robust_width;
+    p->bipolar = cfg->bipolar ? 1 : 0;
+    p->iir.n = cfg->iir_len;
+    for (int i = 0; i < MICLOC_MAX_IIR; ++i) {
+        p->iir.b[i] = i < cfg->iir_len ? cfg->iir_b[i] / cfg->iir_a[0] : 0.0;
+        p->iir.a[i] = i < cfg->iir_len ? cfg->iir_a[i] / cfg->iir_a[0] : 0.0;
+    }
+
+    // compact tap table: delays klo, klo + kstep, ... ; exact-zero taps are dropped when every second tap is zero
+    const int L = cfg->stht_len;
+    int klo = -1, khi = -1;
+    for (int k = 0; k < L; ++k)
+        if (cfg->stht_kernel[k] != 0.0) {
+            if (klo < 0) klo = k;
+            khi = k;
+        }
+    SthtTaps tp{};
+    std::vector<double> compact;
+    if (klo < 0) {
+        tp.klo = 0;
+        tp.kstep = 2;
+        tp.ngroups = 0;
+    } else {
+        bool stride2 = true;
+        for (int k = klo; k <= khi; ++k)
+            if (((k - klo) & 1) && cfg->stht_kernel[k] != 0.0) stride2 = false;
+        tp.kstep = stride2 ? 2 : 1;
+        tp.klo = klo;
+        const int ntaps = (khi - klo) / tp.kstep + 1;
+        const int U = 8 / tp.kstep;
+        tp.ngroups = (ntaps + U - 1) / U;
+        compact.assign((size_t)tp.ngroups * U, 0.0);
+        for (int j = 0; j < ntaps; ++j) compact[j] = cfg->stht_kernel[klo + j * tp.kstep];
+    }
+    {
+        const int U = 8 / tp.kstep;
+        const int kmax = tp.klo + (tp.ngroups * U > 0 ? (tp.ngroups * U - 1) * tp.kstep : 0);
+        tp.halo = tp.klo + 8 * ((kmax - tp.klo + 7) / 8);
+        tp.shift = L / 2;
+    }
+    if (stht_lds_bytes(tp, p->M) > 160 * 1024) {
+        delete p;
+        return MICLOC_ERR_INVALID;  // kernel too long for the LDS-staged tile
+    }
+
+    DeviceGuard guard(p->device);
+    int rc = upload(&p->d_taps, compact);
+    if (rc != MICLOC_OK) {
+        delete p;
+        return rc;
+    }
+    tp.taps = p->d_taps;
+    p->taps = tp;
+    *out = p;
+    return MICLOC_OK;
+}
+
+void micloc_plan_destroy(micloc_plan *p)
+{
+    if (!p) return;
+    DeviceGuard guard(p->device);
+    if (p->d_taps) (void)hipFree(p->d_taps);
+    if (p->d_ntab) (void)hipFree(p->d_ntab);
+    if (p->d_W) (void)hipFree(p->d_W);
+    delete p;
+}
+
+int micloc_plan_set_neuron_kernel(micloc_plan *p, const double *nir, int n)
+{
+    if (!p || !nir || n < 1) return MICLOC_ERR_INVALID;
+    const int NK = (n + 15 + 3) / 4;
+    if ((size_t)(BF_CHUNK + 4 * NK) * 16 * pad_ct(p->C) > 96 * 1024) return MICLOC_ERR_INVALID;  // spike tile must fit in LDS
+    std::vector<double> tab((size_t)4 * NK + 16, 0.0);
+    for (int k = 0; k < n; ++k) tab[(size_t)k + 15] = nir[k];
+    DeviceGuard guard(p->device);
+    // the table may be in use by queued kernels: replace it only after the device went idle
+    HIP_TRY(hipDeviceSynchronize());
+    int rc = upload(&p->d_ntab, tab);
+    if (rc != MICLOC_OK) return rc;
+    p->ntab.tab = p->d_ntab;
+    p->ntab.n = n;
+    p->ntab.NK = NK;
+    return MICLOC_OK;
+}
+
+static int set_W(micloc_plan *p, const std::vector<double> &Wp, int CT, int GT, int C, int Gcols, int is_complex,
+                 int G_out)
+{
+    DeviceGuard guard(p->device);
+    HIP_TRY(hipDeviceSynchronize());
+    int rc = upload(&p->d_W, Wp);
+    if (rc != MICLOC_OK) return rc;
+    p->W.Wp = p->d_W;
+    p->W.CT = CT;
+    p->W.GT = GT;
+    p->W.C = C;
+    p->W.G = Gcols;
+    p->W.complex_pairs = is_complex;
+    p->W_is_complex = is_complex;
+    p->G_out = G_out;
+    return MICLOC_OK;
+}
+
+int micloc_plan_set_bf_mat(micloc_plan *p, const double *W, int C, int G)
+{
+    if (!p || !W || G < 1) return MICLOC_ERR_INVALID;
+    if (C != p->C) return MICLOC_ERR_SHAPE;
+    const int CT = pad_ct(C);
+    if (CT > 8) return MICLOC_ERR_INVALID;
+    const int GT = (G + 15) / 16;
+    const int Gp = 16 * GT;
+    std::vector<double> Wp((size_t)16 * CT * Gp, 0.0);
+    for (int c = 0; c < C; ++c)
+        for (int g = 0; g < G; ++g) Wp[(size_t)c * Gp + g] = W[(size_t)c * G + g];
+    return set_W(p, Wp, CT, GT, C, G, 0, G);
+}
+
+int micloc_plan_set_bf_mat_c128(micloc_plan *p, const double *Wre, const double *Wim, int M, int G)
+{
+    if (!p || !Wre || !Wim || G < 1) return MICLOC_ERR_INVALID;
+    if (M != p->M) return MICLOC_ERR_SHAPE;
+    const int C = 2 * M;
+    const int CT = pad_ct(C);
+    if (CT > 8) return MICLOC_ERR_INVALID;
+    const int Ghp = 16 * ((G + 15) / 16);
+    const int Gp = 2 * Ghp;
+    // (hr + j hi)(wr - j wi):  re = [hr hi] . [wr; wi]   im = [hr hi] . [-wi; wr]
+    std::vector<double> Wp((size_t)16 * CT * Gp, 0.0);
+    for (int m = 0; m < M; ++m)
+        for (int g = 0; g < G; ++g) {
+            const double wr = Wre[(size_t)m * G + g], wi = Wim[(size_t)m * G + g];
+            Wp[(size_t)m * Gp + g] = wr;
+            Wp[(size_t)(M + m) * Gp + g] = wi;
+            Wp[(size_t)m * Gp + Ghp + g] = -wi;
+            Wp[(size_t)(M + m) * Gp + Ghp + g] = wr;
+        }
+    return set_W(p, Wp, CT, Gp / 16, C, 2 * G, 1, G);
+}
+
+size_t micloc_workspace_bytes(const micloc_plan *p, int B, int T)
+{
+    if (!p || B < 1 || T < 1) return 0;
+    return ws_layout(p, B, T).total;
+}
+
+// ---- stages ----------------------------------------------------------------------------------------------
+int micloc_stht_f64(const micloc_plan *p, const double *x, int B, int T, double *h, int Ts, void *stream)
+{
+    if (!p || !x || !h || B < 1 || T < 1) return MICLOC_ERR_INVALID;
+    if (Ts != micloc_padded_T(T)) return MICLOC_ERR_SHAPE;
+    HIP_TRY(launch_stht(p->taps, x, h, B, T, p->M, Ts, (hipStream_t)stream));
+    return MICLOC_OK;
+}
+
+int micloc_bandpass_rzcc_f64(const micloc_plan *p, const double *h, int B, int T, int Ts, double *pre,
+                             int8_t *spikes, void *ws, size_t ws_bytes, void *stream)
+{
+    if (!p || !h || B < 1 || T < 1 || (!pre && !spikes)) return MICLOC_ERR_INVALID;
+    if (Ts != micloc_padded_T(T)) return MICLOC_ERR_SHAPE;
+    const int nl = B * p->C;
+    if (spikes && bad_ws(ws, ws_bytes, rzcc_scratch_bytes(nl, T))) return MICLOC_ERR_WORKSPACE;
+    HIP_TRY(launch_bandpass_rzcc(p->iir, h, nl, p->C, T, Ts, p->robust_width, p->bipolar, pre, spikes, ws,
+                                 (hipStream_t)stream));
+    return MICLOC_OK;
+}
+
+int micloc_lif_beamform_f64(const micloc_plan *p, const int8_t *spikes, int B, int T, double *y, double *power,
+                            int32_t *argmax, void *ws, size_t ws_bytes, void *stream)
+{
+    if (!p || !spikes || B < 1 || T < 1 || (!y && !power && !argmax)) return MICLOC_ERR_INVALID;
+    if (!p->d_ntab || !p->d_W) return MICLOC_ERR_NOT_SET;
+    if (p->W_is_complex) return MICLOC_ERR_SHAPE;
+    const int Gp = 16 * p->W.GT;
+    const bool want_power = power || argmax;
+    if (want_power && bad_ws(ws, ws_bytes, beamform_partial_bytes(B, T, Gp))) return MICLOC_ERR_WORKSPACE;
+    double *partial = want_power ? reinterpret_cast<double *>(ws) : nullptr;
+    HIP_TRY(launch_lif_beamform(p->W, p->ntab, spikes, B, T, y, partial, (hipStream_t)stream));
+    if (want_power)
+        HIP_TRY(launch_power_argmax(partial, B, T, beamform_nchunks(T), Gp, p->G_out, 0, 0, power, argmax,
+                                    (hipStream_t)stream));
+    return MICLOC_OK;
+}
+
+int micloc_beamform_c128_f64(const micloc_plan *p, const double *pre, int B, int T, int Ts, double *y, double *power,
+                             int32_t *argmax, void *ws, size_t ws_bytes, void *stream)
+{
+    if (!p || !pre || B < 1 || T < 1 || (!y && !power && !argmax)) return MICLOC_ERR_INVALID;
+    if (Ts != micloc_padded_T(T)) return MICLOC_ERR_SHAPE;
+    if (!p->d_W) return MICLOC_ERR_NOT_SET;
+    if (!p->W_is_complex) return MICLOC_ERR_SHAPE;
+    const int Gp = 16 * p->W.GT;
+    const bool want_power = power || argmax;
+    if (want_power && bad_ws(ws, ws_bytes, beamform_partial_bytes(B, T, Gp))) return MICLOC_ERR_WORKSPACE;
+    double *partial = want_power ? reinterpret_cast<double *>(ws) : nullptr;
+    HIP_TRY(launch_planar_beamform(p->W, pre, B, T, Ts, y, 1, partial, (hipStream_t)stream));
+    if (want_power)
+        HIP_TRY(launch_power_argmax(partial, B, T, beamform_nchunks(T), Gp, p->G_out, 1, Gp / 2, power, argmax,
+                                    (hipStream_t)stream));
+    return MICLOC_OK;
+}
+
+// ---- pipelines -------------------------------------------------------------------------------------------
+int micloc_snn_pipeline_f64(const micloc_plan *p, const double *x, int B, int T, int8_t *spikes, double *y,
+                            double *power, int32_t *argmax, void *ws, size_t ws_bytes, void *stream)
+{
+    if (!p || !x || B < 1 || T < 1 || (!spikes && !y && !power && !argmax)) return MICLOC_ERR_INVALID;
+    const bool want_bf = y || power || argmax;
+    if (want_bf && (!p->d_ntab || !p->d_W)) return MICLOC_ERR_NOT_SET;
+    if (want_bf && p->W_is_complex) return MICLOC_ERR_SHAPE;
+    const WsLayout w = ws_layout(p, B, T);
+    if (bad_ws(ws, ws_bytes, w.total)) return MICLOC_ERR_WORKSPACE;
+    unsigned char *base = reinterpret_cast<unsigned char *>(ws);
+    double *h = reinterpret_cast<double *>(base + w.h);
+    int8_t *spk = spikes ? spikes : reinterpret_cast<int8_t *>(base + w.spikes);
+    const int Ts = micloc_padded_T(T);
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(launch_stht(p->taps, x, h, B, T, p->M, Ts, st));
+    HIP_TRY(launch_bandpass_rzcc(p->iir, h, B * p->C, p->C, T, Ts, p->robust_width, p->bipolar, nullptr, spk,
+                                 base + w.scratch, st));
+    if (want_bf) {
+        const int Gp = 16 * p->W.GT;
+        const bool want_power = power || argmax;
+        double *partial = want_power ? reinterpret_cast<double *>(base + w.partial) : nullptr;
+        HIP_TRY(launch_lif_beamform(p->W, p->ntab, spk, B, T, y, partial, st));
+        if (want_power)
+            HIP_TRY(launch_power_argmax(partial, B, T, beamform_nchunks(T), Gp, p->G_out, 0, 0, power, argmax, st));
+    }
+    return MICLOC_OK;
+}
+
+int micloc_beamformer_pipeline_f64(const micloc_plan *p, const double *x, int B, int T, double *y, double *power,
+                                   int32_t *argmax, void *ws, size_t ws_bytes, void *stream)
+{
+    if (!p || !x || B < 1 || T < 1 || (!y && !power && !argmax)) return MICLOC_ERR_INVALID;
+    if (!p->d_W) return MICLOC_ERR_NOT_SET;
+    if (!p->W_is_complex) return MICLOC_ERR_SHAPE;
+    const WsLayout w = ws_layout(p, B, T);
+    if (bad_ws(ws, ws_bytes, w.total)) return MICLOC_ERR_WORKSPACE;
+    unsigned char *base = reinterpret_cast<unsigned char *>(ws);
+    double *h = reinterpret_cast<double *>(base + w.h);
+    double *pre = reinterpret_cast<double *>(base + w.pre);
+    const int Ts = micloc_padded_T(T);
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(launch_stht(p->taps, x, h, B, T, p->M, Ts, st));
+    HIP_TRY(launch_bandpass_rzcc(p->iir, h, B * p->C, p->C, T, Ts, p->robust_width, p->bipolar, pre, nullptr,
+                                 nullptr, st));
+    const int Gp = 16 * p->W.GT;
+    const bool want_power = power || argmax;
+    double *partial = want_power ? reinterpret_cast<double *>(base + w.partial) : nullptr;
+    HIP_TRY(launch_planar_beamform(p->W, pre, B, T, Ts, y, 1, partial, st));
+    if (want_power)
+        HIP_TRY(launch_power_argmax(partial, B, T, beamform_nchunks(T), Gp, p->G_out, 1, Gp / 2, power, argmax, st));
+    return MICLOC_OK;
+}
+
+// ---- stand-alone operators -------------------------------------------------------------------------------
+size_t micloc_rzcc_workspace_bytes(int B, int T, int C)
+{
+    if (B < 1 || T < 1 || C < 1) return 0;
+    const size_t planar = align256((size_t)B * C * micloc_padded_T(T) * sizeof(double));
+    return planar + rzcc_scratch_bytes(B * C, T);
+}
+
+int micloc_rzcc_encode_f64(const double *sig, int B, int T, int C, int robust_width, int bipolar, int8_t *spikes,
+                           void *ws, size_t ws_bytes, void *stream)
+{
+    if (!sig || !spikes || B < 1 || T < 1 || C < 1 || robust_width < 1) return MICLOC_ERR_INVALID;
+    if (bad_ws(ws, ws_bytes, micloc_rzcc_workspace_bytes(B, T, C))) return MICLOC_ERR_WORKSPACE;
+    const int Ts = micloc_padded_T(T);
+    unsigned char *base = reinterpret_cast<unsigned char *>(ws);
+    double *planar = reinterpret_cast<double *>(base);
+    void *scratch = base + align256((size_t)B * C * Ts * sizeof(double));
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(launch_pack_planar(sig, planar, B, T, C, Ts, st));
+    IirCoef id{};
+    id.n = 1;
+    id.b[0] = 1.0;  // fma(1, x, +0) == x: the identity filter keeps the stream bit-exact
+    id.a[0] = 1.0;
+    HIP_TRY(launch_bandpass_rzcc(id, planar, B * C, C, T, Ts, robust_width, bipolar ? 1 : 0, nullptr, spikes, scratch,
+                                 st));
+    return MICLOC_OK;
+}
+
+size_t micloc_lfilter_workspace_bytes(int B, int T, int C)
+{
+    if (B < 1 || T < 1 || C < 1) return 0;
+    return 2 * align256((size_t)B * C * micloc_padded_T(T) * sizeof(double));
+}
+
+int micloc_lfilter_f64(const double *b, const double *a, int n, const double *x, int B, int T, int C, double *y,
+                       void *ws, size_t ws_bytes, void *stream)
+{
+    if (!b || !a || !x || !y || n < 1 || n > MICLOC_MAX_IIR || B < 1 || T < 1 || C < 1 || a[0] == 0.0)
+        return MICLOC_ERR_INVALID;
+    if (bad_ws(ws, ws_bytes, micloc_lfilter_workspace_bytes(B, T, C))) return MICLOC_ERR_WORKSPACE;
+    const int Ts = micloc_padded_T(T);
+    const size_t planar_bytes = align256((size_t)B * C * Ts * sizeof(double));
+    unsigned char *base = reinterpret_cast<unsigned char *>(ws);
+    double *pin = reinterpret_cast<double *>(base);
+    double *pout = reinterpret_cast<double *>(base + planar_bytes);
+    IirCoef co{};
+    co.n = n;
+    for (int i = 0; i < n; ++i) {
+        co.b[i] = b[i] / a[0];
+        co.a[i] = a[i] / a[0];
+    }
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(launch_pack_planar(x, pin, B, T, C, Ts, st));
+    HIP_TRY(launch_bandpass_rzcc(co, pin, B * C, C, T, Ts, 1, 0, pout, nullptr, nullptr, st));
+    HIP_TRY(launch_unpack_planar(pout, y, B, T, C, Ts, st));
+    return MICLOC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,290 @@
+// Alpha-kernel ("LIF") FIR + beamforming + power for gfx950, on the fp64 matrix cores.
+// Reference: micloc/snn_beamformer.py:364-368 (vmem = lfilter(nir,[1],spikes); vmem @ bf_mat),
+// micloc/beamformer.py:290 (sig @ bf_mat.conj()), paper_plots/target_snn_localization.py:462-464
+// (power = mean |y|^2, argmax).
+//
+// Everything here is v_mfma_f64_16x16x4_f64 (D[16x16] += A[16x4] B[4x16]; lane l holds A[l&15][l>>4],
+// B[l>>4][l&15] and D[(l>>4)+4r][l&15], r = 0..3):
+//   1. LIF as a Toeplitz product, transposed:  V^T[c][t] = sum_tau S^T[c][tau] * N^T[tau][t],
+//      N^T[tau][t] = nir[t - tau].  A = int8 spikes from the LDS tile (converted to fp64), B = a
+//      zero-padded lookup of nir.  The result lands as lane l -> V[t = l&15][c = (l>>4)+4r], which is
+//      *exactly* the A-operand fragment of k-step r of the next product, so the membrane signal never
+//      leaves registers.
+//   2. Beamforming  Y[t][g] = sum_c V[t][c] W[c][g]  with W fragments read from LDS (or L2 when the
+//      matrix is too large), 4 independent time tiles per wave in flight.
+//   3. power: each lane squares its 4 results and keeps a running sum per DoA column; lanes sharing a
+//      column are combined with two xor-shuffles, waves through LDS, time chunks by a second tiny
+//      kernel in a fixed order (deterministic, no atomics).  The T x G product is only written to
+//      HBM when the caller asks for it (API parity with apply_to_signal).
+//
+// Summation order (== oracle): LIF over past samples in chronological order (tau ascending),
+// beamforming over channels ascending; both as fused multiply-add chains starting from +0.
+#include "micloc_internal.h"
+
+namespace micloc {
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+constexpr int BF_THREADS = BF_WAVES * 64;
+
+int beamform_nchunks(int T) { return (T + BF_CHUNK - 1) / BF_CHUNK; }
+
+size_t beamform_partial_bytes(int B, int T, int Gp)
+{
+    return ((size_t)B * beamform_nchunks(T) * Gp * sizeof(double) + 255) & ~(size_t)255;
+}
+
+template <int CT, bool SRC_SPIKES, bool W_LDS>
+__global__ __launch_bounds__(BF_THREADS) void beamform_kernel(const int8_t *__restrict__ spikes,
+                                                               const double *__restrict__ pre,
+                                                               const double *__restrict__ ntab_g, int NK,
+                                                               const double *__restrict__ Wp, int GT, int C, int G,
+                                                               int T, int Ts, double *__restrict__ y, int y_complex,
+                                                               double *__restrict__ partial)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int Kp = 16 * CT;
+    constexpr int Cs = 16 * CT;  // padded spike row (bytes)
+    const int Gp = 16 * GT;
+    const int tid = threadIdx.x;
+    const int wv = tid >> 6;
+    const int l = tid & 63;
+    const int lc = l & 15;  // MFMA column / A row
+    const int q = l >> 4;   // MFMA k index within a k-step
+    const int chunk = blockIdx.x;
+    const int nchunks = gridDim.x;
+    const int b = blockIdx.y;
+    const int cs = chunk * BF_CHUNK;
+
+    // ---- LDS carve-up -----------------------------------------------------------------------------------
+    double *Wl = reinterpret_cast<double *>(smem);
+    double *red = Wl + (W_LDS ? (size_t)Kp * Gp : 0);
+    double *ntab = red + (size_t)BF_WAVES * Gp;
+    const int ntab_len = SRC_SPIKES ? 4 * NK + 16 : 0;
+    int8_t *spk = reinterpret_cast<int8_t *>(ntab + ntab_len);
+    const int R = BF_CHUNK + 4 * NK - 16;  // staged spike rows
+
+    if (W_LDS) {
+        for (int e = tid; e < Kp * Gp; e += BF_THREADS) Wl[e] = Wp[e];
+    }
+    if (SRC_SPIKES) {
+        for (int e = tid; e < ntab_len; e += BF_THREADS) ntab[e] = ntab_g[e];
+        const int8_t *sb = spikes + (size_t)b * T * C;
+        const int tau0 = cs + 16 - 4 * NK;
+        for (int e = tid; e < R * Cs; e += BF_THREADS) {
+            const int rho = e / Cs, c = e % Cs;
+            const int tau = tau0 + rho;
+            int8_t v = 0;
+            if (c < C && tau >= 0 && tau < T) v = sb[(size_t)tau * C + c];
+            spk[e] = v;
+        }
+    }
+    __syncthreads();
+
+    // ---- stage 1: membrane fragments Vf[tt][ct] (4 doubles each) ------------------------------------------
+    double4_t Vf[BF_NT][CT];
+#pragma unroll
+    for (int tt = 0; tt < BF_NT; ++tt) {
+        const int tb = cs + (wv * BF_NT + tt) * 16;
+        const bool tvalid = (tb + lc) < T;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            double4_t acc = {0.0, 0.0, 0.0, 0.0};
+            if (SRC_SPIKES) {
+                if (tb < T) {  // wave-uniform
+                    const int8_t *sp = spk + (size_t)(tb - cs + q) * Cs + 16 * ct + lc;
+                    const double *np_ = ntab + (lc - q + 4 * NK - 16 + 15);
+                    for (int ks = 0; ks < NK; ++ks) {
+                        const double a = (double)sp[(size_t)(4 * ks) * Cs];
+                        const double bn = np_[-4 * ks];
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bn, acc, 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r] = tvalid ? acc[r] : 0.0;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int c = 16 * ct + 4 * r + q;
+                    double v = 0.0;
+                    if (tvalid && c < C) v = pre[((size_t)b * C + c) * Ts + tb + lc];
+                    acc[r] = v;
+                }
+            }
+            Vf[tt][ct] = acc;
+        }
+    }
+
+    // ---- stage 2: beamforming + power, one 16-column DoA tile at a time ------------------------------------
+    const double *Wsrc = W_LDS ? Wl : Wp;
+    const int Ghp = Gp >> 1;  // complex variant: [0, Ghp) real part, [Ghp, Gp) imaginary part
+    for (int gt = 0; gt < GT; ++gt) {
+        double Wf[CT][4];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Wf[ct][r] = Wsrc[(size_t)(16 * ct + 4 * r + q) * Gp + 16 * gt + lc];
+
+        double4_t acc[BF_NT];
+#pragma unroll
+        for (int tt = 0; tt < BF_NT; ++tt) acc[tt] = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int tt = 0; tt < BF_NT; ++tt)
+                    acc[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(Vf[tt][ct][r], Wf[ct][r], acc[tt], 0, 0, 0);
+
+        double sq = 0.0;
+#pragma unroll
+        for (int tt = 0; tt < BF_NT; ++tt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sq = __builtin_fma(acc[tt][r], acc[tt][r], sq);
+
+        if (y) {
+            const int gcol = 16 * gt + lc;
+#pragma unroll
+            for (int tt = 0; tt < BF_NT; ++tt) {
+                const int tb = cs + (wv * BF_NT + tt) * 16;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int t = tb + q + 4 * r;
+                    if (t < T) {
+                        if (!y_complex) {
+                            if (gcol < G) y[((size_t)b * T + t) * G + gcol] = acc[tt][r];
+                        } else {
+                            const int part = gcol >= Ghp;
+                            const int g = gcol - (part ? Ghp : 0);
+                            if (g < (G >> 1)) y[(((size_t)b * T + t) * (G >> 1) + g) * 2 + part] = acc[tt][r];
+                        }
+                    }
+                }
+            }
+        }
+        sq += __shfl_xor(sq, 16);
+        sq += __shfl_xor(sq, 32);
+        if (l < 16) red[(size_t)wv * Gp + 16 * gt + l] = sq;
+    }
+    __syncthreads();
+    if (partial) {
+        double *pout = partial + ((size_t)b * nchunks + chunk) * Gp;
+        for (int g = tid; g < Gp; g += BF_THREADS) {
+            double s = 0.0;
+#pragma unroll
+            for (int w8 = 0; w8 < BF_WAVES; ++w8) s += red[(size_t)w8 * Gp + g];
+            pout[g] = s;
+        }
+    }
+}
+
+template <int CT, bool SRC_SPIKES>
+static hipError_t launch_bf(const BeamformW &W, const NeuronTab *nt, const int8_t *spikes, const double *pre, int B,
+                            int T, int Ts, double *y, int y_complex, double *partial, hipStream_t stream)
+{
+    const int Gp = 16 * W.GT;
+    const int Kp = 16 * CT;
+    const int NK = SRC_SPIKES ? nt->NK : 0;
+    size_t lds = (size_t)BF_WAVES * Gp * sizeof(double);
+    if (SRC_SPIKES) lds += (size_t)(4 * NK + 16) * sizeof(double) + (size_t)(BF_CHUNK + 4 * NK - 16) * 16 * CT;
+    const size_t wbytes = (size_t)Kp * Gp * sizeof(double);
+    const bool w_lds = (lds + wbytes) <= 150 * 1024 && wbytes <= 96 * 1024;
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    dim3 grid(beamform_nchunks(T), B), block(BF_THREADS);
+    const double *tab = SRC_SPIKES ? nt->tab : nullptr;
+    hipError_t e;
+    if (w_lds) {
+        auto k = &beamform_kernel<CT, SRC_SPIKES, true>;
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k, grid, block, lds + wbytes, stream, spikes, pre, tab, NK, W.Wp, W.GT, W.C, W.G, T, Ts, y,
+                           y_complex, partial);
+    } else {
+        auto k = &beamform_kernel<CT, SRC_SPIKES, false>;
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k, grid, block, lds, stream, spikes, pre, tab, NK, W.Wp, W.GT, W.C, W.G, T, Ts, y,
+                           y_complex, partial);
+    }
+    return hipGetLastError();
+}
+
+template <bool SRC_SPIKES>
+static hipError_t dispatch_ct(const BeamformW &W, const NeuronTab *nt, const int8_t *spikes, const double *pre, int B,
+                              int T, int Ts, double *y, int y_complex, double *partial, hipStream_t stream)
+{
+    switch (W.CT) {
+        case 1: return launch_bf<1, SRC_SPIKES>(W, nt, spikes, pre, B, T, Ts, y, y_complex, partial, stream);
+        case 2: return launch_bf<2, SRC_SPIKES>(W, nt, spikes, pre, B, T, Ts, y, y_complex, partial, stream);
+        case 3: return launch_bf<3, SRC_SPIKES>(W, nt, spikes, pre, B, T, Ts, y, y_complex, partial, stream);
+        case 4: return launch_bf<4, SRC_SPIKES>(W, nt, spikes, pre, B, T, Ts, y, y_complex, partial, stream);
+        case 8: return launch_bf<8, SRC_SPIKES>(W, nt, spikes, pre, B, T, Ts, y, y_complex, partial, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_lif_beamform(const BeamformW &W, const NeuronTab &nt, const int8_t *spikes, int B, int T, double *y,
+                               double *partial, hipStream_t stream)
+{
+    return dispatch_ct<true>(W, &nt, spikes, nullptr, B, T, 0, y, 0, partial, stream);
+}
+
+hipError_t launch_planar_beamform(const BeamformW &W, const double *pre, int B, int T, int Ts, double *y,
+                                  int y_complex, double *partial, hipStream_t stream)
+{
+    return dispatch_ct<false>(W, nullptr, nullptr, pre, B, T, Ts, y, y_complex, partial, stream);
+}
+
+// ---- chunk reduction, mean over time, arg-max (first maximum, like np.argmax) --------------------------------
+__global__ __launch_bounds__(256) void power_argmax_kernel(const double *__restrict__ partial, int T, int nchunks,
+                                                            int Gp, int G, int complex_pairs, int Ghp,
+                                                            double *__restrict__ power, int32_t *__restrict__ argmax)
+{
+    __shared__ double sv[256];
+    __shared__ int si[256];
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x;
+    const double *pb = partial + (size_t)b * nchunks * Gp;
+    double best = -1.0;
+    int bi = 0x7fffffff;
+    for (int g = tid; g < G; g += 256) {
+        double s = 0.0;
+        for (int ch = 0; ch < nchunks; ++ch) {
+            s += pb[(size_t)ch * Gp + g];
+            if (complex_pairs) s += pb[(size_t)ch * Gp + Ghp + g];
+        }
+        const double p = s / (double)T;
+        if (power) power[(size_t)b * G + g] = p;
+        if (p > best) {
+            best = p;
+            bi = g;
+        }
+    }
+    sv[tid] = best;
+    si[tid] = bi;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) {
+            const double ov = sv[tid + s];
+            const int oi = si[tid + s];
+            if (ov > sv[tid] || (ov == sv[tid] && oi < si[tid])) {
+                sv[tid] = ov;
+                si[tid] = oi;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0 && argmax) argmax[b] = si[0] == 0x7fffffff ? 0 : si[0];
+}
+
+hipError_t launch_power_argmax(const double *partial, int B, int T, int nchunks, int Gp, int G, int complex_pairs,
+                               int Ghalf_pad, double *power, int32_t *argmax, hipStream_t stream)
+{
+    hipLaunchKernelGGL(power_argmax_kernel, dim3(B), dim3(256), 0, stream, partial, T, nchunks, Gp, G, complex_pairs,
+                       Ghalf_pad, power, argmax);
+    return hipGetLastError();
+}
+
+}  // namespace micloc

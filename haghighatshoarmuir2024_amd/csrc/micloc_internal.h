@@ -1,0 +1,73 @@
+// Internal declarations shared by the HIP translation units of libmicloc_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/micloc_hip.h"
+
+namespace micloc {
+
+// ---- STHT ---------------------------------------------------------------------------------------
+constexpr int STHT_TILE = 512;  // outputs per wave-task: 64 lanes x 8 consecutive samples
+constexpr int STHT_MAX_MB = 8;  // mics per block (one wave each)
+
+struct SthtTaps {
+    // compact tap table on device: taps[j] = ker[klo + j * kstep], zero padded to a multiple of 8/kstep
+    const double *taps;
+    int ngroups;  // number of groups of (8 / kstep) taps
+    int klo;      // delay of the first tap
+    int kstep;    // 1 or 2
+    int halo;     // Hh: samples staged before the tile; Hh == klo (mod 8), Hh >= largest delay
+    int shift;    // L / 2 (np.roll amount)
+};
+
+hipError_t launch_stht(const SthtTaps &tp, const double *x, double *h, int B, int T, int M, int Ts,
+                       hipStream_t stream);
+size_t stht_lds_bytes(const SthtTaps &tp, int M);
+
+// ---- band-pass + RZCC ---------------------------------------------------------------------------
+struct IirCoef {
+    double b[MICLOC_MAX_IIR];
+    double a[MICLOC_MAX_IIR];
+    int n;
+};
+
+// per-lane candidate lists (slot-major): pos [2][cap][nlanes] int32, val [2][cap][nlanes] double
+size_t rzcc_scratch_bytes(int nlanes, int T);
+hipError_t launch_bandpass_rzcc(const IirCoef &coef, const double *h, int nlanes, int C, int T, int Ts,
+                                int robust_width, int bipolar, double *pre, int8_t *spikes, void *scratch,
+                                hipStream_t stream);
+// row-major [B][T][C] <-> planar [B][C][Ts]
+hipError_t launch_pack_planar(const double *src, double *dst, int B, int T, int C, int Ts, hipStream_t stream);
+hipError_t launch_unpack_planar(const double *src, double *dst, int B, int T, int C, int Ts, hipStream_t stream);
+
+// ---- LIF + beamforming --------------------------------------------------------------------------
+constexpr int BF_WAVES = 8;                         // waves per block
+constexpr int BF_NT = 4;                            // 16-frame tiles per wave
+constexpr int BF_CHUNK = BF_WAVES * BF_NT * 16;     // frames per block (512)
+
+struct BeamformW {
+    const double *Wp;  // device, zero padded [Kp][Gp] row-major; Kp = 16 * CT, Gp = 16 * GT
+    int CT, GT;
+    int C, G;          // logical sizes (G counts real columns: 2 * G_complex for the complex variant)
+    int complex_pairs; // 0: real bf_mat; 1: columns [0,G/2) are Re, [Gp/2 ...) see api
+};
+
+struct NeuronTab {
+    const double *tab;  // device: zero padded Toeplitz lookup, see beamform.hip
+    int n;              // taps
+    int NK;             // k-steps of 4 past samples: 4 * NK >= n + 15
+};
+
+// partial sums: [B][nchunks][Gp] doubles
+size_t beamform_partial_bytes(int B, int T, int Gp);
+hipError_t launch_lif_beamform(const BeamformW &W, const NeuronTab &nt, const int8_t *spikes, int B, int T,
+                               double *y, double *partial, hipStream_t stream);
+hipError_t launch_planar_beamform(const BeamformW &W, const double *pre, int B, int T, int Ts, double *y,
+                                  int y_complex, double *partial, hipStream_t stream);
+hipError_t launch_power_argmax(const double *partial, int B, int T, int nchunks, int Gp, int G, int complex_pairs,
+                               int Ghalf_pad, double *power, int32_t *argmax, hipStream_t stream);
+int beamform_nchunks(int T);
+
+}  // namespace micloc

@@ -1,0 +1,165 @@
+// STHT kernel for gfx950: in-phase = circular roll by L/2, quadrature = causal FIR with the Hilbert
+// kernel (reference: micloc/snn_beamformer.py:325-327, micloc/beamformer.py:281-283).
+//
+// Mapping (wave64): one block = one trial x one 512-sample time tile x up to 8 microphones; each wave
+// owns one microphone, each lane 8 consecutive output samples (8 independent fp64 FMA chains).  The
+// (tile + halo) x mics frame block is read once from HBM with coalesced loads ([t][mic] rows are
+// contiguous) and transposed into per-microphone LDS rows.  The per-lane 8-sample sliding window
+// lives in registers; every tap costs one 16-byte LDS read (kstep 2) and 8 v_fma_f64, the tap value
+// comes from a scalar load.  Rows are skewed by 16 B every 64 B so the 64-B lane stride is
+// conflict-free for ds_read_b128.
+//
+// Arithmetic contract (== oracle/micloc_oracle.c oracle_stht): acc = +0; for taps k ascending:
+// acc = fma(ker[k], x[t-k], acc); exact-zero taps contribute nothing (skipped when every second tap
+// is zero, which is the case for every even-length Hilbert kernel).
+#include "micloc_internal.h"
+
+namespace micloc {
+
+__device__ __forceinline__ int skew(int q) { return q + 2 * (q >> 3); }
+
+template <int S>
+__global__ __launch_bounds__(64 * STHT_MAX_MB) void stht_kernel(const double *__restrict__ x,
+                                                                 double *__restrict__ h,
+                                                                 const double *__restrict__ taps, int ngroups,
+                                                                 int klo, int halo, int shift, int T, int M,
+                                                                 int Ts, int MB, int rowstride)
+{
+    extern __shared__ __attribute__((aligned(16))) double Xs[];
+    constexpr int U = 8 / S;
+    const int tid = threadIdx.x;
+    const int t0 = blockIdx.x * STHT_TILE;
+    const int m0 = blockIdx.y * MB;
+    const int b = blockIdx.z;
+    const int N = 8 + halo + STHT_TILE;
+    const int tq0 = t0 - halo - 8;  // global time of logical LDS index 0
+    const double *xb = x + (size_t)b * T * M;
+
+    // ---- stage (tile + halo) x MB mics, transposed to per-mic rows, zero outside [0, T) ----------
+    {
+        const int mm = tid % MB;
+        const int m = m0 + mm;
+        double *row = Xs + (size_t)mm * rowstride;
+        for (int q = tid / MB; q < N; q += 64) {
+            const int t = tq0 + q;
+            double v = 0.0;
+            if (t >= 0 && t < T && m < M) v = xb[(size_t)t * M + m];
+            row[skew(q)] = v;
+        }
+    }
+    __syncthreads();
+
+    const int wv = tid >> 6;
+    const int lane = tid & 63;
+    const int m = m0 + wv;
+    const int tb = t0 + lane * 8;
+    if (m >= M || tb >= T) return;
+    const double *row = Xs + (size_t)wv * rowstride;
+
+    // ---- quadrature: FIR over the sliding register window -------------------------------------------
+    double acc[8];
+    double w[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) acc[r] = 0.0;
+    int j = lane * 8 + (halo + 8 - klo);  // logical index of x[tb - klo]; j % 8 == 0
+    int pj = skew(j);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) w[r] = row[pj + r];
+    for (int g = 0; g < ngroups; ++g) {
+        pj -= 10;  // skew(j - 8)
+        double tp[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) tp[u] = taps[g * U + u];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            double nx[S];
+#pragma unroll
+            for (int e = 0; e < S; ++e) nx[e] = row[pj + (8 - (u + 1) * S + e)];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) acc[r] = __builtin_fma(tp[u], w[(r - u * S) & 7], acc[r]);
+#pragma unroll
+            for (int e = 0; e < S; ++e) w[(8 - (u + 1) * S + e) & 7] = nx[e];
+        }
+    }
+
+    const int C = 2 * M;
+    double *him = h + ((size_t)b * C + M + m) * Ts + tb;
+#pragma unroll
+    for (int r = 0; r < 8; r += 2) {
+        double2 v2 = make_double2(acc[r], acc[r + 1]);
+        *reinterpret_cast<double2 *>(him + r) = v2;
+    }
+
+    // ---- in-phase: np.roll(x, shift, axis=0) --------------------------------------------------------
+    const int sh = shift % T;
+    double re[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int t = tb + r;
+        double v = 0.0;
+        if (t < T) {
+            int src = t - sh;
+            if (src < 0) src += T;
+            const int q = src - tq0;
+            if (q >= 0 && src <= t)
+                v = row[skew(q)];
+            else
+                v = xb[(size_t)src * M + m];
+        }
+        re[r] = v;
+    }
+    double *hre = h + ((size_t)b * C + m) * Ts + tb;
+#pragma unroll
+    for (int r = 0; r < 8; r += 2) {
+        double2 v2 = make_double2(re[r], re[r + 1]);
+        *reinterpret_cast<double2 *>(hre + r) = v2;
+    }
+}
+
+static int stht_rowstride(const SthtTaps &tp)
+{
+    const int N = 8 + tp.halo + STHT_TILE;
+    int np = N + 2 * ((N + 7) >> 3) + 2;
+    np = (np + 1) & ~1;  // keep rows 16-byte aligned
+    return np + 2;       // +16 B so consecutive mic rows start on different bank groups
+}
+
+size_t stht_lds_bytes(const SthtTaps &tp, int M)
+{
+    const int MB = M < STHT_MAX_MB ? M : STHT_MAX_MB;
+    return (size_t)MB * stht_rowstride(tp) * sizeof(double);
+}
+
+hipError_t launch_stht(const SthtTaps &tp, const double *x, double *h, int B, int T, int M, int Ts,
+                       hipStream_t stream)
+{
+    const int MB = M < STHT_MAX_MB ? M : STHT_MAX_MB;
+    const int rowstride = stht_rowstride(tp);
+    const size_t lds = (size_t)MB * rowstride * sizeof(double);
+    dim3 grid((T + STHT_TILE - 1) / STHT_TILE, (M + MB - 1) / MB, B);
+    dim3 block(64 * MB);
+    if (tp.kstep == 2) {
+        static bool attr2 = false;
+        if (!attr2) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&stht_kernel<2>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            attr2 = true;
+        }
+        hipLaunchKernelGGL(stht_kernel<2>, grid, block, lds, stream, x, h, tp.taps, tp.ngroups, tp.klo, tp.halo,
+                           tp.shift, T, M, Ts, MB, rowstride);
+    } else {
+        static bool attr1 = false;
+        if (!attr1) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&stht_kernel<1>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            attr1 = true;
+        }
+        hipLaunchKernelGGL(stht_kernel<1>, grid, block, lds, stream, x, h, tp.taps, tp.ngroups, tp.klo, tp.halo,
+                           tp.shift, T, M, Ts, MB, rowstride);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace micloc

@@ -1,0 +1,278 @@
+"""Device runtime under the micloc class surface: one `Plan` per (beamformer instance, device).
+
+PyTorch-ROCm is used only as the device-memory / stream provider: tensors are allocated with torch,
+their raw pointers are handed to the C-ABI, and kernels run on torch's current HIP stream.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+
+def _torch():
+    import torch
+
+    return torch
+
+
+def require_gpu(device=None):
+    torch = _torch()
+    if not torch.cuda.is_available():
+        raise _lib.MiclocError("no HIP device visible: the micloc hot path runs on MI355X only (no CPU fallback)")
+    if device is None:
+        return torch.device("cuda", torch.cuda.current_device())
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise _lib.MiclocError(f"device must be a HIP ('cuda') device, got {device}")
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    return device
+
+
+def _dptr(a):
+    return a.ctypes.data_as(_lib.c_double_p)
+
+
+def _stream(device):
+    return ctypes.c_void_p(_torch().cuda.current_stream(device).cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def pad_ba(b, a):
+    b = np.atleast_1d(np.asarray(b, dtype=np.float64))
+    a = np.atleast_1d(np.asarray(a, dtype=np.float64))
+    n = max(len(b), len(a))
+    if n > _lib.MICLOC_MAX_IIR:
+        raise ValueError(f"IIR filters with more than {_lib.MICLOC_MAX_IIR} coefficients are not supported")
+    bb = np.zeros(n)
+    aa = np.zeros(n)
+    bb[: len(b)] = b
+    aa[: len(a)] = a
+    return np.ascontiguousarray(bb), np.ascontiguousarray(aa), n
+
+
+class Workspace:
+    """Grow-only scratch buffer on one device (256-byte aligned by the torch allocator)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.buf = None
+
+    def get(self, nbytes):
+        torch = _torch()
+        if self.buf is None or self.buf.numel() < nbytes:
+            self.buf = None
+            self.buf = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+        return self.buf
+
+
+class Plan:
+    """Owns a micloc_plan (filter taps, neuron kernel, beamforming matrix on the device) + workspace."""
+
+    def __init__(self, num_mic, stht_kernel, b, a, robust_width, bipolar, device=None):
+        self.lib = _lib.load()
+        self.device = require_gpu(device)
+        self.num_mic = int(num_mic)
+        self.C = 2 * self.num_mic
+        ker = np.ascontiguousarray(stht_kernel, dtype=np.float64)
+        bb, aa, n = pad_ba(b, a)
+        cfg = _lib.MiclocConfig(
+            device=self.device.index,
+            num_mic=self.num_mic,
+            stht_len=len(ker),
+            stht_kernel=_dptr(ker),
+            iir_len=n,
+            iir_b=_dptr(bb),
+            iir_a=_dptr(aa),
+            robust_width=int(robust_width),
+            bipolar=int(bool(bipolar)),
+        )
+        handle = ctypes.c_void_p()
+        _lib.check(self.lib.micloc_plan_create(ctypes.byref(cfg), ctypes.byref(handle)), "plan_create")
+        self.handle = handle
+        self.ws = Workspace(self.device)
+        self._nir_key = None
+        self._w_key = None
+        self.G = None
+        self.w_complex = False
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.micloc_plan_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    # ---- plan state ------------------------------------------------------------------------------
+    def set_neuron_kernel(self, nir):
+        nir = np.ascontiguousarray(nir, dtype=np.float64)
+        key = nir.tobytes()
+        if key != self._nir_key:
+            _lib.check(self.lib.micloc_plan_set_neuron_kernel(self.handle, _dptr(nir), len(nir)), "set_neuron_kernel")
+            self._nir_key = key
+
+    def set_bf_mat(self, W):
+        W = np.asarray(W)
+        if np.iscomplexobj(W):
+            key = (True, W.shape, W.tobytes())
+            if key != self._w_key:
+                Wre = np.ascontiguousarray(W.real, dtype=np.float64)
+                Wim = np.ascontiguousarray(W.imag, dtype=np.float64)
+                _lib.check(self.lib.micloc_plan_set_bf_mat_c128(self.handle, _dptr(Wre), _dptr(Wim), W.shape[0], W.shape[1]), "set_bf_mat_c128")
+                self._w_key = key
+            self.w_complex = True
+        else:
+            W = np.ascontiguousarray(W, dtype=np.float64)
+            key = (False, W.shape, W.tobytes())
+            if key != self._w_key:
+                _lib.check(self.lib.micloc_plan_set_bf_mat(self.handle, _dptr(W), W.shape[0], W.shape[1]), "set_bf_mat")
+                self._w_key = key
+            self.w_complex = False
+        self.G = W.shape[1]
+
+    def workspace(self, B, T):
+        n = self.lib.micloc_workspace_bytes(self.handle, B, T)
+        return self.ws.get(n), n
+
+    def padded_T(self, T):
+        return self.lib.micloc_padded_T(T)
+
+    # ---- helpers -----------------------------------------------------------------------------------
+    def to_device(self, x):
+        """numpy / torch [B, T, M] float64 -> contiguous device tensor."""
+        torch = _torch()
+        if isinstance(x, np.ndarray):
+            x = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float64))
+        if x.dtype != torch.float64:
+            x = x.to(torch.float64)
+        if x.device != self.device:
+            x = x.to(self.device)
+        return x.contiguous()
+
+    # ---- pipelines -----------------------------------------------------------------------------------
+    def snn_pipeline(self, x, want_spikes=False, want_y=False, want_power=True):
+        """x: device tensor [B, T, M]. Returns dict of device tensors (spikes int8, y, power, argmax)."""
+        torch = _torch()
+        B, T, M = x.shape
+        if M != self.num_mic:
+            raise ValueError(f"number of channels in the input siganl {M} should be the same as the number of microphones {self.num_mic}!")
+        G = self.G
+        out = {}
+        spikes = torch.empty((B, T, self.C), dtype=torch.int8, device=self.device) if want_spikes else None
+        y = torch.empty((B, T, G), dtype=torch.float64, device=self.device) if want_y else None
+        power = torch.empty((B, G), dtype=torch.float64, device=self.device) if want_power else None
+        argmax = torch.empty((B,), dtype=torch.int32, device=self.device) if want_power else None
+        ws, nbytes = self.workspace(B, T)
+        _lib.check(
+            self.lib.micloc_snn_pipeline_f64(self.handle, _ptr(x), B, T, _ptr(spikes), _ptr(y), _ptr(power), _ptr(argmax),
+                                              _ptr(ws), nbytes, _stream(self.device)),
+            "snn_pipeline",
+        )
+        out.update(spikes=spikes, y=y, power=power, argmax=argmax)
+        return out
+
+    def beamformer_pipeline(self, x, want_y=False, want_power=True):
+        torch = _torch()
+        B, T, M = x.shape
+        if M != self.num_mic:
+            raise ValueError(f"number of channels in the input siganl {M} should be the same as the number of microphones {self.num_mic}!")
+        G = self.G
+        y = torch.empty((B, T, G), dtype=torch.complex128, device=self.device) if want_y else None
+        power = torch.empty((B, G), dtype=torch.float64, device=self.device) if want_power else None
+        argmax = torch.empty((B,), dtype=torch.int32, device=self.device) if want_power else None
+        ws, nbytes = self.workspace(B, T)
+        _lib.check(
+            self.lib.micloc_beamformer_pipeline_f64(self.handle, _ptr(x), B, T, _ptr(y), _ptr(power), _ptr(argmax), _ptr(ws), nbytes,
+                                                     _stream(self.device)),
+            "beamformer_pipeline",
+        )
+        return dict(y=y, power=power, argmax=argmax)
+
+    # ---- single stages (used by tests and by Demo.spike_encoding-style callers) --------------------------
+    def stht(self, x):
+        torch = _torch()
+        B, T, M = x.shape
+        Ts = self.padded_T(T)
+        h = torch.empty((B, self.C, Ts), dtype=torch.float64, device=self.device)
+        _lib.check(self.lib.micloc_stht_f64(self.handle, _ptr(x), B, T, _ptr(h), Ts, _stream(self.device)), "stht")
+        return h
+
+    def bandpass_rzcc(self, h, T, want_pre=True, want_spikes=True):
+        torch = _torch()
+        B, C, Ts = h.shape
+        pre = torch.empty_like(h) if want_pre else None
+        spikes = torch.empty((B, T, C), dtype=torch.int8, device=self.device) if want_spikes else None
+        ws, nbytes = self.workspace(B, T)
+        _lib.check(self.lib.micloc_bandpass_rzcc_f64(self.handle, _ptr(h), B, T, Ts, _ptr(pre), _ptr(spikes), _ptr(ws), nbytes,
+                                                     _stream(self.device)), "bandpass_rzcc")
+        return pre, spikes
+
+    def lif_beamform(self, spikes, want_y=False, want_power=True):
+        torch = _torch()
+        B, T, C = spikes.shape
+        G = self.G
+        y = torch.empty((B, T, G), dtype=torch.float64, device=self.device) if want_y else None
+        power = torch.empty((B, G), dtype=torch.float64, device=self.device) if want_power else None
+        argmax = torch.empty((B,), dtype=torch.int32, device=self.device) if want_power else None
+        ws, nbytes = self.workspace(B, T)
+        _lib.check(self.lib.micloc_lif_beamform_f64(self.handle, _ptr(spikes), B, T, _ptr(y), _ptr(power), _ptr(argmax), _ptr(ws), nbytes,
+                                                    _stream(self.device)), "lif_beamform")
+        return dict(y=y, power=power, argmax=argmax)
+
+
+# ---- plan-less operators -------------------------------------------------------------------------------
+_op_ws = {}
+
+
+def _op_workspace(device, nbytes):
+    ws = _op_ws.get(device)
+    if ws is None:
+        ws = _op_ws[device] = Workspace(device)
+    return ws.get(nbytes)
+
+
+def rzcc_encode(sig, robust_width, bipolar, device=None):
+    """ZeroCrossingSpikeEncoder.evolve on the device. sig: numpy/torch [T, C] or [B, T, C] -> int8 device tensor."""
+    torch = _torch()
+    lib = _lib.load()
+    device = require_gpu(device)
+    if isinstance(sig, np.ndarray):
+        sig = torch.from_numpy(np.ascontiguousarray(sig, dtype=np.float64))
+    sig = sig.to(device=device, dtype=torch.float64).contiguous()
+    squeeze = sig.dim() == 2
+    if squeeze:
+        sig = sig.unsqueeze(0)
+    B, T, C = sig.shape
+    spikes = torch.zeros((B, T, C), dtype=torch.int8, device=device)
+    if B * T * C > 0:
+        nbytes = lib.micloc_rzcc_workspace_bytes(B, T, C)
+        ws = _op_workspace(device, nbytes)
+        _lib.check(lib.micloc_rzcc_encode_f64(_ptr(sig), B, T, C, int(robust_width), int(bool(bipolar)), _ptr(spikes), _ptr(ws), nbytes,
+                                              _stream(device)), "rzcc_encode")
+    return spikes[0] if squeeze else spikes
+
+
+def lfilter(b, a, x, device=None):
+    """scipy.signal.lfilter(b, a, x, axis=0) for real x [T, C] or [B, T, C] on the device."""
+    torch = _torch()
+    lib = _lib.load()
+    device = require_gpu(device)
+    bb, aa, n = pad_ba(b, a)
+    if isinstance(x, np.ndarray):
+        x = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float64))
+    x = x.to(device=device, dtype=torch.float64).contiguous()
+    squeeze = x.dim() == 2
+    if squeeze:
+        x = x.unsqueeze(0)
+    B, T, C = x.shape
+    y = torch.empty_like(x)
+    if B * T * C > 0:
+        nbytes = lib.micloc_lfilter_workspace_bytes(B, T, C)
+        ws = _op_workspace(device, nbytes)
+        _lib.check(lib.micloc_lfilter_f64(_dptr(bb), _dptr(aa), n, _ptr(x), B, T, C, _ptr(y), _ptr(ws), nbytes, _stream(device)), "lfilter")
+    return y[0] if squeeze else y

@@ -1,0 +1,130 @@
+"""Monte-Carlo DoA sweep (restatement of paper_plots/target_snn_localization.py:435-467 as a batched,
+shardable harness).  The script's loop carries no state between trials except the RNG stream, so trials
+shard contiguously across ranks (one process per GPU); the only exchange is one small all-gather of
+per-trial results at the end (RCCL over xGMI when the process group is "nccl").
+
+parity mode      every rank replays the reference's global NumPy stream (rand(1) then randn(T, M) per trial,
+                 legacy MT19937) and keeps its own shard, so results are identical to the single-process
+                 reference for any world size.
+throughput mode  DoAs from a seeded host generator, clean array signals synthesised on the host once per
+                 trial, noise drawn on the device (torch Philox generator seeded per rank).
+"""
+import numpy as np
+
+from .snn_beamformer import synthesize_array_signal
+
+
+def shard_range(total, rank, world_size):
+    """Contiguous shard [lo, hi) of `total` trials for `rank`; sizes differ by at most one."""
+    base, rem = divmod(total, world_size)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def doa_error(doa_est, doa_true):
+    """arcsin|sin(est - true)| (target_snn_localization.py:466; pi-periodic by construction)."""
+    return np.arcsin(np.abs(np.sin(doa_est - doa_true)))
+
+
+def gather_shards(local, total, rank, world_size, group=None):
+    """All-gather equal-dtype 1-d arrays from contiguous shards; returns the full-length arrays on every rank.
+    `local` is a dict name -> 1-d numpy array (this rank's shard).  Uses torch.distributed when world_size > 1."""
+    if world_size == 1:
+        return {k: np.asarray(v) for k, v in local.items()}
+    import torch
+    import torch.distributed as dist
+
+    backend = dist.get_backend(group)
+    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    width = -(-total // world_size)  # padded shard length
+    out = {}
+    for k, v in local.items():
+        v = np.asarray(v)
+        buf = torch.zeros(width, dtype=torch.from_numpy(v[:0].copy()).dtype, device=dev)
+        buf[: len(v)] = torch.from_numpy(np.ascontiguousarray(v)).to(dev)
+        full = torch.empty(width * world_size, dtype=buf.dtype, device=dev)
+        dist.all_gather_into_tensor(full, buf, group=group)
+        full = full.cpu().numpy().reshape(world_size, width)
+        parts = []
+        for r in range(world_size):
+            lo, hi = shard_range(total, r, world_size)
+            parts.append(full[r, : hi - lo])
+        out[k] = np.concatenate(parts)
+    return out
+
+
+def device_localizer(beamf, bf_mat, max_batch=1100):
+    """Default localizer: the HIP pipeline (power + arg-max, no T x G temporary)."""
+
+    def run(sig_batch, time_vec):
+        am, pm = [], []
+        for s in range(0, len(sig_batch), max_batch):
+            out = beamf.localize_batch(bf_mat, sig_batch[s : s + max_batch], time_vec=time_vec)
+            a = out["argmax"].cpu().numpy().astype(np.int64)
+            p = out["power"].cpu().numpy()
+            am.append(a)
+            pm.append(p[np.arange(len(a)), a])
+        return np.concatenate(am), np.concatenate(pm)
+
+    return run
+
+
+def noisy_target_sweep(beamf, bf_mat, doa_list, snr_db_vec=None, num_sim=100, seed=0, mode="parity", rank=0, world_size=1,
+                       group=None, freq_design=2000.0, test_duration=100e-3, snr_gain_due_to_bandwidth=None, localizer=None):
+    """Returns dict(doa, argmax, err, pmax: [num_snr, num_sim]; mae_deg [num_snr]) on every rank."""
+    fs = beamf.fs
+    if snr_db_vec is None:
+        snr_db_vec = np.linspace(-10, 20, 11)
+    snr_db_vec = np.asarray(snr_db_vec, dtype=np.float64)
+    if snr_gain_due_to_bandwidth is None:
+        snr_gain_due_to_bandwidth = (fs / 2) / 1000.0  # (fs/2)/(f_max - f_min) with the paper's [1, 2] kHz band
+    time_test = np.arange(0, test_duration, step=1 / fs)
+    sig_test = np.sin(2 * np.pi * freq_design * time_test)
+    total = len(snr_db_vec) * num_sim
+    lo, hi = shard_range(total, rank, world_size)
+    localizer = localizer or device_localizer(beamf, bf_mat)
+
+    doa_all = np.zeros(total)
+    sigs = []
+    time_in = None
+    if mode == "parity":
+        np.random.seed(seed)
+        for trial in range(total):
+            snr_db = snr_db_vec[trial // num_sim] - 10 * np.log10(snr_gain_due_to_bandwidth)
+            doa = np.random.rand(1)[0] * 2 * np.pi
+            doa_all[trial] = doa
+            if lo <= trial < hi:
+                time_in, sig = synthesize_array_signal(beamf.geometry, fs, time_test, sig_test, doa)
+                sig += np.sqrt(np.mean(sig**2)) / np.sqrt(10 ** (snr_db / 10)) * np.random.randn(*sig.shape)
+                sigs.append(sig)
+            else:
+                # keep the global stream aligned: the reference draws T x M normals for every trial
+                np.random.randn(len(time_test) - 1, len(beamf.geometry))
+        sig_batch = np.stack(sigs) if sigs else np.zeros((0, len(time_test) - 1, len(beamf.geometry)))
+    elif mode == "throughput":
+        import torch
+
+        rng = np.random.RandomState(seed)
+        doa_all[:] = rng.rand(total) * 2 * np.pi
+        for trial in range(lo, hi):
+            time_in, sig = synthesize_array_signal(beamf.geometry, fs, time_test, sig_test, doa_all[trial])
+            sigs.append(sig)
+        clean = torch.from_numpy(np.stack(sigs)).cuda()
+        gen = torch.Generator(device=clean.device)
+        gen.manual_seed(seed * 1_000_003 + rank)
+        snr_db = torch.from_numpy(snr_db_vec[np.arange(lo, hi) // num_sim] - 10 * np.log10(snr_gain_due_to_bandwidth)).to(clean.device)
+        sigma = torch.sqrt(torch.mean(clean**2, dim=(1, 2))) / torch.sqrt(10 ** (snr_db / 10))
+        sig_batch = clean + sigma[:, None, None] * torch.randn(clean.shape, generator=gen, device=clean.device, dtype=torch.float64)
+    else:
+        raise ValueError("mode must be 'parity' or 'throughput'")
+
+    if hi > lo:
+        argmax, pmax = localizer(sig_batch, time_in)
+    else:
+        argmax, pmax = np.zeros(0, dtype=np.int64), np.zeros(0)
+    full = gather_shards({"argmax": np.asarray(argmax, dtype=np.int64), "pmax": np.asarray(pmax, dtype=np.float64)}, total, rank, world_size, group)
+    doa_list = np.asarray(doa_list)
+    err = doa_error(doa_list[full["argmax"]], doa_all)
+    shape = (len(snr_db_vec), num_sim)
+    return dict(doa=doa_all.reshape(shape), argmax=full["argmax"].reshape(shape), pmax=full["pmax"].reshape(shape), err=err.reshape(shape),
+                mae_deg=np.mean(err.reshape(shape), axis=1) * 180 / np.pi, snr_db_vec=snr_db_vec)

@@ -1,0 +1,134 @@
+/*
+ * micloc_hip.h -- C-ABI of libmicloc_hip.so, the MI355X (gfx950) implementation of the micloc
+ * hot path (STHT -> band-pass -> RZCC spike encoding -> alpha-kernel "LIF" filter -> beamforming ->
+ * power / arg-max) of synsense/HaghighatshoarMuir2024.
+ *
+ * The reference has no FFI: its boundary is the Python class surface in micloc/.  Each entry point
+ * below therefore names the reference *method lines* it replaces (paths relative to the reference
+ * repository root); INTEGRATION.md shows the ctypes stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no torch / HIP types in the signatures (`stream` is a
+ *     hipStream_t passed as void*; NULL = the default stream).
+ *   - Pointers documented "host" are read synchronously during the call; everything else is a
+ *     caller-owned DEVICE buffer on the plan's device.  No allocation happens in the stage calls:
+ *     scratch comes from the caller (`ws`, sized by micloc_workspace_bytes).
+ *   - All stage calls are asynchronous on `stream`, re-entrant per plan+stream, and safe to capture
+ *     in a hipGraph.  Return value: MICLOC_OK (0) or a negative micloc_status.
+ *   - All arithmetic is IEEE binary64 unless a name says otherwise (float32 before the
+ *     encoder flips spikes).
+ *
+ * Device layouts
+ *   x        [B][T][M]      row-major: trial b is the reference's `sig_in_vec` (T x num_mic).
+ *   planar   [B][C][Ts]     C = 2M channels ordered re_0..re_{M-1}, im_0..im_{M-1}
+ *                           (np.hstack([real, imag]), snn_beamformer.py:335); Ts = micloc_padded_T(T).
+ *   spikes   [B][T][C]      int8 in {-1,0,+1}: trial b is the reference's spikes_vec (T x 2M).
+ *   y        [B][T][G]      trial b is the reference's return value of apply_to_signal (T x num_grid);
+ *                           complex variant: [B][T][G][2] (re, im) == numpy complex128.
+ *   power    [B][G]         mean_t |y|^2  (target_snn_localization.py:462);  argmax [B] int32.
+ */
+#ifndef MICLOC_HIP_H
+#define MICLOC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MICLOC_ABI_VERSION 1
+#define MICLOC_MAX_IIR 9 /* len(b) = len(a) <= 9, i.e. band-pass order <= 4 */
+
+typedef enum {
+    MICLOC_OK = 0,
+    MICLOC_ERR_INVALID = -1,     /* bad argument (NULL, non-positive size, unsupported length) */
+    MICLOC_ERR_SHAPE = -2,       /* channel count / matrix shape mismatch (the reference's ValueError) */
+    MICLOC_ERR_WORKSPACE = -3,   /* ws too small or misaligned */
+    MICLOC_ERR_NOT_SET = -4,     /* neuron kernel / bf_mat not set on the plan */
+    MICLOC_ERR_HIP = -5,         /* a HIP runtime call failed; see micloc_last_hip_error */
+    MICLOC_ERR_NO_DEVICE = -6    /* no gfx950 device / device ordinal out of range */
+} micloc_status;
+
+typedef struct micloc_plan micloc_plan;
+
+/* Parameters fixed at construction time of SNNBeamformer / Beamformer (host pointers, copied). */
+typedef struct {
+    int device;                 /* HIP device ordinal */
+    int num_mic;                /* M */
+    int stht_len;               /* L = int(fs * kernel_duration)            snn_beamformer.py:50 */
+    const double *stht_kernel;  /* host [L] fftshift(imag(hilbert(delta)))  snn_beamformer.py:51-53 */
+    int iir_len;                /* n = len(b) = len(a) (zero-padded), 1..MICLOC_MAX_IIR */
+    const double *iir_b;        /* host [n]  scipy.signal.butter(...)[0]    snn_beamformer.py:68-72 */
+    const double *iir_a;        /* host [n]  a[0] != 0 (normalised inside) */
+    int robust_width;           /* find_peaks(distance=...)                 snn_beamformer.py:75-80 */
+    int bipolar;                /* 0: +1 spikes only, 1: +1 / -1            spike_encoder.py:131-135 */
+} micloc_config;
+
+/* ---- plan life cycle -------------------------------------------------------------------------- */
+int micloc_plan_create(const micloc_config *cfg, micloc_plan **out);
+void micloc_plan_destroy(micloc_plan *plan);
+
+/* neuron impulse response (host [n]); replaces the kernel built in snn_beamformer.py:342-361 */
+int micloc_plan_set_neuron_kernel(micloc_plan *plan, const double *nir, int n);
+/* real beamforming matrix (host, row-major [C][G], C must equal 2M); SNNBeamformer bf_mat */
+int micloc_plan_set_bf_mat(micloc_plan *plan, const double *W, int C, int G);
+/* complex beamforming matrix (host, row-major [M][G] re and im); Beamformer bf_mat, applied as
+ * sig @ bf_mat.conj() (beamformer.py:290) */
+int micloc_plan_set_bf_mat_c128(micloc_plan *plan, const double *Wre, const double *Wim, int M, int G);
+
+/* padded time stride of planar buffers (multiple of 8 samples) */
+int micloc_padded_T(int T);
+/* bytes of scratch needed by any stage / pipeline call with this (B, T) */
+size_t micloc_workspace_bytes(const micloc_plan *plan, int B, int T);
+
+/* ---- stages (device pointers) ----------------------------------------------------------------- */
+/* STHT: roll by L/2 + 1j * FIR.  Replaces snn_beamformer.py:325-327 / :158-160,
+ * beamformer.py:281-283, xylo_snn_localization.py:329-331.   x [B][T][M] -> h planar [B][2M][Ts]. */
+int micloc_stht_f64(const micloc_plan *plan, const double *x, int B, int T, double *h, int Ts, void *stream);
+
+/* Band-pass (DF2T, lfilter(b,a,.)) + RZCC encoder.  Replaces snn_beamformer.py:330-338 and
+ * spike_encoder.py:115-137.  h planar in; `pre` (planar, post-filter signal) and `spikes` may each be
+ * NULL.  spikes must not alias anything; it is fully overwritten. */
+int micloc_bandpass_rzcc_f64(const micloc_plan *plan, const double *h, int B, int T, int Ts, double *pre,
+                             int8_t *spikes, void *ws, size_t ws_bytes, void *stream);
+
+/* alpha-kernel FIR ("LIF") + real beamforming + power/argmax.  Replaces snn_beamformer.py:364-368 and
+ * target_snn_localization.py:462-464.  y, power, argmax may each be NULL. */
+int micloc_lif_beamform_f64(const micloc_plan *plan, const int8_t *spikes, int B, int T, double *y,
+                            double *power, int32_t *argmax, void *ws, size_t ws_bytes, void *stream);
+
+/* complex beamforming of the band-passed analytic signal: pre (planar) @ conj(W).
+ * Replaces beamformer.py:290.  y is [B][T][G][2]. */
+int micloc_beamform_c128_f64(const micloc_plan *plan, const double *pre, int B, int T, int Ts, double *y,
+                             double *power, int32_t *argmax, void *ws, size_t ws_bytes, void *stream);
+
+/* ---- fused pipelines -------------------------------------------------------------------------- */
+/* SNNBeamformer.apply_to_signal (snn_beamformer.py:283-370) + power/argmax for B trials.
+ * spikes / y / power / argmax may each be NULL (at least one must be given). */
+int micloc_snn_pipeline_f64(const micloc_plan *plan, const double *x, int B, int T, int8_t *spikes, double *y,
+                            double *power, int32_t *argmax, void *ws, size_t ws_bytes, void *stream);
+/* Beamformer.apply_to_signal (beamformer.py:260-292) + power/argmax for B trials. */
+int micloc_beamformer_pipeline_f64(const micloc_plan *plan, const double *x, int B, int T, double *y,
+                                   double *power, int32_t *argmax, void *ws, size_t ws_bytes, void *stream);
+
+/* ---- stand-alone operators (no plan) ---------------------------------------------------------- */
+/* ZeroCrossingSpikeEncoder.evolve (spike_encoder.py:115-137) on row-major sig [B][T][C]. */
+size_t micloc_rzcc_workspace_bytes(int B, int T, int C);
+int micloc_rzcc_encode_f64(const double *sig, int B, int T, int C, int robust_width, int bipolar, int8_t *spikes,
+                           void *ws, size_t ws_bytes, void *stream);
+/* scipy.signal.lfilter(b, a, x, axis=0) on row-major x [B][T][C] (Filterbank.evolve,
+ * filterbank.py:25-46); b, a are host [n], zero-padded to the same length n <= MICLOC_MAX_IIR. */
+size_t micloc_lfilter_workspace_bytes(int B, int T, int C);
+int micloc_lfilter_f64(const double *b, const double *a, int n, const double *x, int B, int T, int C, double *y,
+                       void *ws, size_t ws_bytes, void *stream);
+
+/* ---- misc ------------------------------------------------------------------------------------- */
+int micloc_abi_version(void);
+const char *micloc_status_string(int status);
+int micloc_last_hip_error(void); /* last hipError_t seen by this thread (0 if none) */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MICLOC_HIP_H */

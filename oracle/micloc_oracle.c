@@ -197,15 +197,16 @@ void oracle_rzcc(const double *r, int T, int C, int robust_width, int bipolar, s
     free(keep);
 }
 
-/* vmem[t][c] = sum_{k<n} nir[k] * spikes[t-k][c]  (zero history), ascending k, fma chain from 0. */
+/* vmem[t][c] = sum_{k<n} nir[k] * spikes[t-k][c]  (zero history); the past samples are visited in
+ * chronological order (k descending), fma chain from 0 -- the order of the Toeplitz MFMA on the GPU. */
 void oracle_lif_fir(const signed char *spikes, int T, int C, const double *nir, int n, double *vmem)
 {
     for (int t = 0; t < T; ++t) {
         int kmax = (t < n - 1) ? t : n - 1;
         for (int ch = 0; ch < C; ++ch) {
             double acc = 0.0;
-            for (int k = 0; k <= kmax; ++k)
-                acc = fma(nir[k], (double)spikes[(size_t)(t - k) * C + ch], acc);
+            for (int k = kmax; k >= 0; --k)
+                acc = fma((double)spikes[(size_t)(t - k) * C + ch], nir[k], acc);
             vmem[(size_t)t * C + ch] = acc;
         }
     }

@@ -1,0 +1,244 @@
+"""GPU parity tests: the HIP path (through the C-ABI) against the CPU oracle and the golden vectors.
+
+Bars: bit-exact for the STHT output, the band-passed pre-encoder signal, the spikes and the arg-max;
+the beamformed signal y and the power within 1e-12 relative of the oracle (both fp64; they differ only
+in the order of the final time reduction) and within 1e-10 of the reference's golden vectors.
+"""
+import numpy as np
+import pytest
+
+from conftest import golden
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch
+
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch
+
+
+@pytest.fixture(scope="module")
+def plan2(cfg2, torch):
+    from haghighatshoarmuir2024_amd.runtime import Plan
+
+    p = Plan(7, cfg2["kernel"], cfg2["b"], cfg2["a"], cfg2["robust_width"], True)
+    p.set_neuron_kernel(cfg2["nir"])
+    p.set_bf_mat(cfg2["bf_mat"])
+    return p
+
+
+def planar_to_rows(h, T):
+    """device planar [B, C, Ts] -> numpy [B, T, C]"""
+    return np.ascontiguousarray(h[:, :, :T].cpu().numpy().transpose(0, 2, 1))
+
+
+@pytest.mark.parametrize("T", [1, 7, 8, 100, 479, 480, 481, 513, 1500, 4799])
+def test_stht_bit_exact(plan2, cfg2, T):
+    rng = np.random.RandomState(T)
+    x = rng.randn(3, T, 7)
+    h = planar_to_rows(plan2.stht(plan2.to_device(x)), T)
+    for b in range(3):
+        re, im = O.stht(x[b], cfg2["kernel"])
+        np.testing.assert_array_equal(h[b][:, :7], re)
+        np.testing.assert_array_equal(h[b][:, 7:], im)
+
+
+def test_stht_dense_and_odd_kernels(torch):
+    """kstep = 1 path (a kernel with no zero taps), odd length, leading zeros, and an all-zero kernel."""
+    from haghighatshoarmuir2024_amd.runtime import Plan
+
+    rng = np.random.RandomState(3)
+    for L, maker in [(37, lambda L: rng.randn(L)), (64, lambda L: np.r_[np.zeros(5), rng.randn(L - 5)]), (16, lambda L: np.zeros(L)),
+                     (50, lambda L: np.where(np.arange(L) % 2 == 1, rng.randn(L), 0.0))]:
+        ker = maker(L)
+        p = Plan(5, ker, [1.0], [1.0], 3, True)
+        x = rng.randn(2, 700, 5)
+        h = planar_to_rows(p.stht(p.to_device(x)), 700)
+        for b in range(2):
+            re, im = O.stht(x[b], ker)
+            np.testing.assert_array_equal(h[b][:, :5], re)
+            np.testing.assert_array_equal(h[b][:, 5:], im)
+
+
+def test_bandpass_and_spikes_bit_exact(plan2, cfg2):
+    z = golden("trials_cfg2.npz")
+    x = z["sig_in"]
+    h = plan2.stht(plan2.to_device(x))
+    pre, spikes = plan2.bandpass_rzcc(h, x.shape[1])
+    pre = planar_to_rows(pre, x.shape[1])
+    spikes = spikes.cpu().numpy()
+    for b in range(3):
+        out = O.snn_chain(x[b], cfg2["kernel"], cfg2["b"], cfg2["a"], cfg2["robust_width"], True, cfg2["nir"], cfg2["bf_mat"])
+        np.testing.assert_array_equal(pre[b], out["pre_enc"])
+        np.testing.assert_array_equal(spikes[b], out["spikes"])
+        np.testing.assert_array_equal(spikes[b], z["spikes"][b])  # the reference's own spikes
+
+
+def test_pipeline_vs_golden_and_oracle(plan2, cfg2):
+    z = golden("trials_cfg2.npz")
+    x = z["sig_in"]
+    out = plan2.snn_pipeline(plan2.to_device(x), want_spikes=True, want_y=True, want_power=True)
+    spikes = out["spikes"].cpu().numpy()
+    y = out["y"].cpu().numpy()
+    power = out["power"].cpu().numpy()
+    argmax = out["argmax"].cpu().numpy()
+    np.testing.assert_array_equal(spikes, z["spikes"])
+    np.testing.assert_array_equal(argmax, z["argmax"])
+    np.testing.assert_allclose(power, z["power"], rtol=1e-10, atol=0)
+    for b in range(3):
+        ref = O.snn_chain(x[b], cfg2["kernel"], cfg2["b"], cfg2["a"], cfg2["robust_width"], True, cfg2["nir"], cfg2["bf_mat"])
+        np.testing.assert_allclose(y[b], ref["y"], rtol=0, atol=1e-15)
+        np.testing.assert_allclose(power[b], ref["power"], rtol=1e-12, atol=0)
+        np.testing.assert_allclose(y[b][z["row_idx"]], z["y_rows"][b], rtol=0, atol=1e-12)
+        assert argmax[b] == ref["argmax"]
+    # power-only call (no T x G store) gives the same numbers
+    out2 = plan2.snn_pipeline(plan2.to_device(x), want_power=True)
+    np.testing.assert_array_equal(out2["power"].cpu().numpy(), power)
+
+
+def test_membrane_and_y_bit_exact(plan2, cfg2):
+    """bf_mat = I returns the membrane signal itself: the MFMA chains reproduce the oracle's fma order exactly."""
+    from haghighatshoarmuir2024_amd.runtime import Plan
+
+    z = golden("trials_cfg2.npz")
+    x = z["sig_in"][:1]
+    p = Plan(7, cfg2["kernel"], cfg2["b"], cfg2["a"], cfg2["robust_width"], True)
+    p.set_neuron_kernel(cfg2["nir"])
+    p.set_bf_mat(np.eye(14))
+    v = p.snn_pipeline(p.to_device(x), want_y=True, want_power=False)["y"][0].cpu().numpy()
+    ref = O.snn_chain(x[0], cfg2["kernel"], cfg2["b"], cfg2["a"], cfg2["robust_width"], True, cfg2["nir"], cfg2["bf_mat"])
+    np.testing.assert_array_equal(v, ref["vmem"])
+    y = plan2.snn_pipeline(plan2.to_device(x), want_y=True, want_power=False)["y"][0].cpu().numpy()
+    np.testing.assert_array_equal(y, ref["y"])
+
+
+def _edge_cases():
+    z = golden("rzcc_edge.npz")
+    return z, sorted({n.split("__")[0] for n in z.files})
+
+
+def test_rzcc_edge_cases(torch):
+    from haghighatshoarmuir2024_amd.spike_encoder import ZeroCrossingSpikeEncoder
+
+    z, names = _edge_cases()
+    for n in names:
+        x, w, bip = z[f"{n}__in"], int(z[f"{n}__w"]), int(z[f"{n}__bip"])
+        enc = ZeroCrossingSpikeEncoder(fs=48_000, robust_width=w, bipolar=bool(bip))
+        got = enc.evolve(x)
+        assert got.dtype == x.dtype and got.shape == x.shape
+        np.testing.assert_array_equal(got.astype(np.int8), O.rzcc(x, w, bip), err_msg=n)
+        if not n.startswith("int_ties"):  # tie order is unspecified in the reference (see test_oracle_golden)
+            np.testing.assert_array_equal(got.astype(np.int8), z[f"{n}__out"], err_msg=n)
+
+
+def test_rzcc_random_batches_vs_oracle(torch):
+    from haghighatshoarmuir2024_amd import runtime
+
+    rng = np.random.RandomState(0)
+    for (B, T, C, w, bip, kind) in [(5, 1000, 14, 12, 1, "walk"), (3, 777, 3, 1, 1, "noise"), (2, 2048, 130, 24, 0, "noise"),
+                                    (4, 500, 7, 5, 1, "int"), (1, 3000, 2, 400, 1, "noise"), (70, 64, 1, 3, 1, "int")]:
+        if kind == "int":
+            x = rng.randint(-2, 3, size=(B, T, C)).astype(np.float64)
+        elif kind == "walk":
+            x = np.sin(np.arange(T)[None, :, None] * 0.2 + rng.rand(B, 1, C) * 6) + 0.5 * rng.randn(B, T, C)
+        else:
+            x = rng.randn(B, T, C)
+        got = runtime.rzcc_encode(x, w, bip).cpu().numpy()
+        for b in range(B):
+            np.testing.assert_array_equal(got[b], O.rzcc(x[b], w, bip), err_msg=f"{(B, T, C, w, bip, kind)} b={b}")
+
+
+def test_unipolar_trial(torch):
+    from haghighatshoarmuir2024_amd.runtime import Plan
+
+    z = golden("unipolar_trial.npz")
+    W = golden("bf_mat_sin225_unipolar.npz")["bf_mat_f2000"]
+    fs, f = 48_000, 2000
+    b, a = O.bandpass(fs, [0.5 * f, 2 * f])
+    x = z["sig_in"]
+    tau = 1 / (2 * np.pi * f)
+    p = Plan(7, O.stht_kernel(fs, 10e-3), b, a, O.robust_width(fs, 2 * f), False)
+    p.set_neuron_kernel(O.neuron_kernel(np.arange(x.shape[0]) / fs, [tau, tau]))
+    p.set_bf_mat(W)
+    out = p.snn_pipeline(p.to_device(x[None]), want_spikes=True)
+    np.testing.assert_array_equal(out["spikes"][0].cpu().numpy(), z["spikes"])
+    np.testing.assert_allclose(out["power"][0].cpu().numpy(), z["power"], rtol=1e-10)
+    assert int(out["argmax"][0]) == int(z["argmax"])
+
+
+def test_wide_case_generic_shapes(torch):
+    """16 mics (C = 32 -> two channel tiles), 96 kHz (L = 960, w = 24, 71-tap neuron kernel), G = 90."""
+    from haghighatshoarmuir2024_amd.runtime import Plan
+
+    z = golden("wide_case.npz")
+    fs = int(z["fs"])
+    b, a = O.bandpass(fs, [1000.0, 2000.0])
+    tau = 1 / (2 * np.pi * 2000.0)
+    nir = O.neuron_kernel(z["time_vec"], [tau, tau])
+    ker = O.stht_kernel(fs, 10e-3)
+    p = Plan(16, ker, b, a, O.robust_width(fs, 2000.0), True)
+    p.set_neuron_kernel(nir)
+    p.set_bf_mat(z["bf_mat"])
+    x = z["sig_in"]
+    out = p.snn_pipeline(p.to_device(x[None]), want_spikes=True, want_y=True)
+    ref = O.snn_chain(x, ker, b, a, O.robust_width(fs, 2000.0), True, nir, z["bf_mat"])
+    np.testing.assert_array_equal(out["spikes"][0].cpu().numpy(), z["spikes"])
+    np.testing.assert_array_equal(out["spikes"][0].cpu().numpy(), ref["spikes"])
+    np.testing.assert_allclose(out["y"][0].cpu().numpy(), ref["y"], rtol=0, atol=1e-14)
+    np.testing.assert_allclose(out["power"][0].cpu().numpy(), z["power"], rtol=1e-10)
+    assert int(out["argmax"][0]) == int(z["argmax"])
+
+
+def test_beamformer_c128(cfg2, torch):
+    from haghighatshoarmuir2024_amd.runtime import Plan
+
+    z = golden("beamformer_c128.npz")
+    p = Plan(7, cfg2["kernel"], cfg2["b"], cfg2["a"], 1, False)
+    p.set_bf_mat(z["bf_mat"])
+    x = z["sig_in"]
+    out = p.beamformer_pipeline(p.to_device(x[None]), want_y=True)
+    ref = O.beamformer_chain(x, cfg2["kernel"], cfg2["b"], cfg2["a"], z["bf_mat"])
+    y = out["y"][0].cpu().numpy()
+    np.testing.assert_allclose(y, ref["y"], rtol=0, atol=1e-14)
+    np.testing.assert_allclose(y[z["row_idx"]], z["y_rows"], rtol=0, atol=1e-11)
+    np.testing.assert_allclose(out["power"][0].cpu().numpy(), z["power"], rtol=1e-10)
+    np.testing.assert_allclose(out["power"][0].cpu().numpy(), ref["power"], rtol=1e-12)
+    assert int(out["argmax"][0]) == int(z["argmax"])
+
+
+def test_lfilter_filterbank(cfg2, torch):
+    from haghighatshoarmuir2024_amd.filterbank import ButterworthFilterbank
+    from haghighatshoarmuir2024_amd import runtime
+
+    z = golden("filterbank.npz")
+    re, im = O.stht(z["sig_in"], cfg2["kernel"])
+    sig_real = np.hstack([re, im])
+    fb = ButterworthFilterbank(freq_bands=[[1000, 2000]], order=1, fs=48_000)
+    filt = fb.evolve(sig_real)
+    assert filt.shape == (1,) + sig_real.shape
+    np.testing.assert_array_equal(filt[0], O.iir(z["b"], z["a"], sig_real))
+    np.testing.assert_allclose(filt[0][:800], z["filt_head"], rtol=0, atol=1e-11)
+    s = runtime.rzcc_encode(filt[0], cfg2["robust_width"], True).cpu().numpy()
+    np.testing.assert_array_equal(np.hstack([(s > 0), (s < 0)]).astype(np.int8), z["spikes_in"])
+
+
+def test_error_conventions(cfg2, torch):
+    from haghighatshoarmuir2024_amd.snn_beamformer import SNNBeamformer
+    from haghighatshoarmuir2024_amd.beamformer import Beamformer
+    from haghighatshoarmuir2024_amd.array_geometry import CenterCircularArray
+
+    geo = CenterCircularArray(4.5e-2, 7)
+    tau = 1 / (2 * np.pi * 2000)
+    bf = SNNBeamformer(geo, 10e-3, [1000, 2000], [tau, tau], bipolar_spikes=True)
+    with pytest.raises(ValueError):
+        bf.apply_to_signal(cfg2["bf_mat"], (np.arange(100) / 48000, np.zeros((100, 6))))
+    with pytest.raises(ValueError):
+        bf.apply_to_template(cfg2["bf_mat"], (np.arange(10), np.arange(10)), 3.0)
+    with pytest.raises(ValueError):
+        SNNBeamformer(geo, 10e-3, [2000, 1000], [tau, tau])
+    with pytest.raises(ValueError):
+        Beamformer(geo, 10e-3, [1000, 2000]).apply_to_signal(np.zeros((7, 5), complex), np.zeros((50, 3)))

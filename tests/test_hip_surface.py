@@ -1,0 +1,141 @@
+"""GPU tests of the reference call surface (micloc.*) and of the Monte-Carlo sweep against golden data."""
+import numpy as np
+import pytest
+
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+
+def make_beamformer(bipolar=True):
+    from micloc.array_geometry import CenterCircularArray
+    from micloc.snn_beamformer import SNNBeamformer
+
+    geo = CenterCircularArray(radius=4.5e-2, num_mic=7)
+    tau = 1.0 / (2 * np.pi * 2000)
+    return SNNBeamformer(geometry=geo, kernel_duration=10.0e-3, tau_vec=np.asarray([tau, tau]), freq_range=[1000.0, 2000.0], fs=48_000,
+                         bipolar_spikes=bipolar)
+
+
+def test_constructor_matches_reference_constants():
+    k = golden("kat_init.npz")
+    bf = make_beamformer()
+    np.testing.assert_array_equal(bf.kernel, k["kernel_48k"])
+    np.testing.assert_array_equal(bf.bandpass_filter[0], k["b_48k"])
+    np.testing.assert_array_equal(bf.bandpass_filter[1], k["a_48k"])
+    assert bf.kernel_length == 480 and bf.spk_encoder.robust_width == 12 and bf.spk_encoder.bipolar
+
+
+def test_apply_to_signal_like_the_scripts(cfg2):
+    z = golden("trials_cfg2.npz")
+    bf = make_beamformer()
+    y = bf.apply_to_signal(bf_mat=cfg2["bf_mat"], sig_in_vec=(z["time0"], z["sig_in"][0]))
+    assert y.shape == (4799, 449) and y.dtype == np.float64
+    np.testing.assert_allclose(y[z["row_idx"]], z["y_rows"][0], rtol=0, atol=1e-12)
+    power = np.mean(np.abs(y) ** 2, axis=0)
+    np.testing.assert_allclose(power, z["power"][0], rtol=1e-10)
+    assert int(np.argmax(power)) == 83
+
+
+def test_apply_to_template_reference_rng_order(cfg2):
+    """np.random.seed(1234); doa = rand(1)*2pi; apply_to_template(...) -> the reference's trials."""
+    z = golden("trials_cfg2.npz")
+    bf = make_beamformer()
+    fs = 48_000
+    time_test = np.arange(0, 100e-3, step=1 / fs)
+    sig_test = np.sin(2 * np.pi * 2000 * time_test)
+    np.random.seed(1234)
+    for i in range(3):
+        doa = np.random.rand(1)[0] * 2 * np.pi
+        assert doa == z["doa"][i]
+        y = bf.apply_to_template(bf_mat=cfg2["bf_mat"], template=(time_test, sig_test, doa), snr_db=float(z["snr_db"]))
+        power = np.mean(np.abs(y) ** 2, axis=0)
+        assert int(np.argmax(power)) == int(z["argmax"][i])
+        np.testing.assert_allclose(power, z["power"][i], rtol=1e-10)
+
+
+def test_sweep_seed0_matches_reference(cfg2):
+    """300 trials of the paper's sweep (3 SNRs x 100): identical arg-max and MAE to the reference."""
+    from haghighatshoarmuir2024_amd.sweep import noisy_target_sweep
+
+    z = golden("sweep_seed0.npz")
+    bf = make_beamformer()
+    res = noisy_target_sweep(bf, cfg2["bf_mat"], cfg2["doa_list"], snr_db_vec=z["snr_db_vec"], num_sim=100, seed=int(z["seed"]), mode="parity")
+    np.testing.assert_array_equal(res["doa"], z["doa"])
+    np.testing.assert_array_equal(res["argmax"], z["argmax"])
+    np.testing.assert_allclose(res["err"], z["err"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(res["mae_deg"], z["mae_deg"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(res["pmax"], z["pmax"], rtol=1e-10)
+
+
+def test_synthesis_matches_reference(cfg2):
+    from haghighatshoarmuir2024_amd.snn_beamformer import synthesize_array_signal
+
+    z = golden("synth.npz")
+    bf = make_beamformer()
+    for name in ("fixed", "moving"):
+        doa = z[f"{name}_doa"]
+        doa = float(doa) if doa.ndim == 0 else doa
+        t, sig = synthesize_array_signal(bf.geometry, 48_000, z["time_test"], z["sig_test"], doa)
+        np.testing.assert_array_equal(t, z[f"{name}_time"])
+        np.testing.assert_allclose(sig, z[f"{name}_sig"], rtol=0, atol=1e-100)
+
+
+def test_design_from_template_bipolar_subset(cfg2):
+    """Device chain + host SVD reproduces the reference's bf_mat columns (same LAPACK, inputs equal to ~1e-15)."""
+    z = golden("bf_mat_chirp449_bipolar.npz")
+    bf = make_beamformer()
+    fs = 48_000
+    time_temp = np.arange(0, 1.0, step=1 / fs)
+    period = time_temp[-1]
+    freq_inst = 1000 + 1000 * (time_temp % period) / period
+    sig_temp = np.sin(2 * np.pi * np.cumsum(freq_inst) / fs)
+    idx = z["cov_idx"][:6]
+    W = bf.design_from_template((time_temp, sig_temp), z["doa_list"][idx], doa_batch=3)
+    assert W.shape == (14, len(idx))
+    ref = z["bf_mat"][:, idx]
+    # columns are defined up to a unit complex phase of U[:,0]; compare after aligning the phase
+    Wc, Rc = W[:7] + 1j * W[7:], ref[:7] + 1j * ref[7:]
+    phase = np.sum(np.conj(Wc) * Rc, axis=0)
+    phase /= np.abs(phase)
+    np.testing.assert_allclose(Wc * phase, Rc, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(W, ref, rtol=0, atol=1e-8)  # and in practice LAPACK picks the same phase
+
+
+def test_design_from_template_unipolar_subset():
+    from micloc.array_geometry import CenterCircularArray
+    from micloc.snn_beamformer import SNNBeamformer
+
+    z = golden("bf_mat_sin225_unipolar.npz")
+    f, fs = 2000, 48_000
+    tau = 1 / (2 * np.pi * f)
+    bf = SNNBeamformer(CenterCircularArray(4.5e-2, 7), 10e-3, [0.5 * f, 2 * f], np.asarray([tau, tau]), bipolar_spikes=False, fs=fs)
+    time_temp = np.arange(0, 0.4, step=1 / fs)
+    idx = z["cov_idx"][:4]
+    W = bf.design_from_template((time_temp, np.sin(2 * np.pi * f * time_temp)), z["doa_list"][idx])
+    np.testing.assert_allclose(W, z["bf_mat_f2000"][:, idx], rtol=0, atol=1e-7)
+
+
+def test_beamformer_class_surface(cfg2):
+    from micloc.array_geometry import CenterCircularArray
+    from micloc.beamformer import Beamformer
+
+    z = golden("beamformer_c128.npz")
+    bf = Beamformer(CenterCircularArray(4.5e-2, 7), 10e-3, [1000.0, 2000.0], fs=48_000)
+    y = bf.apply_to_signal(z["bf_mat"], z["sig_in"])
+    assert y.dtype == np.complex128 and y.shape == (4799, 57)
+    np.testing.assert_allclose(y[z["row_idx"]], z["y_rows"], rtol=0, atol=1e-11)
+    np.random.seed(99)
+    doa = np.random.rand(1)[0] * 2 * np.pi
+    fs = 48_000
+    time_test = np.arange(0, 100e-3, step=1 / fs)
+    y2 = bf.apply_to_template(z["bf_mat"], (time_test, np.sin(2 * np.pi * 2000 * time_test), doa), snr_db=3.0)
+    np.testing.assert_allclose(np.mean(np.abs(y2) ** 2, axis=0), z["power"], rtol=1e-10)
+    # design (no interference removal): covariances to 1e-12, bf_mat columns up to phase
+    t = np.arange(0, 1.0, step=1 / fs)
+    period = t[-1]
+    s = np.sin(2 * np.pi * np.cumsum(1000 + 1000 * (t % period) / period) / fs)
+    W, covs = bf.design_from_template((t, s), z["doa_list"][:5])
+    np.testing.assert_allclose(np.asarray(covs), z["cov_list"][:5], rtol=0, atol=1e-11)
+    phase = np.sum(np.conj(W) * z["bf_mat"][:, :5], axis=0)
+    np.testing.assert_allclose(W * (phase / np.abs(phase)), z["bf_mat"][:, :5], rtol=0, atol=1e-8)
