@@ -1,0 +1,252 @@
+#!/usr/bin/env python3
+"""Headline benchmark: audio frames/s through the full STHT -> RZCC -> SNN-beamform pipeline.
+
+Workload (BASELINE.json configs[1], target_snn_localization.py): 7-mic centre-circular array, 48 kHz,
+0.1 s noisy 2 kHz test tone (T = 4799 frames), 11 SNRs x 100 Monte-Carlo trials = 1100 trials per step,
+DoA grid 360 (BASELINE's nominal grid; `--grid 449` selects the script-exact one), bf_mat designed from the
+1 s 1->2 kHz chirp with design_from_template on the device before timing.  One "step" = one pass of the
+hot path over the 1100-trial batch (inputs resident in HBM): STHT, band-pass, RZCC, LIF, beamforming,
+power, arg-max, DoA error / MAE.  Weak scaling: every rank processes its own 1100-trial batch.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--grid G] [--no-cpu-baseline]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for the field definitions).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X datasheet fp64 matrix = fp64 vector = 1/2 of the 157.3 TF fp32 rate in MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--grid", type=int, default=360)
+    ap.add_argument("--trials", type=int, default=1100, help="trials per rank per step (11 SNRs x 100)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=300, help="trials timed on the CPU oracle")
+    ap.add_argument("--traffic-bytes", type=float, default=None, help="HBM bytes per dominant-kernel launch from a separate rocprofv3 --pmc pass")
+    return ap.parse_args()
+
+
+def build_workload(args, rank, device):
+    import torch
+
+    from haghighatshoarmuir2024_amd.array_geometry import CenterCircularArray
+    from haghighatshoarmuir2024_amd.snn_beamformer import SNNBeamformer, neuron_impulse_response, synthesize_array_signal
+
+    fs, num_mic, freq_design = 48_000, 7, 2000.0
+    freq_range = [0.5 * freq_design, freq_design]
+    tau = 1.0 / (2 * np.pi * freq_design)
+    geometry = CenterCircularArray(radius=4.5e-2, num_mic=num_mic)
+    beamf = SNNBeamformer(geometry=geometry, kernel_duration=10.0e-3, tau_vec=np.asarray([tau, tau]), freq_range=freq_range, fs=fs,
+                          bipolar_spikes=True, device=device)
+    # chirp template and DoA grid (target_snn_localization.py:345-371)
+    time_temp = np.arange(0, 1.0, step=1 / fs)
+    period = time_temp[-1]
+    freq_inst = freq_range[0] + (freq_range[1] - freq_range[0]) * (time_temp % period) / period
+    sig_temp = np.sin(2 * np.pi * np.cumsum(freq_inst) / fs)
+    doa_list = np.linspace(-np.pi, np.pi, args.grid)
+    bf_mat = beamf.design_from_template((time_temp, sig_temp), doa_list)
+
+    # test signals (target_snn_localization.py:435-455): synthetic, generated here, noise drawn on the device
+    time_test = np.arange(0, 100e-3, step=1 / fs)
+    sig_test = np.sin(2 * np.pi * freq_design * time_test)
+    B = args.trials
+    rng = np.random.RandomState(1000 + rank)
+    doa = rng.rand(B) * 2 * np.pi
+    snr_db_vec = np.linspace(-10, 20, 11)
+    snr_db = snr_db_vec[(np.arange(B) * len(snr_db_vec)) // B] - 10 * np.log10((fs / 2) / (freq_range[1] - freq_range[0]))
+    clean = []
+    time_in = None
+    for i in range(B):
+        time_in, sig = synthesize_array_signal(geometry, fs, time_test, sig_test, doa[i])
+        clean.append(sig)
+    clean = torch.from_numpy(np.stack(clean)).to(device)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(1234 + rank)
+    sigma = torch.sqrt(torch.mean(clean**2, dim=(1, 2))) / torch.sqrt(10 ** (torch.from_numpy(snr_db).to(device) / 10))
+    x = (clean + sigma[:, None, None] * torch.randn(clean.shape, generator=gen, device=device, dtype=torch.float64)).contiguous()
+    del clean
+
+    plan = beamf.plan()
+    nir = neuron_impulse_response(time_in, beamf.tau_vec)
+    plan.set_neuron_kernel(nir)
+    plan.set_bf_mat(bf_mat)
+    return dict(beamf=beamf, plan=plan, x=x, doa=torch.from_numpy(doa).to(device), doa_list=torch.from_numpy(doa_list).to(device),
+                bf_mat=bf_mat, nir=nir, snr_groups=len(snr_db_vec), fs=fs)
+
+
+def make_step(wl):
+    import torch
+
+    plan, x, doa, doa_list, S = wl["plan"], wl["x"], wl["doa"], wl["doa_list"], wl["snr_groups"]
+
+    def step():
+        out = plan.snn_pipeline(x, want_power=True)
+        est = doa_list[out["argmax"].long()]
+        err = torch.arcsin(torch.abs(torch.sin(est - doa)))
+        mae = err.reshape(S, -1).mean(dim=1)
+        return out, mae
+
+    return step
+
+
+def stage_times(wl, iters):
+    """Average duration of each stage of the pipeline (HIP events on the launch stream), in ms."""
+    import torch
+
+    plan, x = wl["plan"], wl["x"]
+    B, T, M = x.shape
+    h = plan.stht(x)
+    _, spikes = plan.bandpass_rzcc(h, T, want_pre=False, want_spikes=True)
+    res = {}
+
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize()
+        e0 = [torch.cuda.Event(enable_timing=True) for _ in range(iters)]
+        e1 = [torch.cuda.Event(enable_timing=True) for _ in range(iters)]
+        for i in range(iters):
+            e0[i].record()
+            fn()
+            e1[i].record()
+        torch.cuda.synchronize()
+        return float(np.mean([a.elapsed_time(b) for a, b in zip(e0, e1)]))
+
+    res["stht_kernel"] = timed(lambda: plan.stht(x))
+    res["bandpass_rzcc_kernel"] = timed(lambda: plan.bandpass_rzcc(h, T, want_pre=False, want_spikes=True))
+    res["beamform_kernel"] = timed(lambda: plan.lif_beamform(spikes, want_power=True))
+    return res
+
+
+def cpu_baseline(wl, n):
+    """The oracle (CPU restatement, scalar C, one thread) on the first n trials of the same batch."""
+    from oracle import oracle as O
+
+    beamf = wl["beamf"]
+    x = wl["x"][:n].cpu().numpy()
+    b, a = beamf.bandpass_filter
+    O.lib()
+    t0 = time.perf_counter()
+    pw, am = O.snn_chain_batch(x, beamf.kernel, b, a, beamf.spk_encoder.robust_width, True, wl["nir"], wl["bf_mat"])
+    dt = time.perf_counter() - t0
+    return dict(value=n * x.shape[1] / dt, unit="frames/s", cores=1, kind="port",
+                sample=f"{n} of the {wl['x'].shape[0]} trials of the same batch (T={x.shape[1]}, M={x.shape[2]}, G={wl['bf_mat'].shape[1]}), "
+                       f"{dt:.1f} s, oracle/micloc_oracle.c single thread"), am
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    wl = build_workload(args, rank, device)
+    step = make_step(wl)
+    B, T, M = wl["x"].shape
+    G = wl["bf_mat"].shape[1]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out, mae = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        # the sweep's one exchange step: gather the per-rank MAE curves (RCCL)
+        gathered = [torch.empty_like(mae) for _ in range(world)]
+        dist.all_gather(gathered, mae)
+        mae = torch.stack(gathered).mean(dim=0)
+    dt = float(tmax.item())
+    frames = world * B * T * args.steps
+    value = frames / dt
+
+    result = None
+    if rank == 0:
+        st = stage_times(wl, max(5, min(args.steps, 20)))
+        n_nir = len(wl["nir"])
+        C = 2 * M
+        # algorithmic work per frame (SURVEY 8d / DESIGN.md): dense-tap STHT as the reference computes it
+        flops = {
+            "stht_kernel": 2 * len(wl["beamf"].kernel) * M,
+            "bandpass_rzcc_kernel": 17 * C,
+            "beamform_kernel": 2 * n_nir * C + 2 * C * G + 2 * G,
+        }
+        dom = max(st, key=st.get)
+        frames_launch = B * T
+        if dom == "bandpass_rzcc_kernel":
+            # latency-bound sequential stage: price it against HBM with its algorithmic bytes (8 B in per channel sample + 1 B spike out)
+            achieved = frames_launch * (8 * C + C) / (st[dom] * 1e-3) / 1e9
+            roof = dict(kernel=dom, bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
+                        traffic=args.traffic_bytes)
+        else:
+            achieved = frames_launch * flops[dom] / (st[dom] * 1e-3) / 1e12
+            roof = dict(kernel=dom, bound="mfma", achieved=achieved, peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                        frac=achieved / FP64_MFMA_PEAK_TFLOPS, traffic=args.traffic_bytes)
+        roof["avg_launch_ms"] = st[dom]
+        roof["stages_ms"] = st
+        result = {
+            "metric": "audio samples/sec through STHT+RZCC+SNN beamform, 7-mic 48kHz 360-DoA; DoA MAE vs ref",
+            "value": value,
+            "unit": "frames/s (one frame = one 7-mic audio sample instant)",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"target_snn_localization noisy sweep: 7-mic centre-circular, 48 kHz, T={T}, {B} trials/GPU/step (11 SNR x {B // 11}), "
+                                   f"{G}-DoA grid, bipolar RZCC, bf_mat designed on device from the 1 s chirp",
+                       "trials_per_gpu": B, "frames_per_trial": T, "num_mic": M, "num_doa": G, "mic_samples_per_s": value * M,
+                       "parallelism": f"trial-sharded x{world}"},
+            "mae_deg_per_snr": [float(v) for v in (mae * 180 / np.pi).cpu().numpy()],
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            cb, am_cpu = cpu_baseline(wl, min(args.cpu_sample, B))
+            am_gpu = out["argmax"][: len(am_cpu)].cpu().numpy()
+            cb["argmax_equal_to_gpu"] = bool(np.array_equal(am_cpu, am_gpu))
+            result["cpu_baseline"] = cb
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -34,7 +34,7 @@ size_t beamform_partial_bytes(int B, int T, int Gp)
     return ((size_t)B * beamform_nchunks(T) * Gp * sizeof(double) + 255) & ~(size_t)255;
 }
 
-template <int CT, bool SRC_SPIKES, bool W_LDS>
+template <int CT, bool SRC_SPIKES, bool W_LDS, bool WANT_Y>
 __global__ __launch_bounds__(BF_THREADS) void beamform_kernel(const int8_t *__restrict__ spikes,
                                                                const double *__restrict__ pre,
                                                                const double *__restrict__ ntab_g, int NK,
@@ -45,6 +45,7 @@ __global__ __launch_bounds__(BF_THREADS) void beamform_kernel(const int8_t *__re
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int Kp = 16 * CT;
     constexpr int Cs = 16 * CT;  // padded spike row (bytes)
+    constexpr int KS = 4 * CT;   // beamforming k-steps
     const int Gp = 16 * GT;
     const int tid = threadIdx.x;
     const int wv = tid >> 6;
@@ -65,7 +66,9 @@ __global__ __launch_bounds__(BF_THREADS) void beamform_kernel(const int8_t *__re
     const int R = BF_CHUNK + 4 * NK - 16;  // staged spike rows
 
     if (W_LDS) {
-        for (int e = tid; e < Kp * Gp; e += BF_THREADS) Wl[e] = Wp[e];
+        const double2 *src2 = reinterpret_cast<const double2 *>(Wp);
+        double2 *dst2 = reinterpret_cast<double2 *>(Wl);
+        for (int e = tid; e < (Kp * Gp) / 2; e += BF_THREADS) dst2[e] = src2[e];
     }
     if (SRC_SPIKES) {
         for (int e = tid; e < ntab_len; e += BF_THREADS) ntab[e] = ntab_g[e];
@@ -82,27 +85,54 @@ __global__ __launch_bounds__(BF_THREADS) void beamform_kernel(const int8_t *__re
     __syncthreads();
 
     // ---- stage 1: membrane fragments Vf[tt][ct] (4 doubles each) ------------------------------------------
+    // The 4 time tiles of the wave are 4 independent accumulation chains; the operands of k-step ks+1
+    // are fetched from LDS while the MFMAs of k-step ks run.
+    const int tb0 = cs + wv * BF_NT * 16;
     double4_t Vf[BF_NT][CT];
-#pragma unroll
-    for (int tt = 0; tt < BF_NT; ++tt) {
-        const int tb = cs + (wv * BF_NT + tt) * 16;
-        const bool tvalid = (tb + lc) < T;
+    if (SRC_SPIKES) {
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
-            double4_t acc = {0.0, 0.0, 0.0, 0.0};
-            if (SRC_SPIKES) {
-                if (tb < T) {  // wave-uniform
-                    const int8_t *sp = spk + (size_t)(tb - cs + q) * Cs + 16 * ct + lc;
-                    const double *np_ = ntab + (lc - q + 4 * NK - 16 + 15);
-                    for (int ks = 0; ks < NK; ++ks) {
-                        const double a = (double)sp[(size_t)(4 * ks) * Cs];
-                        const double bn = np_[-4 * ks];
-                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bn, acc, 0, 0, 0);
-                    }
-                }
+            double4_t acc[BF_NT];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[r] = tvalid ? acc[r] : 0.0;
-            } else {
+            for (int tt = 0; tt < BF_NT; ++tt) acc[tt] = double4_t{0.0, 0.0, 0.0, 0.0};
+            if (tb0 < T) {  // wave-uniform
+                const int8_t *sp = spk + (size_t)(tb0 - cs + q) * Cs + 16 * ct + lc;
+                const double *np_ = ntab + (lc - q + 4 * NK - 16 + 15);
+                double bn_n = np_[0];
+                int an[BF_NT];
+#pragma unroll
+                for (int tt = 0; tt < BF_NT; ++tt) an[tt] = sp[(size_t)(16 * tt) * Cs];
+                for (int ks = 0; ks < NK; ++ks) {
+                    const double bn = bn_n;
+                    double a[BF_NT];
+#pragma unroll
+                    for (int tt = 0; tt < BF_NT; ++tt) a[tt] = (double)an[tt];
+                    if (ks + 1 < NK) {
+                        bn_n = np_[-4 * (ks + 1)];
+#pragma unroll
+                        for (int tt = 0; tt < BF_NT; ++tt) an[tt] = sp[(size_t)(16 * tt + 4 * (ks + 1)) * Cs];
+                    }
+#pragma unroll
+                    for (int tt = 0; tt < BF_NT; ++tt)
+                        acc[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tt], bn, acc[tt], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int tt = 0; tt < BF_NT; ++tt) {
+                const bool tvalid = (tb0 + 16 * tt + lc) < T;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[tt][r] = tvalid ? acc[tt][r] : 0.0;
+                Vf[tt][ct] = acc[tt];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int tt = 0; tt < BF_NT; ++tt) {
+            const int tb = tb0 + 16 * tt;
+            const bool tvalid = (tb + lc) < T;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                double4_t acc;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int c = 16 * ct + 4 * r + q;
@@ -110,43 +140,46 @@ __global__ __launch_bounds__(BF_THREADS) void beamform_kernel(const int8_t *__re
                     if (tvalid && c < C) v = pre[((size_t)b * C + c) * Ts + tb + lc];
                     acc[r] = v;
                 }
+                Vf[tt][ct] = acc;
             }
-            Vf[tt][ct] = acc;
         }
     }
 
     // ---- stage 2: beamforming + power, one 16-column DoA tile at a time ------------------------------------
+    // Two accumulator sets: the MFMAs of tile gt+1 are issued before the (VALU) epilogue of tile gt, so the
+    // matrix pipe never waits for the squares / shuffles / stores.
     const double *Wsrc = W_LDS ? Wl : Wp;
     const int Ghp = Gp >> 1;  // complex variant: [0, Ghp) real part, [Ghp, Gp) imaginary part
-    for (int gt = 0; gt < GT; ++gt) {
-        double Wf[CT][4];
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) Wf[ct][r] = Wsrc[(size_t)(16 * ct + 4 * r + q) * Gp + 16 * gt + lc];
 
-        double4_t acc[BF_NT];
+    auto load_w = [&](int gt, double (&Wf)[KS]) {
+        const double *wp = Wsrc + (size_t)q * Gp + 16 * gt + lc;
+#pragma unroll
+        for (int k = 0; k < KS; ++k) Wf[k] = wp[(size_t)(4 * k) * Gp];
+    };
+    auto issue = [&](const double (&Wf)[KS], double4_t (&acc)[BF_NT]) {
 #pragma unroll
         for (int tt = 0; tt < BF_NT; ++tt) acc[tt] = double4_t{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct)
+        for (int k = 0; k < KS; ++k)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+            for (int tt = 0; tt < BF_NT; ++tt)
+                acc[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(Vf[tt][k >> 2][k & 3], Wf[k], acc[tt], 0, 0, 0);
+    };
+    auto epilogue = [&](int gt, const double4_t (&acc)[BF_NT]) {
+        double sqt[BF_NT];
 #pragma unroll
-                for (int tt = 0; tt < BF_NT; ++tt)
-                    acc[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(Vf[tt][ct][r], Wf[ct][r], acc[tt], 0, 0, 0);
-
-        double sq = 0.0;
+        for (int tt = 0; tt < BF_NT; ++tt) {
+            double s_ = acc[tt][0] * acc[tt][0];
 #pragma unroll
-        for (int tt = 0; tt < BF_NT; ++tt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) sq = __builtin_fma(acc[tt][r], acc[tt][r], sq);
-
-        if (y) {
+            for (int r = 1; r < 4; ++r) s_ = __builtin_fma(acc[tt][r], acc[tt][r], s_);
+            sqt[tt] = s_;
+        }
+        double sq = (sqt[0] + sqt[1]) + (sqt[2] + sqt[3]);
+        if (WANT_Y) {
             const int gcol = 16 * gt + lc;
 #pragma unroll
             for (int tt = 0; tt < BF_NT; ++tt) {
-                const int tb = cs + (wv * BF_NT + tt) * 16;
+                const int tb = tb0 + 16 * tt;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int t = tb + q + 4 * r;
@@ -165,6 +198,31 @@ __global__ __launch_bounds__(BF_THREADS) void beamform_kernel(const int8_t *__re
         sq += __shfl_xor(sq, 16);
         sq += __shfl_xor(sq, 32);
         if (l < 16) red[(size_t)wv * Gp + 16 * gt + l] = sq;
+    };
+
+    {
+        double WfA[KS], WfB[KS];
+        double4_t accA[BF_NT], accB[BF_NT];
+        load_w(0, WfA);
+        issue(WfA, accA);
+        int gt = 0;
+        for (; gt + 2 < GT; gt += 2) {
+            load_w(gt + 1, WfB);
+            issue(WfB, accB);
+            epilogue(gt, accA);
+            load_w(gt + 2, WfA);
+            issue(WfA, accA);
+            epilogue(gt + 1, accB);
+        }
+        // tail: gt is the last issued-into-A tile; one or two tiles remain
+        if (gt + 1 < GT) {
+            load_w(gt + 1, WfB);
+            issue(WfB, accB);
+            epilogue(gt, accA);
+            epilogue(gt + 1, accB);
+        } else {
+            epilogue(gt, accA);
+        }
     }
     __syncthreads();
     if (partial) {
@@ -193,21 +251,27 @@ static hipError_t launch_bf(const BeamformW &W, const NeuronTab *nt, const int8_
     dim3 grid(beamform_nchunks(T), B), block(BF_THREADS);
     const double *tab = SRC_SPIKES ? nt->tab : nullptr;
     hipError_t e;
+#define BF_LAUNCH(WL, WY, LDSB)                                                                                       \
+    do {                                                                                                             \
+        auto k = &beamform_kernel<CT, SRC_SPIKES, WL, WY>;                                                           \
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,       \
+                                160 * 1024);                                                                         \
+        if (e != hipSuccess) return e;                                                                               \
+        hipLaunchKernelGGL(k, grid, block, (LDSB), stream, spikes, pre, tab, NK, W.Wp, W.GT, W.C, W.G, T, Ts, y,      \
+                           y_complex, partial);                                                                      \
+    } while (0)
     if (w_lds) {
-        auto k = &beamform_kernel<CT, SRC_SPIKES, true>;
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k, grid, block, lds + wbytes, stream, spikes, pre, tab, NK, W.Wp, W.GT, W.C, W.G, T, Ts, y,
-                           y_complex, partial);
+        if (y)
+            BF_LAUNCH(true, true, lds + wbytes);
+        else
+            BF_LAUNCH(true, false, lds + wbytes);
     } else {
-        auto k = &beamform_kernel<CT, SRC_SPIKES, false>;
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k, grid, block, lds, stream, spikes, pre, tab, NK, W.Wp, W.GT, W.C, W.G, T, Ts, y,
-                           y_complex, partial);
+        if (y)
+            BF_LAUNCH(false, true, lds);
+        else
+            BF_LAUNCH(false, false, lds);
     }
+#undef BF_LAUNCH
     return hipGetLastError();
 }
 

@@ -5,200 +5,350 @@
 // The encoder contract is bit-exact, and both the DF2T recurrence and np.cumsum are strictly
 // sequential in time, so the time axis is NOT parallelised: one lane owns one (trial, channel) stream
 // and walks it with the exact operation order of oracle/micloc_oracle.c; parallelism comes from the
-// B x 2M independent streams (one wave = 64 streams, one wave per workgroup so the streams spread
-// over all CUs).  Input is the planar [stream][Ts] layout written by the STHT kernel, so each lane
-// reads its own 64-byte line per 8 steps (16-byte vector loads, next chunk prefetched).
+// B x 2M independent streams.  The kernel is therefore bound by the instruction-issue latency of one
+// wave per 64 streams, and everything is arranged to keep that wave's loop short and stall-free:
 //
-// Phase 1 (stream): y = IIR(x); c += y; local maxima / minima of c with scipy's plateau rule
-//   (_local_maxima_1d: strict rise, flat run, strict fall -> midpoint, edges never peaks) are appended
-//   to per-lane candidate lists kept slot-major in scratch so the lock-step appends/reads coalesce.
-// Phase 2 (select): scipy's _select_by_peak_distance is a greedy by descending priority; peaks only
-//   interact within `distance`, so the list splits into independent clusters at every gap >= distance
-//   and the greedy is run per cluster (equal priority: the later peak wins, i.e. a stable sort).
-//   Kept peaks are scattered as +1 / -1 bytes into the zero-initialised [B][T][C] spike tensor.
+//   * workgroup = 2 waves.  Wave 1 is a LOADER: it streams 32-step x 64-stream input tiles from the
+//     planar [stream][Ts] layout (256-byte coalesced row segments) into a double-buffered, transposed
+//     LDS tile and (for the band-pass-only variants) stores the filtered tile back.  Wave 0 is the
+//     COMPUTE wave: it reads its sample from LDS, so no global load ever sits in front of its global
+//     stores in the in-order vmcnt queue (measured: a conditional global store in the serial loop cost
+//     a vmcnt(0) drain per chunk and 2.5x the loop time).
+//   * detection is branch-free: per step two fp64 compares maintain (dir, left) = direction and index
+//     of the last strict change of the cumulative sum; a maximum completes when c falls after a rise
+//     (scipy _local_maxima_1d: plateau -> midpoint, edges never peaks), minima mirror it.  Candidates
+//     are written unconditionally into a per-lane LDS ring; the write index only advances on an event.
+//   * scipy's _select_by_peak_distance (greedy by descending priority, later peak wins ties) only
+//     couples peaks closer than `distance`, so the candidate list splits into independent clusters at
+//     every same-polarity gap >= distance.  After each 32-step tile the compute wave walks the NEW
+//     events (not the time steps), closes finished clusters, resolves them in LDS and scatters the kept
+//     peaks as +1 / -1 bytes into the zero-initialised [B][T][C] spike tensor.
+//   * a cluster that outgrows the LDS ring (pathological inputs: long runs of close peaks) flags its
+//     stream; flagged streams are redone by a slow list-based kernel with unbounded capacity, so the
+//     result is exact for every input.
 #include "micloc_internal.h"
 
 namespace micloc {
 
-constexpr int RZ_CHUNK = 8;
-
-struct PeakState {
-    int left;   // start of the current candidate plateau, -1 if none
-    double pv;  // its value
-};
+constexpr int RZ_MACRO = 32;   // time steps per LDS tile
+constexpr int RZ_RING = 64;    // candidate ring entries per stream (power of two)
+constexpr int RZ_ROW = 65;     // padded row of the transposed input tile (doubles)
 
 template <int N>
-__global__ __launch_bounds__(64) void bandpass_rzcc_kernel(const double *__restrict__ h, double *__restrict__ pre,
-                                                            int8_t *__restrict__ spikes, int *__restrict__ plist,
-                                                            double *__restrict__ vlist, IirCoef coef, int nlanes,
-                                                            int C, int T, int Ts, int w, int bipolar, int cap)
-{
-    const int lane_g = blockIdx.x * 64 + threadIdx.x;
-    if (lane_g >= nlanes) return;
-    const double *src = h + (size_t)lane_g * Ts;
-    double *dst = pre ? pre + (size_t)lane_g * Ts : nullptr;
-
+struct Iir {
     double z[N > 1 ? N - 1 : 1];
-#pragma unroll
-    for (int i = 0; i < (N > 1 ? N - 1 : 1); ++i) z[i] = 0.0;
 
-    double c = 0.0, prev = 0.0;
-    PeakState smax{-1, 0.0}, smin{-1, 0.0};
-    int cnt_max = 0, cnt_min = 0;
-    const size_t pol_stride = (size_t)cap * nlanes;
-    const bool want_spikes = spikes != nullptr;
-
-    double2 nxt[RZ_CHUNK / 2];
+    __device__ __forceinline__ void init()
+    {
 #pragma unroll
-    for (int i = 0; i < RZ_CHUNK / 2; ++i) nxt[i] = reinterpret_cast<const double2 *>(src)[i];
+        for (int i = 0; i < (N > 1 ? N - 1 : 1); ++i) z[i] = 0.0;
+    }
 
-    for (int t0 = 0; t0 < T; t0 += RZ_CHUNK) {
-        double xv[RZ_CHUNK], yv[RZ_CHUNK];
+    __device__ __forceinline__ double step(const IirCoef &coef, double xin)
+    {
+        double y;
+        if (N == 1) {
+            y = __builtin_fma(coef.b[0], xin, 0.0);
+        } else {
+            y = __builtin_fma(coef.b[0], xin, z[0]);
 #pragma unroll
-        for (int i = 0; i < RZ_CHUNK / 2; ++i) {
-            xv[2 * i] = nxt[i].x;
-            xv[2 * i + 1] = nxt[i].y;
+            for (int i = 0; i < N - 2; ++i)
+                z[i] = __builtin_fma(-coef.a[i + 1], y, __builtin_fma(coef.b[i + 1], xin, z[i + 1]));
+            z[N - 2] = __builtin_fma(-coef.a[N - 1], y, coef.b[N - 1] * xin);
         }
-        if (t0 + RZ_CHUNK < T) {
-#pragma unroll
-            for (int i = 0; i < RZ_CHUNK / 2; ++i)
-                nxt[i] = reinterpret_cast<const double2 *>(src + t0 + RZ_CHUNK)[i];
-        }
-#pragma unroll
-        for (int jj = 0; jj < RZ_CHUNK; ++jj) {
-            const int t = t0 + jj;
-            if (t < T) {  // wave-uniform
-                const double xin = xv[jj];
-                double y;
-                if (N == 1) {
-                    y = __builtin_fma(coef.b[0], xin, 0.0);
-                } else {
-                    y = __builtin_fma(coef.b[0], xin, z[0]);
-#pragma unroll
-                    for (int i = 0; i < N - 2; ++i)
-                        z[i] = __builtin_fma(-coef.a[i + 1], y, __builtin_fma(coef.b[i + 1], xin, z[i + 1]));
-                    z[N - 2] = __builtin_fma(-coef.a[N - 1], y, coef.b[N - 1] * xin);
-                }
-                yv[jj] = y;
-                if (want_spikes) {
-                    c = c + y;
-                    if (t > 0) {
-                        // ---- local maxima of c (scipy _local_maxima_1d, streaming form) ----
-                        if (smax.left >= 0) {
-                            if (c < smax.pv) {
-                                if (cnt_max < cap) {
-                                    plist[(size_t)cnt_max * nlanes + lane_g] = (smax.left + t - 1) >> 1;
-                                    vlist[(size_t)cnt_max * nlanes + lane_g] = smax.pv;
-                                }
-                                ++cnt_max;
-                                smax.left = -1;
-                            } else if (c > smax.pv) {
-                                smax.left = t;
-                                smax.pv = c;
-                            }
-                        } else if (prev < c) {
-                            smax.left = t;
-                            smax.pv = c;
-                        }
-                        // ---- local minima of c == local maxima of -c ----
-                        if (bipolar) {
-                            if (smin.left >= 0) {
-                                if (c > smin.pv) {
-                                    if (cnt_min < cap) {
-                                        plist[pol_stride + (size_t)cnt_min * nlanes + lane_g] = (smin.left + t - 1) >> 1;
-                                        vlist[pol_stride + (size_t)cnt_min * nlanes + lane_g] = -smin.pv;
-                                    }
-                                    ++cnt_min;
-                                    smin.left = -1;
-                                } else if (c < smin.pv) {
-                                    smin.left = t;
-                                    smin.pv = c;
-                                }
-                            } else if (prev > c) {
-                                smin.left = t;
-                                smin.pv = c;
-                            }
-                        }
-                    }
-                    prev = c;
-                }
-            } else {
-                yv[jj] = 0.0;
+        return y;
+    }
+};
+
+// Greedy min-distance selection inside one cluster.  Entries live at list indices s, s+stride, ... < e;
+// word = (position << 1) | polarity, complemented once decided.  `at(i)` maps a list index to storage.
+template <typename WordAt, typename ValAt>
+__device__ __forceinline__ void resolve_cluster(int s, int e, int stride, int w, int8_t mark, int8_t *sp, int C,
+                                                WordAt word_at, ValAt val_at)
+{
+    int remaining = (e - s + stride - 1) / stride;
+    while (remaining > 0) {
+        int best = -1;
+        double bv = 0.0;
+        for (int k = s; k < e; k += stride) {
+            const int wk = *word_at(k);
+            if (wk < 0) continue;
+            const double vk = *val_at(k);
+            if (best < 0 || vk >= bv) {  // >= : equal priority -> the later peak wins (stable sort order)
+                best = k;
+                bv = vk;
             }
         }
-        if (dst) {
-#pragma unroll
-            for (int i = 0; i < RZ_CHUNK / 2; ++i)
-                reinterpret_cast<double2 *>(dst + t0)[i] = make_double2(yv[2 * i], yv[2 * i + 1]);
+        const int wb = *word_at(best);
+        const int pb = wb >> 1;
+        sp[(size_t)pb * C] = mark;
+        *word_at(best) = ~wb;
+        --remaining;
+        for (int k = best - stride; k >= s; k -= stride) {
+            const int wk = *word_at(k);
+            const int pk = (wk < 0 ? ~wk : wk) >> 1;
+            if (pb - pk >= w) break;
+            if (wk >= 0) {
+                *word_at(k) = ~wk;
+                --remaining;
+            }
+        }
+        for (int k = best + stride; k < e; k += stride) {
+            const int wk = *word_at(k);
+            const int pk = (wk < 0 ? ~wk : wk) >> 1;
+            if (pk - pb >= w) break;
+            if (wk >= 0) {
+                *word_at(k) = ~wk;
+                --remaining;
+            }
         }
     }
-    if (!want_spikes) return;
+}
 
-    // ---- phase 2: min-distance selection, cluster by cluster -----------------------------------------
+// ---------------------------------------------------------------------------------------------------
+// Fast path.
+// ---------------------------------------------------------------------------------------------------
+template <int N, bool WANT_PRE, bool WANT_SPIKES>
+__global__ __launch_bounds__(128) void bandpass_rzcc_fast_kernel(const double *__restrict__ h,
+                                                                  double *__restrict__ pre,
+                                                                  int8_t *__restrict__ spikes,
+                                                                  int *__restrict__ flag_count,
+                                                                  int *__restrict__ flag_list, IirCoef coef,
+                                                                  int nlanes, int C, int T, int Ts, int w, int bipolar)
+{
+    __shared__ __attribute__((aligned(16))) double tile[2][RZ_MACRO][RZ_ROW];
+    __shared__ double ringV[WANT_SPIKES ? RZ_RING : 1][64];
+    __shared__ int ringP[WANT_SPIKES ? RZ_RING : 1][64];
+
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int base = blockIdx.x * 64;
+    const int NM = (T + RZ_MACRO - 1) / RZ_MACRO;
+
+    if (wave == 1) {
+        // ------------------------------- loader wave ---------------------------------------------------
+        // Two tiles ahead: tile m+1 sits in LDS, tile m+2 is in flight in registers, so the loads get a
+        // whole tile time to land and the barrier never waits on memory.
+        const int tl = lane & 31;  // time offset inside the tile
+        const int sh = lane >> 5;  // which of the two streams of a pair
+        const bool full_block = base + 64 <= nlanes;
+        double v[32];
+        auto issue_loads = [&](int m) {
+            int t = m * RZ_MACRO + tl;
+            t = t < Ts ? t : Ts - 1;  // clamp: samples past T are never used by the compute wave
+            if (full_block) {
+                const double *p = h + (size_t)(base + sh) * Ts + t;
+#pragma unroll
+                for (int j = 0; j < 32; ++j) v[j] = p[(size_t)(2 * j) * Ts];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 32; ++j) {
+                    int g = base + 2 * j + sh;
+                    g = g < nlanes ? g : nlanes - 1;
+                    v[j] = h[(size_t)g * Ts + t];
+                }
+            }
+        };
+        auto write_tile = [&](int buf) {
+#pragma unroll
+            for (int j = 0; j < 32; ++j) tile[buf][tl][2 * j + sh] = v[j];
+        };
+        auto store_tile = [&](int m, int buf) {
+            const int t = m * RZ_MACRO + tl;
+            if (full_block && (m + 1) * RZ_MACRO <= Ts) {
+                double *p = pre + (size_t)(base + sh) * Ts + t;
+#pragma unroll
+                for (int j = 0; j < 32; ++j) p[(size_t)(2 * j) * Ts] = tile[buf][tl][2 * j + sh];
+            } else {
+#pragma unroll 4
+                for (int j = 0; j < 32; ++j) {
+                    const int g = base + 2 * j + sh;
+                    if (g < nlanes && t < Ts) pre[(size_t)g * Ts + t] = tile[buf][tl][2 * j + sh];
+                }
+            }
+        };
+        issue_loads(0);
+        write_tile(0);
+        if (NM > 1) issue_loads(1);
+        __syncthreads();
+        for (int m = 0; m < NM; ++m) {
+            if (m + 1 < NM) write_tile((m + 1) & 1);
+            if (m + 2 < NM) issue_loads(m + 2);
+            __syncthreads();
+            if (WANT_PRE) store_tile(m, m & 1);
+        }
+        return;
+    }
+
+    // ----------------------------------- compute wave --------------------------------------------------
+    const int lane_g = base + lane;
+    const bool active = lane_g < nlanes;
+    Iir<N> iir;
+    iir.init();
+    double c = 0.0;
+    double prev = __builtin_nan("");  // comparisons with NaN are false: no event at t = 0
+    int left = 0, dir = 0;
+    int n = 0, n_done = 0;       // candidates appended / processed
+    int s0 = -1, s1 = -1;        // first list index of the open cluster per polarity (-1: none)
+    int l0 = 0, l1 = 0;          // position of the last candidate per polarity
+    bool dead = !active;         // overflowed (or out of range): stop selecting, redo in the fallback kernel
+    const int stride = bipolar ? 2 : 1;
+    const int b = active ? lane_g / C : 0;
+    const int ch = active ? lane_g - b * C : 0;
+    int8_t *sp = WANT_SPIKES ? spikes + (size_t)b * T * C + ch : nullptr;
+
+    auto word_at = [&](int i) { return &ringP[i & (RZ_RING - 1)][lane]; };
+    auto val_at = [&](int i) { return &ringV[i & (RZ_RING - 1)][lane]; };
+    auto close_cluster = [&](int s, int e, int pol, int lastpos) {
+        const int8_t mark = pol ? -1 : 1;
+        if (e - s <= stride)
+            sp[(size_t)lastpos * C] = mark;
+        else
+            resolve_cluster(s, e, stride, w, mark, sp, C, word_at, val_at);
+    };
+
+    __syncthreads();
+    for (int m = 0; m < NM; ++m) {
+        const int buf = m & 1;
+        const int tbase = m * RZ_MACRO;
+        const int steps = (T - tbase) < RZ_MACRO ? (T - tbase) : RZ_MACRO;
+        auto one_step = [&](int j) {
+            const double xin = tile[buf][j][lane];
+            const double y = iir.step(coef, xin);
+            if (WANT_PRE) tile[buf][j][lane] = y;
+            if (WANT_SPIKES) {
+                const int t = tbase + j;
+                c = c + y;
+                const bool rise = c > prev;
+                const bool fall = c < prev;
+                const bool ev = (fall && dir > 0) || (bipolar && rise && dir < 0);
+                // candidate (unconditional store; the slot is only consumed when n advances)
+                const int slot = n & (RZ_RING - 1);
+                ringP[slot][lane] = ((left + t - 1) & ~1) | (rise ? 1 : 0);
+                ringV[slot][lane] = rise ? -prev : prev;
+                n += ev ? 1 : 0;
+                left = (rise || fall) ? t : left;
+                dir = rise ? 1 : (fall ? -1 : dir);
+                prev = c;
+            }
+        };
+        if (steps == RZ_MACRO) {
+#pragma unroll 8
+            for (int j = 0; j < RZ_MACRO; ++j) one_step(j);
+        } else {
+            for (int j = 0; j < steps; ++j) one_step(j);
+        }
+
+        if (WANT_SPIKES) {
+            // ---- walk the new candidates (event order, not time order) and close finished clusters ----
+            for (int i = n_done; __any(!dead && i < n); ++i) {
+                if (!dead && i < n) {
+                    const int word = *word_at(i);
+                    const int pol = word & 1;
+                    const int pos = word >> 1;
+                    const int sp_i = pol ? s1 : s0;
+                    const int lp = pol ? l1 : l0;
+                    int snew = sp_i;
+                    if (sp_i >= 0 && pos - lp >= w) {
+                        close_cluster(sp_i, i, pol, lp);
+                        snew = i;
+                    }
+                    if (sp_i < 0) snew = i;
+                    if (pol) {
+                        s1 = snew;
+                        l1 = pos;
+                    } else {
+                        s0 = snew;
+                        l0 = pos;
+                    }
+                }
+            }
+            n_done = n;
+            // the next tile may append up to RZ_MACRO candidates: everything still open must survive that
+            const int oldest = (s0 >= 0 && (s1 < 0 || s0 < s1)) ? s0 : (s1 >= 0 ? s1 : n);
+            if (!dead && n - oldest > RZ_RING - RZ_MACRO) dead = true;
+        }
+        __syncthreads();
+    }
+    if (WANT_SPIKES && active) {
+        if (!dead) {
+            if (s0 >= 0) close_cluster(s0, n, 0, l0);
+            if (s1 >= 0) close_cluster(s1, n, 1, l1);
+        } else {
+            const int k = atomicAdd(flag_count, 1);
+            flag_list[k] = lane_g;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Fallback for flagged streams: unbounded candidate lists in global scratch (slot-major), selection
+// after the stream.  Slow (conditional global stores in the serial loop) but exact for any input.
+// ---------------------------------------------------------------------------------------------------
+template <int N>
+__global__ __launch_bounds__(64) void rzcc_fallback_kernel(const double *__restrict__ h, int8_t *__restrict__ spikes,
+                                                            const int *__restrict__ flag_count,
+                                                            const int *__restrict__ flag_list, int *__restrict__ plist,
+                                                            double *__restrict__ vlist, IirCoef coef, int nlanes,
+                                                            int C, int T, int Ts, int w, int bipolar)
+{
+    const int idx = blockIdx.x * 64 + threadIdx.x;
+    if (idx >= *flag_count) return;
+    const int lane_g = flag_list[idx];
+    const double *src = h + (size_t)lane_g * Ts;
+    const size_t NL = (size_t)nlanes;
+    int *P = plist + idx;
+    double *V = vlist + idx;
+
+    Iir<N> iir;
+    iir.init();
+    double c = 0.0, prev = __builtin_nan("");
+    int left = 0, dir = 0, n = 0;
+    for (int t = 0; t < T; ++t) {
+        const double y = iir.step(coef, src[t]);
+        c = c + y;
+        const bool rise = c > prev;
+        const bool fall = c < prev;
+        if ((fall && dir > 0) || (bipolar && rise && dir < 0)) {
+            P[(size_t)n * NL] = ((left + t - 1) & ~1) | (rise ? 1 : 0);
+            V[(size_t)n * NL] = rise ? -prev : prev;
+            ++n;  // n <= T - 1 < capacity T
+        }
+        left = (rise || fall) ? t : left;
+        dir = rise ? 1 : (fall ? -1 : dir);
+        prev = c;
+    }
+
     const int b = lane_g / C;
     const int ch = lane_g - b * C;
     int8_t *sp = spikes + (size_t)b * T * C + ch;
+    const int stride = bipolar ? 2 : 1;
+    auto word_at = [&](int i) { return P + (size_t)i * NL; };
+    auto val_at = [&](int i) { return V + (size_t)i * NL; };
+    const int first_pol = n > 0 ? (P[0] & 1) : 0;
     for (int pol = 0; pol < (bipolar ? 2 : 1); ++pol) {
-        int *P = plist + pol * pol_stride + lane_g;
-        const double *V = vlist + pol * pol_stride + lane_g;
-        int n = pol ? cnt_min : cnt_max;
-        if (n > cap) n = cap;  // cannot happen: peaks are >= 2 samples apart and cap = T/2 + 1
         const int8_t mark = pol ? -1 : 1;
-        int s = 0;
-        int plast = n > 0 ? P[0] : 0;
-        for (int i = 1; i <= n; ++i) {
+        const int i0 = bipolar ? (first_pol == pol ? 0 : 1) : 0;
+        if (i0 >= n) continue;
+        int s = i0;
+        int plast = *word_at(i0) >> 1;
+        for (int i = i0 + stride;; i += stride) {
+            const bool has = i < n;
             int pi = 0;
             bool closes = true;
-            if (i < n) {
-                pi = P[(size_t)i * nlanes];
+            if (has) {
+                pi = *word_at(i) >> 1;
                 closes = (pi - plast) >= w;
             }
             if (closes) {
-                const int e = i;
-                if (e - s == 1) {
+                const int e = has ? i : n;
+                if (e - s <= stride)
                     sp[(size_t)plast * C] = mark;
-                } else {
-                    // greedy by descending priority inside the cluster [s, e); a decided entry is
-                    // flagged by complementing its position (positions are >= 0).
-                    int remaining = e - s;
-                    while (remaining > 0) {
-                        int best = -1;
-                        double bv = 0.0;
-                        for (int k = s; k < e; ++k) {
-                            const int pk = P[(size_t)k * nlanes];
-                            if (pk < 0) continue;
-                            const double vk = V[(size_t)k * nlanes];
-                            if (best < 0 || vk >= bv) {  // >= : equal priority -> later index wins
-                                best = k;
-                                bv = vk;
-                            }
-                        }
-                        const int pb = P[(size_t)best * nlanes];
-                        sp[(size_t)pb * C] = mark;
-                        P[(size_t)best * nlanes] = ~pb;
-                        --remaining;
-                        for (int k = best - 1; k >= s; --k) {
-                            int pk = P[(size_t)k * nlanes];
-                            const int pk_abs = pk < 0 ? ~pk : pk;
-                            if (pb - pk_abs >= w) break;
-                            if (pk >= 0) {
-                                P[(size_t)k * nlanes] = ~pk;
-                                --remaining;
-                            }
-                        }
-                        for (int k = best + 1; k < e; ++k) {
-                            int pk = P[(size_t)k * nlanes];
-                            const int pk_abs = pk < 0 ? ~pk : pk;
-                            if (pk_abs - pb >= w) break;
-                            if (pk >= 0) {
-                                P[(size_t)k * nlanes] = ~pk;
-                                --remaining;
-                            }
-                        }
-                    }
-                }
-                s = e;
+                else
+                    resolve_cluster(s, e, stride, w, mark, sp, C, word_at, val_at);
+                s = i;
             }
+            if (!has) break;
             plast = pi;
         }
     }
@@ -206,35 +356,55 @@ __global__ __launch_bounds__(64) void bandpass_rzcc_kernel(const double *__restr
 
 size_t rzcc_scratch_bytes(int nlanes, int T)
 {
-    const size_t cap = (size_t)T / 2 + 1;
-    size_t bytes = 2 * cap * (size_t)nlanes * sizeof(double);  // vlist
-    bytes += 2 * cap * (size_t)nlanes * sizeof(int);           // plist
+    size_t bytes = 256;                                         // flagged-stream counter
+    bytes += ((size_t)nlanes * sizeof(int) + 255) & ~(size_t)255;  // flagged-stream list
+    bytes += (size_t)T * nlanes * sizeof(double);               // fallback priority lists
+    bytes += (size_t)T * nlanes * sizeof(int);                  // fallback position lists
     return (bytes + 255) & ~(size_t)255;
 }
 
 template <int N>
 static void launch_rz(const IirCoef &coef, const double *h, int nlanes, int C, int T, int Ts, int w, int bipolar,
-                      double *pre, int8_t *spikes, int *plist, double *vlist, int cap, hipStream_t stream)
+                      double *pre, int8_t *spikes, int *flag_count, int *flag_list, int *plist, double *vlist,
+                      hipStream_t stream)
 {
-    dim3 grid((nlanes + 63) / 64), block(64);
-    hipLaunchKernelGGL(bandpass_rzcc_kernel<N>, grid, block, 0, stream, h, pre, spikes, plist, vlist, coef, nlanes,
-                       C, T, Ts, w, bipolar, cap);
+    dim3 grid((nlanes + 63) / 64), block(128);
+    if (pre && spikes)
+        hipLaunchKernelGGL((bandpass_rzcc_fast_kernel<N, true, true>), grid, block, 0, stream, h, pre, spikes,
+                           flag_count, flag_list, coef, nlanes, C, T, Ts, w, bipolar);
+    else if (spikes)
+        hipLaunchKernelGGL((bandpass_rzcc_fast_kernel<N, false, true>), grid, block, 0, stream, h, pre, spikes,
+                           flag_count, flag_list, coef, nlanes, C, T, Ts, w, bipolar);
+    else
+        hipLaunchKernelGGL((bandpass_rzcc_fast_kernel<N, true, false>), grid, block, 0, stream, h, pre, spikes,
+                           flag_count, flag_list, coef, nlanes, C, T, Ts, w, bipolar);
+    if (spikes)
+        hipLaunchKernelGGL((rzcc_fallback_kernel<N>), grid, dim3(64), 0, stream, h, spikes, flag_count, flag_list,
+                           plist, vlist, coef, nlanes, C, T, Ts, w, bipolar);
 }
 
 hipError_t launch_bandpass_rzcc(const IirCoef &coef, const double *h, int nlanes, int C, int T, int Ts,
                                 int robust_width, int bipolar, double *pre, int8_t *spikes, void *scratch,
                                 hipStream_t stream)
 {
-    const int cap = T / 2 + 1;
-    double *vlist = reinterpret_cast<double *>(scratch);
-    int *plist = reinterpret_cast<int *>(vlist + 2 * (size_t)cap * nlanes);
+    if (!pre && !spikes) return hipErrorInvalidValue;
+    int *flag_count = nullptr, *flag_list = nullptr, *plist = nullptr;
+    double *vlist = nullptr;
     if (spikes) {
-        hipError_t e = hipMemsetAsync(spikes, 0, (size_t)nlanes * T, stream);
+        unsigned char *base = reinterpret_cast<unsigned char *>(scratch);
+        flag_count = reinterpret_cast<int *>(base);
+        flag_list = reinterpret_cast<int *>(base + 256);
+        vlist = reinterpret_cast<double *>(base + 256 + (((size_t)nlanes * sizeof(int) + 255) & ~(size_t)255));
+        plist = reinterpret_cast<int *>(vlist + (size_t)T * nlanes);
+        hipError_t e = hipMemsetAsync(flag_count, 0, 256, stream);
+        if (e != hipSuccess) return e;
+        e = hipMemsetAsync(spikes, 0, (size_t)nlanes * T, stream);
         if (e != hipSuccess) return e;
     }
-#define RZ_CASE(NN)                                                                                              \
-    case NN:                                                                                                     \
-        launch_rz<NN>(coef, h, nlanes, C, T, Ts, robust_width, bipolar, pre, spikes, plist, vlist, cap, stream); \
+#define RZ_CASE(NN)                                                                                       \
+    case NN:                                                                                              \
+        launch_rz<NN>(coef, h, nlanes, C, T, Ts, robust_width, bipolar, pre, spikes, flag_count, flag_list, \
+                      plist, vlist, stream);                                                              \
         break;
     switch (coef.n) {
         RZ_CASE(1)
