@@ -169,6 +169,7 @@ int micloc_plan_create(const micloc_config *cfg, micloc_plan **out)
         tp.klo = 0;
         tp.kstep = 2;
         tp.ngroups = 0;
+        compact.assign(4, 0.0);
     } else {
         bool stride2 = true;
         for (int k = klo; k <= khi; ++k)
@@ -178,7 +179,7 @@ int micloc_plan_create(const micloc_config *cfg, micloc_plan **out)
         const int ntaps = (khi - klo) / tp.kstep + 1;
         const int U = 8 / tp.kstep;
         tp.ngroups = (ntaps + U - 1) / U;
-        compact.assign((size_t)tp.ngroups * U, 0.0);
+        compact.assign((size_t)(tp.ngroups + 1) * U, 0.0);  // +1 all-zero group: the kernel prefetches one group ahead
         for (int j = 0; j < ntaps; ++j) compact[j] = cfg->stht_kernel[klo + j * tp.kstep];
     }
     {

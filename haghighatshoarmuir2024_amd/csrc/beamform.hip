@@ -200,7 +200,10 @@ __global__ __launch_bounds__(BF_THREADS) void beamform_kernel(const int8_t *__re
         if (l < 16) red[(size_t)wv * Gp + 16 * gt + l] = sq;
     };
 
-    {
+    if (tb0 >= T) {
+        // every frame of this wave lies beyond the end of the trial (tail chunk): contribute exact zeros
+        for (int g = l; g < Gp; g += 64) red[(size_t)wv * Gp + g] = 0.0;
+    } else {
         double WfA[KS], WfB[KS];
         double4_t accA[BF_NT], accB[BF_NT];
         load_w(0, WfA);

@@ -36,15 +36,28 @@ __global__ __launch_bounds__(64 * STHT_MAX_MB) void stht_kernel(const double *__
     const double *xb = x + (size_t)b * T * M;
 
     // ---- stage (tile + halo) x MB mics, transposed to per-mic rows, zero outside [0, T) ----------
+    // Loads are issued in batches of 8 (clamped addresses, so unconditional) before any LDS write: the
+    // block pays the HBM latency twice per tile instead of once per row.
     {
         const int mm = tid % MB;
         const int m = m0 + mm;
+        const int mc = m < M ? m : M - 1;
         double *row = Xs + (size_t)mm * rowstride;
-        for (int q = tid / MB; q < N; q += 64) {
-            const int t = tq0 + q;
-            double v = 0.0;
-            if (t >= 0 && t < T && m < M) v = xb[(size_t)t * M + m];
-            row[skew(q)] = v;
+        const int q0 = tid / MB;
+        for (int qb = q0; qb < N; qb += 64 * 8) {
+            double v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                int t = tq0 + qb + 64 * i;
+                t = t < 0 ? 0 : (t >= T ? T - 1 : t);
+                v[i] = xb[(size_t)t * M + mc];
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int q = qb + 64 * i;
+                const int t = tq0 + q;
+                if (q < N) row[skew(q)] = (t >= 0 && t < T && m < M) ? v[i] : 0.0;
+            }
         }
     }
     __syncthreads();
@@ -64,17 +77,35 @@ __global__ __launch_bounds__(64 * STHT_MAX_MB) void stht_kernel(const double *__
     int j = lane * 8 + (halo + 8 - klo);  // logical index of x[tb - klo]; j % 8 == 0
     int pj = skew(j);
 #pragma unroll
-    for (int r = 0; r < 8; ++r) w[r] = row[pj + r];
+    for (int r = 0; r < 8; r += 2) {
+        const double2 v2 = *reinterpret_cast<const double2 *>(row + pj + r);
+        w[r] = v2.x;
+        w[r + 1] = v2.y;
+    }
+    // taps of group g+1 are fetched (scalar loads) while group g is being accumulated; the table is padded
+    // with one extra all-zero group so the look-ahead never reads out of bounds
+    double tpn[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) tpn[u] = taps[u];
     for (int g = 0; g < ngroups; ++g) {
         pj -= 10;  // skew(j - 8)
         double tp[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) tp[u] = taps[g * U + u];
+        for (int u = 0; u < U; ++u) tp[u] = tpn[u];
+#pragma unroll
+        for (int u = 0; u < U; ++u) tpn[u] = taps[(g + 1) * U + u];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             double nx[S];
+            if (S == 2) {
+                // pj and the offset are even and rows are 16-byte aligned: one ds_read_b128
+                const double2 v2 = *reinterpret_cast<const double2 *>(row + pj + (8 - (u + 1) * S));
+                nx[0] = v2.x;
+                nx[S - 1] = v2.y;
+            } else {
 #pragma unroll
-            for (int e = 0; e < S; ++e) nx[e] = row[pj + (8 - (u + 1) * S + e)];
+                for (int e = 0; e < S; ++e) nx[e] = row[pj + (8 - (u + 1) * S + e)];
+            }
 #pragma unroll
             for (int r = 0; r < 8; ++r) acc[r] = __builtin_fma(tp[u], w[(r - u * S) & 7], acc[r]);
 #pragma unroll
