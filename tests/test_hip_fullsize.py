@@ -1,0 +1,90 @@
+"""GPU tests at BASELINE.json's full config-2 size (1100 trials x 4799 frames x 7 mics, G = 449) through
+size-independent properties, plus spot checks of individual trials against the oracle."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+B, T, M = 1100, 4799, 7
+
+
+@pytest.fixture(scope="module")
+def big(cfg2):
+    import torch
+
+    from haghighatshoarmuir2024_amd.runtime import Plan
+
+    p = Plan(M, cfg2["kernel"], cfg2["b"], cfg2["a"], cfg2["robust_width"], True)
+    p.set_neuron_kernel(cfg2["nir"])
+    p.set_bf_mat(cfg2["bf_mat"])
+    g = torch.Generator(device="cuda")
+    g.manual_seed(7)
+    t = torch.arange(T, device="cuda", dtype=torch.float64) / 48_000
+    phase = torch.rand((B, 1, M), generator=g, device="cuda", dtype=torch.float64) * 6.28
+    amp = 10 ** (torch.rand((B, 1, 1), generator=g, device="cuda", dtype=torch.float64) * 2 - 1)
+    x = torch.sin(2 * np.pi * 2000 * t[None, :, None] + phase) + amp * torch.randn((B, T, M), generator=g, device="cuda", dtype=torch.float64)
+    out = p.snn_pipeline(x, want_spikes=True, want_power=True)
+    torch.cuda.synchronize()
+    return p, x, out
+
+
+def test_spot_trials_against_oracle(big, cfg2):
+    p, x, out = big
+    for i in (0, 1, 547, 1099):
+        ref = O.snn_chain(x[i].cpu().numpy(), cfg2["kernel"], cfg2["b"], cfg2["a"], cfg2["robust_width"], True, cfg2["nir"], cfg2["bf_mat"],
+                          want=("spikes", "power"))
+        np.testing.assert_array_equal(out["spikes"][i].cpu().numpy(), ref["spikes"])
+        np.testing.assert_allclose(out["power"][i].cpu().numpy(), ref["power"], rtol=1e-12, atol=0)
+        assert int(out["argmax"][i]) == ref["argmax"]
+
+
+def test_deterministic_and_batch_independent(big):
+    import torch
+
+    p, x, out = big
+    again = p.snn_pipeline(x, want_spikes=True, want_power=True)
+    assert torch.equal(again["spikes"], out["spikes"]) and torch.equal(again["power"], out["power"]) and torch.equal(again["argmax"], out["argmax"])
+    sub = p.snn_pipeline(x[500:503].contiguous(), want_spikes=True, want_power=True)
+    assert torch.equal(sub["spikes"], out["spikes"][500:503]) and torch.equal(sub["power"], out["power"][500:503])
+
+
+def test_power_of_two_scaling_invariance(big):
+    """Every stage before the encoder is linear and a scale by 2^k is exact in binary64, so the spikes (hence the
+    power and arg-max) must not change at all."""
+    import torch
+
+    p, x, out = big
+    for k in (-7, 5):
+        sc = p.snn_pipeline(x * (2.0**k), want_spikes=True, want_power=True)
+        assert torch.equal(sc["spikes"], out["spikes"])
+        assert torch.equal(sc["power"], out["power"]) and torch.equal(sc["argmax"], out["argmax"])
+
+
+def test_min_distance_property_and_counts(big, cfg2):
+    """No two same-polarity spikes of a channel are closer than robust_width; argmax is the arg-max of power."""
+    import torch
+
+    p, x, out = big
+    w = cfg2["robust_width"]
+    s = out["spikes"]
+    for mark in (1, -1):
+        m = (s == mark).to(torch.int32)
+        c = torch.cumsum(m, dim=1)
+        win = c[:, w - 1 :, :] - torch.nn.functional.pad(c, (0, 0, 1, 0))[:, : c.shape[1] - w + 1, :]
+        assert int(win.max()) <= 1
+    assert torch.equal(out["power"].argmax(dim=1).to(torch.int32), out["argmax"])
+    rate = (s != 0).double().mean().item()
+    assert 0.04 < rate < 0.12  # ~3.5 k spikes / channel / s at 48 kHz (density 6.8 %)
+
+
+def test_negation_swaps_polarity(big):
+    """x -> -x negates the cumulative sum exactly: maxima and minima swap, so spikes flip sign bit for bit, except
+    where a priority tie is broken by index order (none with continuous data)."""
+    import torch
+
+    p, x, out = big
+    neg = p.snn_pipeline(-x[:64].contiguous(), want_spikes=True, want_power=True)
+    assert torch.equal(neg["spikes"], -out["spikes"][:64])
+    torch.testing.assert_close(neg["power"], out["power"][:64], rtol=1e-12, atol=0)
