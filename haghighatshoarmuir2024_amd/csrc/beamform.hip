@@ -19,6 +19,8 @@
 //
 // Summation order (== oracle): LIF over past samples in chronological order (tau ascending),
 // beamforming over channels ascending; both as fused multiply-add chains starting from +0.
+#include <stdlib.h>
+
 #include "micloc_internal.h"
 
 namespace micloc {
@@ -58,9 +60,11 @@ __global__ __launch_bounds__(BF_THREADS) void beamform_kernel(const int8_t *__re
     const int cs = chunk * BF_CHUNK;
 
     // ---- LDS carve-up -----------------------------------------------------------------------------------
+    // [ W: C rows + one zero row ][ union{ red[8][Gp] , nir table + spike tile } ]
+    // red is only written after every wave has finished stage 1 (barrier below), so it may alias the spike tile.
     double *Wl = reinterpret_cast<double *>(smem);
-    double *red = Wl + (W_LDS ? (size_t)Kp * Gp : 0);
-    double *ntab = red + (size_t)BF_WAVES * Gp;
+    double *red = Wl + (W_LDS ? (size_t)(C + 1) * Gp : 0);
+    double *ntab = red;
     const int ntab_len = SRC_SPIKES ? 4 * NK + 16 : 0;
     int8_t *spk = reinterpret_cast<int8_t *>(ntab + ntab_len);
     const int R = BF_CHUNK + 4 * NK - 16;  // staged spike rows
@@ -68,7 +72,8 @@ __global__ __launch_bounds__(BF_THREADS) void beamform_kernel(const int8_t *__re
     if (W_LDS) {
         const double2 *src2 = reinterpret_cast<const double2 *>(Wp);
         double2 *dst2 = reinterpret_cast<double2 *>(Wl);
-        for (int e = tid; e < (Kp * Gp) / 2; e += BF_THREADS) dst2[e] = src2[e];
+        for (int e = tid; e < (C * Gp) / 2; e += BF_THREADS) dst2[e] = src2[e];
+        for (int e = tid; e < Gp; e += BF_THREADS) Wl[(size_t)C * Gp + e] = 0.0;
     }
     if (SRC_SPIKES) {
         for (int e = tid; e < ntab_len; e += BF_THREADS) ntab[e] = ntab_g[e];
@@ -145,16 +150,25 @@ __global__ __launch_bounds__(BF_THREADS) void beamform_kernel(const int8_t *__re
         }
     }
 
+    __syncthreads();  // all waves are done with the spike tile / nir table: `red` may now overwrite them
+
     // ---- stage 2: beamforming + power, one 16-column DoA tile at a time ------------------------------------
     // Two accumulator sets: the MFMAs of tile gt+1 are issued before the (VALU) epilogue of tile gt, so the
     // matrix pipe never waits for the squares / shuffles / stores.
     const double *Wsrc = W_LDS ? Wl : Wp;
     const int Ghp = Gp >> 1;  // complex variant: [0, Ghp) real part, [Ghp, Gp) imaginary part
 
-    auto load_w = [&](int gt, double (&Wf)[KS]) {
-        const double *wp = Wsrc + (size_t)q * Gp + 16 * gt + lc;
+    // rows >= C of the padded matrix are zero: in LDS they all map to the single zero row stored at index C
+    int woff[KS];
 #pragma unroll
-        for (int k = 0; k < KS; ++k) Wf[k] = wp[(size_t)(4 * k) * Gp];
+    for (int k = 0; k < KS; ++k) {
+        const int row = 4 * k + q;
+        woff[k] = (W_LDS ? (row < C ? row : C) : row) * Gp;
+    }
+    auto load_w = [&](int gt, double (&Wf)[KS]) {
+        const double *wp = Wsrc + 16 * gt + lc;
+#pragma unroll
+        for (int k = 0; k < KS; ++k) Wf[k] = wp[woff[k]];
     };
     auto issue = [&](const double (&Wf)[KS], double4_t (&acc)[BF_NT]) {
 #pragma unroll
@@ -247,8 +261,14 @@ static hipError_t launch_bf(const BeamformW &W, const NeuronTab *nt, const int8_
     const int Kp = 16 * CT;
     const int NK = SRC_SPIKES ? nt->NK : 0;
     size_t lds = (size_t)BF_WAVES * Gp * sizeof(double);
-    if (SRC_SPIKES) lds += (size_t)(4 * NK + 16) * sizeof(double) + (size_t)(BF_CHUNK + 4 * NK - 16) * 16 * CT;
-    const size_t wbytes = (size_t)Kp * Gp * sizeof(double);
+    if (SRC_SPIKES) {
+        const size_t tile = (size_t)(4 * NK + 16) * sizeof(double) + (size_t)(BF_CHUNK + 4 * NK - 16) * 16 * CT;
+        lds = lds > tile ? lds : tile;  // red aliases the nir table + spike tile
+    }
+    lds = (lds + 15) & ~(size_t)15;
+    if (const char *pad = getenv("MICLOC_BF_LDS_PAD")) lds += (size_t)atoi(pad) * 1024;  // experiment knob
+    const size_t wbytes = (size_t)(W.C + 1) * Gp * sizeof(double);
+    (void)Kp;
     const bool w_lds = (lds + wbytes) <= 150 * 1024 && wbytes <= 96 * 1024;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     dim3 grid(beamform_nchunks(T), B), block(BF_THREADS);

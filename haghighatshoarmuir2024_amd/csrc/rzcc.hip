@@ -30,7 +30,6 @@
 
 namespace micloc {
 
-constexpr int RZ_MACRO = 32;   // time steps per LDS tile
 constexpr int RZ_RING = 64;    // candidate ring entries per stream (power of two)
 constexpr int RZ_ROW = 65;     // padded row of the transposed input tile (doubles)
 
@@ -106,44 +105,55 @@ __device__ __forceinline__ void resolve_cluster(int s, int e, int stride, int w,
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Fast path.
+// Fast path: a 4-stage wave pipeline over 16-step tiles (one barrier per tile).
+//   wave L (loader)  tile k+1 -> LDS (loads issued one tile earlier, into registers), stores filtered tiles
+//   wave F (filter)  tile k  : x -> band-pass -> cumulative sum, in place in LDS
+//   wave D (detect)  tile k-1: local maxima / minima of the cumulative sum -> candidate ring
+//   wave S (select)  tile k-2: walks the new candidates, closes clusters, min-distance greedy, scatters spikes
+// Each stage is a different wave of the workgroup, i.e. a different SIMD of the CU, so the serial chain of
+// one stream costs max(stage) instructions per time step instead of their sum.
 // ---------------------------------------------------------------------------------------------------
+constexpr int RZ_MT = 16;
+
 template <int N, bool WANT_PRE, bool WANT_SPIKES>
-__global__ __launch_bounds__(128) void bandpass_rzcc_fast_kernel(const double *__restrict__ h,
+__global__ __launch_bounds__(256) void bandpass_rzcc_fast_kernel(const double *__restrict__ h,
                                                                   double *__restrict__ pre,
                                                                   int8_t *__restrict__ spikes,
                                                                   int *__restrict__ flag_count,
                                                                   int *__restrict__ flag_list, IirCoef coef,
                                                                   int nlanes, int C, int T, int Ts, int w, int bipolar)
 {
-    __shared__ __attribute__((aligned(16))) double tile[2][RZ_MACRO][RZ_ROW];
+    __shared__ __attribute__((aligned(16))) double X[3][RZ_MT][RZ_ROW];
+    __shared__ double Y[WANT_PRE ? 2 : 1][WANT_PRE ? RZ_MT : 1][WANT_PRE ? RZ_ROW : 1];
     __shared__ double ringV[WANT_SPIKES ? RZ_RING : 1][64];
     __shared__ int ringP[WANT_SPIKES ? RZ_RING : 1][64];
+    __shared__ int nPub[64];
 
-    const int wave = threadIdx.x >> 6;
+    const int wave = threadIdx.x >> 6;  // 0: filter, 1: loader, 2: detect, 3: select
     const int lane = threadIdx.x & 63;
     const int base = blockIdx.x * 64;
-    const int NM = (T + RZ_MACRO - 1) / RZ_MACRO;
+    const int NM = (T + RZ_MT - 1) / RZ_MT;
+    const int NSTEP = WANT_SPIKES ? NM + 2 : NM + 1;
+    const int lane_g = base + lane;
+    const bool active = lane_g < nlanes;
 
     if (wave == 1) {
-        // ------------------------------- loader wave ---------------------------------------------------
-        // Two tiles ahead: tile m+1 sits in LDS, tile m+2 is in flight in registers, so the loads get a
-        // whole tile time to land and the barrier never waits on memory.
-        const int tl = lane & 31;  // time offset inside the tile
-        const int sh = lane >> 5;  // which of the two streams of a pair
+        // ------------------------------------ loader ---------------------------------------------------
+        const int tl = lane & 15;  // time offset inside the tile
+        const int sq = lane >> 4;  // stream slot 0..3 of each group of four
         const bool full_block = base + 64 <= nlanes;
-        double v[32];
+        double v[16];
         auto issue_loads = [&](int m) {
-            int t = m * RZ_MACRO + tl;
-            t = t < Ts ? t : Ts - 1;  // clamp: samples past T are never used by the compute wave
+            int t = m * RZ_MT + tl;
+            t = t < Ts ? t : Ts - 1;  // clamp: samples past T are never used
             if (full_block) {
-                const double *p = h + (size_t)(base + sh) * Ts + t;
+                const double *p = h + (size_t)(base + sq) * Ts + t;
 #pragma unroll
-                for (int j = 0; j < 32; ++j) v[j] = p[(size_t)(2 * j) * Ts];
+                for (int j = 0; j < 16; ++j) v[j] = p[(size_t)(4 * j) * Ts];
             } else {
 #pragma unroll
-                for (int j = 0; j < 32; ++j) {
-                    int g = base + 2 * j + sh;
+                for (int j = 0; j < 16; ++j) {
+                    int g = base + 4 * j + sq;
                     g = g < nlanes ? g : nlanes - 1;
                     v[j] = h[(size_t)g * Ts + t];
                 }
@@ -151,19 +161,20 @@ __global__ __launch_bounds__(128) void bandpass_rzcc_fast_kernel(const double *_
         };
         auto write_tile = [&](int buf) {
 #pragma unroll
-            for (int j = 0; j < 32; ++j) tile[buf][tl][2 * j + sh] = v[j];
+            for (int j = 0; j < 16; ++j) X[buf][tl][4 * j + sq] = v[j];
         };
-        auto store_tile = [&](int m, int buf) {
-            const int t = m * RZ_MACRO + tl;
-            if (full_block && (m + 1) * RZ_MACRO <= Ts) {
-                double *p = pre + (size_t)(base + sh) * Ts + t;
+        auto store_tile = [&](int m) {
+            const int t = m * RZ_MT + tl;
+            const int yb = m & 1;
+            if (full_block && (m + 1) * RZ_MT <= Ts) {
+                double *p = pre + (size_t)(base + sq) * Ts + t;
 #pragma unroll
-                for (int j = 0; j < 32; ++j) p[(size_t)(2 * j) * Ts] = tile[buf][tl][2 * j + sh];
+                for (int j = 0; j < 16; ++j) p[(size_t)(4 * j) * Ts] = Y[WANT_PRE ? yb : 0][WANT_PRE ? tl : 0][WANT_PRE ? 4 * j + sq : 0];
             } else {
 #pragma unroll 4
-                for (int j = 0; j < 32; ++j) {
-                    const int g = base + 2 * j + sh;
-                    if (g < nlanes && t < Ts) pre[(size_t)g * Ts + t] = tile[buf][tl][2 * j + sh];
+                for (int j = 0; j < 16; ++j) {
+                    const int g = base + 4 * j + sq;
+                    if (g < nlanes && t < Ts) pre[(size_t)g * Ts + t] = Y[WANT_PRE ? yb : 0][WANT_PRE ? tl : 0][WANT_PRE ? 4 * j + sq : 0];
                 }
             }
         };
@@ -171,32 +182,99 @@ __global__ __launch_bounds__(128) void bandpass_rzcc_fast_kernel(const double *_
         write_tile(0);
         if (NM > 1) issue_loads(1);
         __syncthreads();
-        for (int m = 0; m < NM; ++m) {
-            if (m + 1 < NM) write_tile((m + 1) & 1);
-            if (m + 2 < NM) issue_loads(m + 2);
+        for (int k = 0; k < NSTEP; ++k) {
+            if (k + 1 < NM) write_tile((k + 1) % 3);
+            if (k + 2 < NM) issue_loads(k + 2);
+            if (WANT_PRE && k >= 1 && k <= NM) store_tile(k - 1);
             __syncthreads();
-            if (WANT_PRE) store_tile(m, m & 1);
         }
         return;
     }
 
-    // ----------------------------------- compute wave --------------------------------------------------
-    const int lane_g = base + lane;
-    const bool active = lane_g < nlanes;
-    Iir<N> iir;
-    iir.init();
-    double c = 0.0;
-    double prev = __builtin_nan("");  // comparisons with NaN are false: no event at t = 0
-    int left = 0, dir = 0;
-    int n = 0, n_done = 0;       // candidates appended / processed
-    int s0 = -1, s1 = -1;        // first list index of the open cluster per polarity (-1: none)
-    int l0 = 0, l1 = 0;          // position of the last candidate per polarity
-    bool dead = !active;         // overflowed (or out of range): stop selecting, redo in the fallback kernel
+    if (wave == 0) {
+        // ------------------------------------ filter ---------------------------------------------------
+        Iir<N> iir;
+        iir.init();
+        double cs = 0.0;
+        __syncthreads();
+        for (int k = 0; k < NSTEP; ++k) {
+            if (k < NM) {
+                const int buf = k % 3;
+                const int steps = (T - k * RZ_MT) < RZ_MT ? (T - k * RZ_MT) : RZ_MT;
+                auto one = [&](int j) {
+                    const double y = iir.step(coef, X[buf][j][lane]);
+                    if (WANT_PRE) Y[WANT_PRE ? (k & 1) : 0][WANT_PRE ? j : 0][WANT_PRE ? lane : 0] = y;
+                    if (WANT_SPIKES) {
+                        cs = cs + y;
+                        X[buf][j][lane] = cs;
+                    }
+                };
+                if (steps == RZ_MT) {
+#pragma unroll
+                    for (int j = 0; j < RZ_MT; ++j) one(j);
+                } else {
+                    for (int j = 0; j < steps; ++j) one(j);
+                }
+            }
+            __syncthreads();
+        }
+        return;
+    }
+
+    if (!WANT_SPIKES) return;  // (band-pass-only launches have just the two waves above)
+
+    if (wave == 2) {
+        // ------------------------------------ detect ---------------------------------------------------
+        // dir  = direction of the last strict change of c (+1 rise, -1 fall, 0 none yet); left = its time index.
+        // A maximum completes when c falls after a rise: plateau [left, t-1] -> position (left+t-1)>>1, priority =
+        // plateau value = prev.  Minima mirror this (priority -prev).  Maxima and minima alternate strictly, so both
+        // share one candidate list, tagged by the low bit of the stored word.
+        double prev = __builtin_nan("");  // comparisons with NaN are false: no event at t = 0
+        int left = 0, dir = 0, n = 0;
+        nPub[lane] = 0;
+        __syncthreads();
+        for (int k = 0; k < NSTEP; ++k) {
+            if (k >= 1 && k <= NM) {
+                const int m = k - 1;
+                const int buf = m % 3;
+                const int tbase = m * RZ_MT;
+                const int steps = (T - tbase) < RZ_MT ? (T - tbase) : RZ_MT;
+                auto one = [&](int j) {
+                    const double c = X[buf][j][lane];
+                    const int t = tbase + j;
+                    const bool rise = c > prev;
+                    const bool fall = c < prev;
+                    const bool ev = (fall && dir > 0) || (bipolar && rise && dir < 0);
+                    const int slot = n & (RZ_RING - 1);  // unconditional store; consumed only if n advances
+                    ringP[slot][lane] = ((left + t - 1) & ~1) | (rise ? 1 : 0);
+                    ringV[slot][lane] = rise ? -prev : prev;
+                    n += ev ? 1 : 0;
+                    left = (rise || fall) ? t : left;
+                    dir = rise ? 1 : (fall ? -1 : dir);
+                    prev = c;
+                };
+                if (steps == RZ_MT) {
+#pragma unroll
+                    for (int j = 0; j < RZ_MT; ++j) one(j);
+                } else {
+                    for (int j = 0; j < steps; ++j) one(j);
+                }
+                nPub[lane] = n;
+            }
+            __syncthreads();
+        }
+        return;
+    }
+
+    // ---------------------------------------- select -------------------------------------------------------
+    int n_done = 0;
+    int s0 = -1, s1 = -1;  // first list index of the open cluster per polarity (-1: none)
+    int l0 = 0, l1 = 0;    // position of the last candidate per polarity
+    bool dead = !active;   // ring overflow (or lane out of range): stop selecting; redone by the fallback kernel
     const int stride = bipolar ? 2 : 1;
     const int b = active ? lane_g / C : 0;
     const int ch = active ? lane_g - b * C : 0;
-    int8_t *sp = WANT_SPIKES ? spikes + (size_t)b * T * C + ch : nullptr;
-
+    int8_t *sp = spikes + (size_t)b * T * C + ch;
     auto word_at = [&](int i) { return &ringP[i & (RZ_RING - 1)][lane]; };
     auto val_at = [&](int i) { return &ringV[i & (RZ_RING - 1)][lane]; };
     auto close_cluster = [&](int s, int e, int pol, int lastpos) {
@@ -206,41 +284,10 @@ __global__ __launch_bounds__(128) void bandpass_rzcc_fast_kernel(const double *_
         else
             resolve_cluster(s, e, stride, w, mark, sp, C, word_at, val_at);
     };
-
     __syncthreads();
-    for (int m = 0; m < NM; ++m) {
-        const int buf = m & 1;
-        const int tbase = m * RZ_MACRO;
-        const int steps = (T - tbase) < RZ_MACRO ? (T - tbase) : RZ_MACRO;
-        auto one_step = [&](int j) {
-            const double xin = tile[buf][j][lane];
-            const double y = iir.step(coef, xin);
-            if (WANT_PRE) tile[buf][j][lane] = y;
-            if (WANT_SPIKES) {
-                const int t = tbase + j;
-                c = c + y;
-                const bool rise = c > prev;
-                const bool fall = c < prev;
-                const bool ev = (fall && dir > 0) || (bipolar && rise && dir < 0);
-                // candidate (unconditional store; the slot is only consumed when n advances)
-                const int slot = n & (RZ_RING - 1);
-                ringP[slot][lane] = ((left + t - 1) & ~1) | (rise ? 1 : 0);
-                ringV[slot][lane] = rise ? -prev : prev;
-                n += ev ? 1 : 0;
-                left = (rise || fall) ? t : left;
-                dir = rise ? 1 : (fall ? -1 : dir);
-                prev = c;
-            }
-        };
-        if (steps == RZ_MACRO) {
-#pragma unroll 8
-            for (int j = 0; j < RZ_MACRO; ++j) one_step(j);
-        } else {
-            for (int j = 0; j < steps; ++j) one_step(j);
-        }
-
-        if (WANT_SPIKES) {
-            // ---- walk the new candidates (event order, not time order) and close finished clusters ----
+    for (int k = 0; k < NSTEP; ++k) {
+        if (k >= 2) {
+            const int n = nPub[lane];  // candidates published by the detect wave before the last barrier
             for (int i = n_done; __any(!dead && i < n); ++i) {
                 if (!dead && i < n) {
                     const int word = *word_at(i);
@@ -264,19 +311,20 @@ __global__ __launch_bounds__(128) void bandpass_rzcc_fast_kernel(const double *_
                 }
             }
             n_done = n;
-            // the next tile may append up to RZ_MACRO candidates: everything still open must survive that
+            // the detect wave runs up to two tiles ahead of what has been selected: everything still open must
+            // survive 2 * RZ_MT more appends
             const int oldest = (s0 >= 0 && (s1 < 0 || s0 < s1)) ? s0 : (s1 >= 0 ? s1 : n);
-            if (!dead && n - oldest > RZ_RING - RZ_MACRO) dead = true;
+            if (!dead && n - oldest >= RZ_RING - 2 * RZ_MT) dead = true;
         }
         __syncthreads();
     }
-    if (WANT_SPIKES && active) {
+    if (active) {
         if (!dead) {
-            if (s0 >= 0) close_cluster(s0, n, 0, l0);
-            if (s1 >= 0) close_cluster(s1, n, 1, l1);
+            if (s0 >= 0) close_cluster(s0, n_done, 0, l0);
+            if (s1 >= 0) close_cluster(s1, n_done, 1, l1);
         } else {
-            const int k = atomicAdd(flag_count, 1);
-            flag_list[k] = lane_g;
+            const int kk = atomicAdd(flag_count, 1);
+            flag_list[kk] = lane_g;
         }
     }
 }
@@ -368,7 +416,7 @@ static void launch_rz(const IirCoef &coef, const double *h, int nlanes, int C, i
                       double *pre, int8_t *spikes, int *flag_count, int *flag_list, int *plist, double *vlist,
                       hipStream_t stream)
 {
-    dim3 grid((nlanes + 63) / 64), block(128);
+    dim3 grid((nlanes + 63) / 64), block(spikes ? 256 : 128);
     if (pre && spikes)
         hipLaunchKernelGGL((bandpass_rzcc_fast_kernel<N, true, true>), grid, block, 0, stream, h, pre, spikes,
                            flag_count, flag_list, coef, nlanes, C, T, Ts, w, bipolar);
