@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--trials", type=int, default=1100, help="trials per rank per step (11 SNRs x 100)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=300, help="trials timed on the CPU oracle")
+    ap.add_argument("--streams", type=int, default=3, help="HIP streams consecutive steps are pipelined over (1 = serial)")
     ap.add_argument("--traffic-bytes", type=float, default=None, help="HBM bytes per dominant-kernel launch from a separate rocprofv3 --pmc pass")
     return ap.parse_args()
 
@@ -90,19 +91,34 @@ def build_workload(args, rank, device):
                 bf_mat=bf_mat, nir=nir, snr_groups=len(snr_db_vec), fs=fs)
 
 
-def make_step(wl):
+def make_step(wl, nstreams):
+    """One step = one pass of the hot path over the batch.  Consecutive steps are independent batches, so they are
+    dispatched round-robin over `nstreams` HIP streams (one plan/workspace each): the latency-bound RZCC kernel of
+    one step overlaps the throughput-bound STHT / beamforming kernels of its neighbours."""
     import torch
 
-    plan, x, doa, doa_list, S = wl["plan"], wl["x"], wl["doa"], wl["doa_list"], wl["snr_groups"]
+    from haghighatshoarmuir2024_amd.runtime import StreamPipeline
 
-    def step():
+    x, doa, doa_list, S = wl["x"], wl["doa"], wl["doa_list"], wl["snr_groups"]
+    plans = [wl["plan"]]
+    for _ in range(nstreams - 1):
+        p = wl["beamf"].new_plan()
+        p.set_neuron_kernel(wl["nir"])
+        p.set_bf_mat(wl["bf_mat"])
+        plans.append(p)
+    pipe = StreamPipeline(plans)
+
+    def body(plan):
         out = plan.snn_pipeline(x, want_power=True)
         est = doa_list[out["argmax"].long()]
         err = torch.arcsin(torch.abs(torch.sin(est - doa)))
         mae = err.reshape(S, -1).mean(dim=1)
         return out, mae
 
-    return step
+    def step():
+        return pipe.submit(body)
+
+    return step, pipe
 
 
 def stage_times(wl, iters):
@@ -165,11 +181,12 @@ def main():
         dist.init_process_group("nccl", device_id=device)
 
     wl = build_workload(args, rank, device)
-    step = make_step(wl)
+    step, pipe = make_step(wl, max(1, args.streams))
     B, T, M = wl["x"].shape
     G = wl["bf_mat"].shape[1]
 
     def barrier():
+        pipe.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -233,7 +250,7 @@ def main():
             "config": {"workload": f"target_snn_localization noisy sweep: 7-mic centre-circular, 48 kHz, T={T}, {B} trials/GPU/step (11 SNR x {B // 11}), "
                                    f"{G}-DoA grid, bipolar RZCC, bf_mat designed on device from the 1 s chirp",
                        "trials_per_gpu": B, "frames_per_trial": T, "num_mic": M, "num_doa": G, "mic_samples_per_s": value * M,
-                       "parallelism": f"trial-sharded x{world}"},
+                       "parallelism": f"trial-sharded x{world}", "hip_streams": max(1, args.streams)},
             "mae_deg_per_snr": [float(v) for v in (mae * 180 / np.pi).cpu().numpy()],
             "roofline": roof,
         }

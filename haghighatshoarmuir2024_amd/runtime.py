@@ -276,3 +276,37 @@ def lfilter(b, a, x, device=None):
         ws = _op_workspace(device, nbytes)
         _lib.check(lib.micloc_lfilter_f64(_dptr(bb), _dptr(aa), n, _ptr(x), B, T, C, _ptr(y), _ptr(ws), nbytes, _stream(device)), "lfilter")
     return y[0] if squeeze else y
+
+
+class StreamPipeline:
+    """Round-robin dispatch of consecutive batches over several HIP streams, one Plan (= workspace) per stream.
+
+    The band-pass/RZCC kernel is latency bound (one wave per 64 streams, the time axis is sequential) and leaves
+    most of the chip idle; running batch i+1's STHT / batch i-1's beamformer next to it on other streams fills
+    the machine.  Results are device tensors owned by the stream that produced them: call synchronize() (or make
+    the consumer stream wait) before reading them elsewhere.
+    """
+
+    def __init__(self, plans):
+        torch = _torch()
+        self.plans = list(plans)
+        self.device = self.plans[0].device
+        self.streams = [torch.cuda.Stream(device=self.device) for _ in self.plans]
+        self._next = 0
+
+    def submit(self, fn):
+        """Run fn(plan) on the next stream; returns fn's result."""
+        torch = _torch()
+        i = self._next % len(self.plans)
+        self._next += 1
+        s = self.streams[i]
+        s.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(s):
+            return fn(self.plans[i])
+
+    def synchronize(self):
+        torch = _torch()
+        cur = torch.cuda.current_stream(self.device)
+        for s in self.streams:
+            cur.wait_stream(s)
+        cur.synchronize()

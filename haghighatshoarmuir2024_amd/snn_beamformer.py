@@ -97,6 +97,12 @@ class SNNBeamformer:
             self._plan_key = key
         return self._plan
 
+    def new_plan(self):
+        """A fresh, un-cached device plan (own coefficient tables and workspace): one per HIP stream when
+        consecutive batches are pipelined across streams (see runtime.StreamPipeline)."""
+        b, a = self.bandpass_filter
+        return runtime.Plan(len(self.geometry), self.kernel, b, a, self.spk_encoder.robust_width, self.spk_encoder.bipolar, device=self.device)
+
     def _resample(self, time_vec, sig_in_vec, num_mic):
         """reference :309-321 (only taken when the time axis is not on the fs grid)."""
         if np.allclose(np.diff(time_vec), 1 / self.fs):

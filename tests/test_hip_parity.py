@@ -242,3 +242,29 @@ def test_error_conventions(cfg2, torch):
         SNNBeamformer(geo, 10e-3, [2000, 1000], [tau, tau])
     with pytest.raises(ValueError):
         Beamformer(geo, 10e-3, [1000, 2000]).apply_to_signal(np.zeros((7, 5), complex), np.zeros((50, 3)))
+
+
+@pytest.mark.parametrize("M,G,T", [(64, 50, 700), (24, 33, 530), (40, 16, 100)])
+def test_many_mic_shapes_vs_oracle(torch, M, G, T):
+    """Stress-shape plumbing (BASELINE config 5 uses 64 mics): C = 128 / 48 / 80 channels, 96 kHz kernel."""
+    from haghighatshoarmuir2024_amd.runtime import Plan
+
+    fs = 96_000
+    rng = np.random.RandomState(M)
+    ker = O.stht_kernel(fs, 10e-3)
+    b, a = O.bandpass(fs, [1000.0, 2000.0])
+    w = O.robust_width(fs, 2000.0)
+    tau = 1 / (2 * np.pi * 2000.0)
+    nir = O.neuron_kernel(np.arange(T) / fs, [tau, tau])
+    W = rng.randn(2 * M, G)
+    x = np.sin(2 * np.pi * 1500 * np.arange(T)[None, :, None] / fs + rng.rand(2, 1, M) * 6) + 0.3 * rng.randn(2, T, M)
+    p = Plan(M, ker, b, a, w, True)
+    p.set_neuron_kernel(nir)
+    p.set_bf_mat(W)
+    out = p.snn_pipeline(p.to_device(x), want_spikes=True, want_y=True)
+    for i in range(2):
+        ref = O.snn_chain(x[i], ker, b, a, w, True, nir, W)
+        np.testing.assert_array_equal(out["spikes"][i].cpu().numpy(), ref["spikes"])
+        np.testing.assert_array_equal(out["y"][i].cpu().numpy(), ref["y"])
+        np.testing.assert_allclose(out["power"][i].cpu().numpy(), ref["power"], rtol=1e-12)
+        assert int(out["argmax"][i]) == ref["argmax"]
