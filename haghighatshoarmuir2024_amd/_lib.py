@@ -77,6 +77,11 @@ def load():
                 f"{LIB_PATH} not found: build it with `make -C haghighatshoarmuir2024_amd/csrc` "
                 "(or __graft_entry__.build()); there is no CPU fallback"
             )
+        # PyTorch-ROCm ships its own libamdhip64 / libhsa-runtime64; it must be in the process BEFORE this library
+        # is loaded so that both resolve to ONE HIP runtime (same SONAME).  Loaded the other way round, the two
+        # runtimes each try to own the device and hipGetDeviceCount() fails in the second one.
+        import torch  # noqa: F401
+
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol

@@ -520,6 +520,50 @@ def gen_filterbank():
     save("filterbank.npz", sig_in=sig, b=b, a=a, filt_head=filt[:800], spikes_in=spikes_in.astype(np.int8))
 
 
+def gen_speech():
+    """Speech configuration (paper_plots/target_snn_localization.py:148-154, 213-245): the LibriSpeech utterance
+    resampled to 48 kHz by np.interp, one noisy trial through the reference.  The FLAC file is decoded with the
+    in-repo decoder (soundfile is not installed); the decoder checks the STREAMINFO MD5, so the PCM is exactly what
+    libsndfile would return.  The PCM is committed as a data fixture, the 4.6 MB spike raster as its SHA-256."""
+    import hashlib
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("flac", os.path.join(OUT, "..", "..", "haghighatshoarmuir2024_amd", "flac.py"))
+    flac = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(flac)
+    path = os.path.join(REF, "paper_plots", "84-121123-0020.flac")
+    pcm, rate, bps = flac.decode(open(path, "rb").read())
+    assert rate == 16000 and bps == 16 and pcm.shape == (110720, 1)
+    sig_test = pcm[:, 0].astype(np.float64) / 32768.0
+    beamf, geometry, fs, fd, fr = cfg2_beamformer(True)
+    z = np.load(os.path.join(OUT, "bf_mat_chirp449_bipolar.npz"))
+    bf_mat, doa_list = z["bf_mat"], z["doa_list"]
+    time_test = np.arange(len(sig_test)) / rate
+    time_fs = np.linspace(time_test[0], time_test[-1], int(len(sig_test) / rate * fs))
+    sig_fs = np.interp(time_fs, time_test, sig_test)
+    np.random.seed(5)
+    doa = np.random.rand(1)[0] * 2 * np.pi
+    cap_in = {}
+    orig_apply = beamf.apply_to_signal
+
+    def spy(bf_mat, sig_in_vec):
+        cap = capture_chain_cls(beamf, orig_apply, bf_mat, sig_in_vec)
+        cap_in.update(cap)
+        return cap["y"]
+
+    beamf.apply_to_signal = spy
+    try:
+        y = beamf.apply_to_template(bf_mat=bf_mat, template=(time_fs, sig_fs, doa), snr_db=10.0)
+    finally:
+        del beamf.apply_to_signal
+    power = np.mean(np.abs(y) ** 2, axis=0)
+    spikes = cap_in["spikes"].astype(np.int8)
+    row_idx = np.array([0, 240, 1000, 100000, 332156])
+    save("speech_trial.npz", pcm16=pcm[:, 0].astype(np.int16), rate=np.int64(rate), seed=np.int64(5), snr_db=np.float64(10.0), doa=np.float64(doa),
+         T=np.int64(y.shape[0]), power=power, argmax=np.int64(np.argmax(power)), spikes_sha256=np.frombuffer(hashlib.sha256(np.ascontiguousarray(spikes).tobytes()).digest(), dtype=np.uint8),
+         spikes_head=spikes[:3000], n_spikes=np.int64((spikes != 0).sum()), y_rows=y[row_idx], row_idx=row_idx)
+
+
 GENS = {
     "kat_init": gen_kat_init,
     "bf_mat_chirp": gen_bf_mat_chirp,
@@ -532,6 +576,7 @@ GENS = {
     "unipolar_trial": gen_unipolar_trial,
     "synth": gen_synth,
     "filterbank": gen_filterbank,
+    "speech": gen_speech,
 }
 
 if __name__ == "__main__":
