@@ -461,4 +461,27 @@ int micloc_lfilter_f64(const double *b, const double *a, int n, const double *x,
     return MICLOC_OK;
 }
 
+// ---- Xylo integer LIF (BASELINE config 4; parity unpinned, see xylo.hip) ------------------------------------
+size_t micloc_xylo_workspace_bytes(int Cin, int N)
+{
+    if (Cin < 1 || N < 1) return 0;
+    return xylo_ws_bytes(Cin, N);
+}
+
+int micloc_xylo_lif_i16(const uint8_t *spikes_in, int B, int T, int Cin, const int8_t *W_in, int N, int w_rec,
+                        const uint8_t *dash_syn, const uint8_t *dash_mem, const int16_t *thr, int max_spikes,
+                        uint8_t *spikes_out, int32_t *rate, void *ws, size_t ws_bytes, void *stream)
+{
+    if (!spikes_in || !W_in || !dash_syn || !dash_mem || !thr || B < 1 || T < 1 || Cin < 1 || N < 1 || max_spikes < 1 ||
+        (!spikes_out && !rate))
+        return MICLOC_ERR_INVALID;
+    if (Cin > 64 || (w_rec != 0 && N > 1024)) return MICLOC_ERR_SHAPE;
+    for (int g = 0; g < N; ++g)
+        if (thr[g] <= 0 || dash_syn[g] > 15 || dash_mem[g] > 15) return MICLOC_ERR_INVALID;
+    if (bad_ws(ws, ws_bytes, xylo_ws_bytes(Cin, N))) return MICLOC_ERR_WORKSPACE;
+    HIP_TRY(launch_xylo(spikes_in, B, T, Cin, W_in, N, w_rec, dash_syn, dash_mem, thr, max_spikes, spikes_out, rate, ws,
+                        (hipStream_t)stream));
+    return MICLOC_OK;
+}
+
 }  // extern "C"

@@ -70,4 +70,10 @@ hipError_t launch_power_argmax(const double *partial, int B, int T, int nchunks,
                                int Ghalf_pad, double *power, int32_t *argmax, hipStream_t stream);
 int beamform_nchunks(int T);
 
+// ---- Xylo integer LIF (parity unpinned) ------------------------------------------------------------------
+size_t xylo_ws_bytes(int Cin, int N);
+hipError_t launch_xylo(const uint8_t *spikes_in, int B, int T, int Cin, const int8_t *W_in_host, int N, int w_rec,
+                       const uint8_t *dash_syn_host, const uint8_t *dash_mem_host, const int16_t *thr_host,
+                       int max_spikes, uint8_t *spikes_out, int32_t *rate, void *ws, hipStream_t stream);
+
 }  // namespace micloc

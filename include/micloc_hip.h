@@ -123,6 +123,18 @@ size_t micloc_lfilter_workspace_bytes(int B, int T, int C);
 int micloc_lfilter_f64(const double *b, const double *a, int n, const double *x, int B, int T, int C, double *y,
                        void *ws, size_t ws_bytes, void *stream);
 
+/* ---- Xylo-A2 hidden-layer integer LIF (BASELINE config 4) -------------------------------------- */
+/* Replaces XyloSim.evolve as called by Demo.xylo_process (xylo_snn_localization.py:358-377) with the network built at
+ * :173-290: bit-shift decay, int8 weights, saturating int16 state, subtractive reset, one shared recurrent weight.
+ * PARITY UNPINNED: the reference's arithmetic is rockpool/xylosim (third party, unpinned, absent); this follows the
+ * published update rule (oracle/micloc_oracle.c oracle_xylo_lif).  spikes_in [B][T][Cin] uint8 (device),
+ * W_in [Cin][N] / dash_syn [N] / dash_mem [N] / thr [N] host arrays; spikes_out [B][T][N] uint8 and rate [B][N]
+ * int32 (device) may each be NULL.  Synchronises the stream once (coefficient upload). */
+size_t micloc_xylo_workspace_bytes(int Cin, int N);
+int micloc_xylo_lif_i16(const uint8_t *spikes_in, int B, int T, int Cin, const int8_t *W_in, int N, int w_rec,
+                        const uint8_t *dash_syn, const uint8_t *dash_mem, const int16_t *thr, int max_spikes,
+                        uint8_t *spikes_out, int32_t *rate, void *ws, size_t ws_bytes, void *stream);
+
 /* ---- misc ------------------------------------------------------------------------------------- */
 int micloc_abi_version(void);
 const char *micloc_status_string(int status);

@@ -370,3 +370,68 @@ void oracle_snn_chain_batch(const double *x, int B, int T, int M, const double *
                                      power + (size_t)i * G);
     }
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * Xylo-A2 (SYNS61201) hidden-layer integer LIF, restated from the PUBLIC description of the chip /
+ * XyloSim (bit-shift decay, 8-bit weights, 16-bit state, subtractive reset).  PARITY UNPINNED: the
+ * arithmetic of the reference for this stage lives in rockpool/xylosim (third party, not vendored, not
+ * pinned in setup.py:19, not installed here) and the reference holds no test vectors for it, so this
+ * function follows the published update rule, not a checked-against-XyloSim one.
+ * Call sites in the reference: micloc/xylo_snn_localization.py:269-290 (XyloSim.from_config),
+ * :358-377 (xylo_process: reset_state, evolve, rec["Spikes"]).
+ *
+ * Per time step t and hidden neuron g (all state int16, saturating):
+ *   isyn <- decay(isyn, dash_syn[g]);  vmem <- decay(vmem, dash_mem[g])
+ *        decay(v, d) = v - dv,  dv = v >> d (arithmetic), and if dv == 0 and v != 0: dv = sign(v)
+ *   isyn <- sat16(isyn + sum_c W_in[c][g] * s_in[t][c] + w_rec * (sum_g' s_out[t-1][g']))
+ *   vmem <- sat16(vmem + isyn)
+ *   n = 0; while vmem >= thr[g] and n < max_spikes: vmem -= thr[g]; ++n      (subtractive reset)
+ *   s_out[t][g] = n
+ * spikes_in: [T][Cin] uint8 (event counts), W_in: [Cin][N] int8, w_rec: one shared recurrent weight
+ * (Demo uses an all-equal w_rec = -0.1/N, xylo_snn_localization.py:231-232).
+ * spikes_out ([T][N] uint8) and rate ([N] int32, sum over t) may each be NULL.
+ * ---------------------------------------------------------------------------------------------- */
+static int sat16(int v) { return v > 32767 ? 32767 : (v < -32768 ? -32768 : v); }
+
+static int xylo_decay(int v, int dash)
+{
+    int dv = v >> dash; /* arithmetic shift of a (sign-extended) int16 value */
+    if (dv == 0 && v != 0) dv = v > 0 ? 1 : -1;
+    return v - dv;
+}
+
+void oracle_xylo_lif(const unsigned char *spikes_in, int T, int Cin, const signed char *W_in, int N, int w_rec,
+                     const unsigned char *dash_syn, const unsigned char *dash_mem, const short *thr, int max_spikes,
+                     unsigned char *spikes_out, int *rate)
+{
+    int *isyn = (int *)calloc((size_t)N, sizeof(int));
+    int *vmem = (int *)calloc((size_t)N, sizeof(int));
+    int prev_total = 0;
+    if (rate)
+        for (int g = 0; g < N; ++g) rate[g] = 0;
+    for (int t = 0; t < T; ++t) {
+        const unsigned char *s = spikes_in + (size_t)t * Cin;
+        int total = 0;
+        for (int g = 0; g < N; ++g) {
+            int in = 0;
+            for (int c = 0; c < Cin; ++c) in += (int)W_in[(size_t)c * N + g] * (int)s[c];
+            int i = xylo_decay(isyn[g], dash_syn[g]);
+            int v = xylo_decay(vmem[g], dash_mem[g]);
+            i = sat16(i + in + w_rec * prev_total);
+            v = sat16(v + i);
+            int n = 0;
+            while (v >= thr[g] && n < max_spikes) {
+                v -= thr[g];
+                ++n;
+            }
+            isyn[g] = i;
+            vmem[g] = v;
+            total += n;
+            if (spikes_out) spikes_out[(size_t)t * N + g] = (unsigned char)n;
+            if (rate) rate[g] += n;
+        }
+        prev_total = total;
+    }
+    free(isyn);
+    free(vmem);
+}

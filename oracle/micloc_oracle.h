@@ -35,6 +35,10 @@ void oracle_snn_chain_batch(const double *x, int B, int T, int M, const double *
                             int bipolar, const double *nir, int n_nir, const double *W, int G,
                             double *power, int *argmax);
 
+void oracle_xylo_lif(const unsigned char *spikes_in, int T, int Cin, const signed char *W_in, int N, int w_rec,
+                     const unsigned char *dash_syn, const unsigned char *dash_mem, const short *thr, int max_spikes,
+                     unsigned char *spikes_out, int *rate);
+
 #ifdef __cplusplus
 }
 #endif

@@ -62,6 +62,8 @@ def lib():
         L.oracle_snn_chain_batch.argtypes = [_dp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _dp, ctypes.c_int, _dp, _dp,
                                              ctypes.c_int, ctypes.c_int, ctypes.c_int, _dp, ctypes.c_int, _dp,
                                              ctypes.c_int, _dp, _ip]
+        L.oracle_xylo_lif.argtypes = [_ubp, ctypes.c_int, ctypes.c_int, _bp, ctypes.c_int, ctypes.c_int, _ubp, _ubp,
+                                      ctypes.POINTER(ctypes.c_short), ctypes.c_int, _ubp, _ip]
         _lib = L
     return _lib
 
@@ -285,3 +287,21 @@ def add_noise(sig, snr_db, randn=None):
 
 def doa_error(doa_est, doa_true):
     return np.arcsin(np.abs(np.sin(doa_est - doa_true)))
+
+
+def xylo_lif(spikes_in, W_in, w_rec, dash_syn, dash_mem, thr, max_spikes=31):
+    """Integer LIF of the Xylo hidden layer (parity unpinned, see micloc_oracle.c). spikes_in [T, Cin] uint8,
+    W_in [Cin, N] int8 -> (spikes_out [T, N] uint8, rate [N] int32)."""
+    s = np.ascontiguousarray(spikes_in, dtype=np.uint8)
+    W = np.ascontiguousarray(W_in, dtype=np.int8)
+    T, Cin = s.shape
+    N = W.shape[1]
+    ds = np.ascontiguousarray(np.broadcast_to(dash_syn, (N,)), dtype=np.uint8)
+    dm = np.ascontiguousarray(np.broadcast_to(dash_mem, (N,)), dtype=np.uint8)
+    th = np.ascontiguousarray(np.broadcast_to(thr, (N,)), dtype=np.int16)
+    out = np.zeros((T, N), dtype=np.uint8)
+    rate = np.zeros(N, dtype=np.int32)
+    lib().oracle_xylo_lif(s.ctypes.data_as(_ubp), T, Cin, W.ctypes.data_as(_bp), N, int(w_rec), ds.ctypes.data_as(_ubp),
+                          dm.ctypes.data_as(_ubp), th.ctypes.data_as(ctypes.POINTER(ctypes.c_short)), int(max_spikes),
+                          out.ctypes.data_as(_ubp), rate.ctypes.data_as(_ip))
+    return out, rate
