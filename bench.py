@@ -47,7 +47,7 @@ def build_workload(args, rank, device):
     import torch
 
     from haghighatshoarmuir2024_amd.array_geometry import CenterCircularArray
-    from haghighatshoarmuir2024_amd.snn_beamformer import SNNBeamformer, neuron_impulse_response, synthesize_array_signal
+    from haghighatshoarmuir2024_amd.snn_beamformer import SNNBeamformer, neuron_impulse_response
 
     fs, num_mic, freq_design = 48_000, 7, 2000.0
     freq_range = [0.5 * freq_design, freq_design]
@@ -71,12 +71,7 @@ def build_workload(args, rank, device):
     doa = rng.rand(B) * 2 * np.pi
     snr_db_vec = np.linspace(-10, 20, 11)
     snr_db = snr_db_vec[(np.arange(B) * len(snr_db_vec)) // B] - 10 * np.log10((fs / 2) / (freq_range[1] - freq_range[0]))
-    clean = []
-    time_in = None
-    for i in range(B):
-        time_in, sig = synthesize_array_signal(geometry, fs, time_test, sig_test, doa[i])
-        clean.append(sig)
-    clean = torch.from_numpy(np.stack(clean)).to(device)
+    time_in, clean = beamf.synthesize_batch((time_test, sig_test), doa)  # device synthesis, bit-exact with np.interp
     gen = torch.Generator(device=device)
     gen.manual_seed(1234 + rank)
     sigma = torch.sqrt(torch.mean(clean**2, dim=(1, 2))) / torch.sqrt(10 ** (torch.from_numpy(snr_db).to(device) / 10))

@@ -461,6 +461,15 @@ int micloc_lfilter_f64(const double *b, const double *a, int n, const double *x,
     return MICLOC_OK;
 }
 
+// ---- array-signal synthesis (noise-free part of apply_to_template) -------------------------------------------
+int micloc_synth_delay_f64(const double *time, const double *sig, const double *slopes, int T, const double *delays,
+                           int B, int M, double fs, double *x, void *stream)
+{
+    if (!time || !sig || !slopes || !delays || !x || T < 2 || B < 1 || M < 1 || !(fs > 0.0)) return MICLOC_ERR_INVALID;
+    HIP_TRY(launch_synth(time, sig, slopes, T, delays, B, M, fs, x, (hipStream_t)stream));
+    return MICLOC_OK;
+}
+
 // ---- Xylo integer LIF (BASELINE config 4; parity unpinned, see xylo.hip) ------------------------------------
 size_t micloc_xylo_workspace_bytes(int Cin, int N)
 {

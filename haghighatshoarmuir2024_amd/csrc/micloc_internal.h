@@ -76,4 +76,8 @@ hipError_t launch_xylo(const uint8_t *spikes_in, int B, int T, int Cin, const in
                        const uint8_t *dash_syn_host, const uint8_t *dash_mem_host, const int16_t *thr_host,
                        int max_spikes, uint8_t *spikes_out, int32_t *rate, void *ws, hipStream_t stream);
 
+// ---- array-signal synthesis ---------------------------------------------------------------------------------
+hipError_t launch_synth(const double *xp, const double *fp, const double *slopes, int T, const double *delays, int B,
+                        int M, double inv_step, double *out, hipStream_t stream);
+
 }  // namespace micloc

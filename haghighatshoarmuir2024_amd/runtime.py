@@ -278,6 +278,28 @@ def lfilter(b, a, x, device=None):
     return y[0] if squeeze else y
 
 
+def synth_delay(time_in, sig_in, delays, fs, device=None):
+    """Device synthesis of noise-free array signals: time_in/sig_in numpy [T] (already on the fs grid), delays numpy
+    [B, M] (min-shifted) -> device tensor [B, T, M], bit-exact with np.interp (see csrc/synth.hip)."""
+    torch = _torch()
+    lib = _lib.load()
+    device = require_gpu(device)
+    time_in = np.ascontiguousarray(time_in, dtype=np.float64)
+    sig_in = np.ascontiguousarray(sig_in, dtype=np.float64)
+    slopes = np.diff(sig_in) / np.diff(time_in)
+    delays = np.ascontiguousarray(delays, dtype=np.float64)
+    B, M = delays.shape
+    T = len(time_in)
+    d_time = torch.from_numpy(time_in).to(device)
+    d_sig = torch.from_numpy(sig_in).to(device)
+    d_slopes = torch.from_numpy(np.ascontiguousarray(slopes)).to(device)
+    d_delays = torch.from_numpy(delays).to(device)
+    x = torch.empty((B, T, M), dtype=torch.float64, device=device)
+    _lib.check(lib.micloc_synth_delay_f64(_ptr(d_time), _ptr(d_sig), _ptr(d_slopes), T, _ptr(d_delays), B, M, float(fs), _ptr(x),
+                                          _stream(device)), "synth_delay")
+    return x
+
+
 class StreamPipeline:
     """Round-robin dispatch of consecutive batches over several HIP streams, one Plan (= workspace) per stream.
 

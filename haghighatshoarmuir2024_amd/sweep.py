@@ -6,8 +6,9 @@ per-trial results at the end (RCCL over xGMI when the process group is "nccl").
 parity mode      every rank replays the reference's global NumPy stream (rand(1) then randn(T, M) per trial,
                  legacy MT19937) and keeps its own shard, so results are identical to the single-process
                  reference for any world size.
-throughput mode  DoAs from a seeded host generator, clean array signals synthesised on the host once per
-                 trial, noise drawn on the device (torch Philox generator seeded per rank).
+throughput mode  DoAs from a seeded host generator, clean array signals synthesised on the device
+                 (micloc_synth_delay_f64, bit-exact with np.interp), noise drawn on the device (torch Philox generator
+                 seeded per rank).
 """
 import numpy as np
 
@@ -106,10 +107,8 @@ def noisy_target_sweep(beamf, bf_mat, doa_list, snr_db_vec=None, num_sim=100, se
 
         rng = np.random.RandomState(seed)
         doa_all[:] = rng.rand(total) * 2 * np.pi
-        for trial in range(lo, hi):
-            time_in, sig = synthesize_array_signal(beamf.geometry, fs, time_test, sig_test, doa_all[trial])
-            sigs.append(sig)
-        clean = torch.from_numpy(np.stack(sigs)).cuda()
+        # noise-free array signals synthesised on the device (bit-exact with the host np.interp path)
+        time_in, clean = beamf.synthesize_batch((time_test, sig_test), doa_all[lo:hi])
         gen = torch.Generator(device=clean.device)
         gen.manual_seed(seed * 1_000_003 + rank)
         snr_db = torch.from_numpy(snr_db_vec[np.arange(lo, hi) // num_sim] - 10 * np.log10(snr_gain_due_to_bandwidth)).to(clean.device)

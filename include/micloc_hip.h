@@ -123,6 +123,14 @@ size_t micloc_lfilter_workspace_bytes(int B, int T, int C);
 int micloc_lfilter_f64(const double *b, const double *a, int n, const double *x, int B, int T, int C, double *y,
                        void *ws, size_t ws_bytes, void *stream);
 
+/* ---- array-signal synthesis ------------------------------------------------------------------- */
+/* Noise-free part of SNNBeamformer.apply_to_template for a constant DoA per trial (snn_beamformer.py:246-267):
+ * x[b][t][m] = np.interp(max(time[t] - delays[b][m], time[0]), time, sig), bit-exact with NumPy.  All pointers are
+ * DEVICE buffers: time [T] (the resampled grid, np.arange(t.min(), t.max(), 1/fs)), sig [T], slopes [T-1] =
+ * diff(sig)/diff(time), delays [B][M] (already shifted so that their minimum is 0), x [B][T][M]. */
+int micloc_synth_delay_f64(const double *time, const double *sig, const double *slopes, int T, const double *delays,
+                           int B, int M, double fs, double *x, void *stream);
+
 /* ---- Xylo-A2 hidden-layer integer LIF (BASELINE config 4) -------------------------------------- */
 /* Replaces XyloSim.evolve as called by Demo.xylo_process (xylo_snn_localization.py:358-377) with the network built at
  * :173-290: bit-shift decay, int8 weights, saturating int16 state, subtractive reset, one shared recurrent weight.

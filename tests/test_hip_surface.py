@@ -139,3 +139,39 @@ def test_beamformer_class_surface(cfg2):
     np.testing.assert_allclose(np.asarray(covs), z["cov_list"][:5], rtol=0, atol=1e-11)
     phase = np.sum(np.conj(W) * z["bf_mat"][:, :5], axis=0)
     np.testing.assert_allclose(W * (phase / np.abs(phase)), z["bf_mat"][:, :5], rtol=0, atol=1e-8)
+
+
+def test_device_synthesis_bit_exact(cfg2):
+    """synthesize_batch (device) == synthesize_array_signal (host NumPy, itself == the reference's golden output)."""
+    from haghighatshoarmuir2024_amd.snn_beamformer import synthesize_array_signal
+
+    z = golden("synth.npz")
+    bf = make_beamformer()
+    rng = np.random.RandomState(3)
+    doas = np.concatenate([[float(z["fixed_doa"])], rng.rand(40) * 2 * np.pi, [0.0, np.pi, -np.pi / 2]])
+    t, x = bf.synthesize_batch((z["time_test"], z["sig_test"]), doas)
+    x = x.cpu().numpy()
+    np.testing.assert_array_equal(t, z["fixed_time"])
+    np.testing.assert_allclose(x[0], z["fixed_sig"], rtol=0, atol=1e-100)
+    for i, doa in enumerate(doas):
+        _, ref = synthesize_array_signal(bf.geometry, 48_000, z["time_test"], z["sig_test"], float(doa))
+        np.testing.assert_array_equal(x[i], ref)
+    # a template that is NOT on the fs grid (resampled first) and the 0.1 s test tone of the sweep
+    fs = 48_000
+    time_test = np.arange(0, 100e-3, step=1 / fs)
+    sig_test = np.sin(2 * np.pi * 2000 * time_test)
+    t2, x2 = bf.synthesize_batch((time_test, sig_test), doas[:8])
+    for i in range(8):
+        _, ref = synthesize_array_signal(bf.geometry, fs, time_test, sig_test, float(doas[i]))
+        np.testing.assert_array_equal(x2[i].cpu().numpy(), ref)
+
+
+def test_throughput_sweep_statistics(cfg2):
+    """Throughput mode (device synthesis + device noise): MAE-vs-SNR must look like the reference's curve
+    (13.3 / 1.23 / 1.17 deg at -10 / +5 / +20 dB, grid step 0.8 deg)."""
+    from haghighatshoarmuir2024_amd.sweep import noisy_target_sweep
+
+    bf = make_beamformer()
+    res = noisy_target_sweep(bf, cfg2["bf_mat"], cfg2["doa_list"], snr_db_vec=[-10.0, 5.0, 20.0], num_sim=200, seed=11, mode="throughput")
+    mae = res["mae_deg"]
+    assert 6.0 < mae[0] < 25.0 and 0.5 < mae[1] < 2.5 and 0.5 < mae[2] < 2.0 and mae[0] > 3 * mae[1]
