@@ -96,7 +96,12 @@ WsLayout ws_layout(const micloc_plan *p, int B, int T)
     w.spikes = off;
     off += align256((size_t)B * T * p->C);
     w.partial = off;
-    off += beamform_partial_bytes(B, T, Gp);
+    {
+        const size_t pb = beamform_partial_bytes(B, T, Gp);
+        const int ct = pad_ct(p->C);
+        const size_t pc = ct <= 4 ? cov_partial_bytes(B, T, ct) : 0;
+        off += pb > pc ? pb : pc;
+    }
     w.total = off;
     return w;
 }
@@ -458,6 +463,53 @@ int micloc_lfilter_f64(const double *b, const double *a, int n, const double *x,
     HIP_TRY(launch_pack_planar(x, pin, B, T, C, Ts, st));
     HIP_TRY(launch_bandpass_rzcc(co, pin, B * C, C, T, Ts, 1, 0, pout, nullptr, nullptr, st));
     HIP_TRY(launch_unpack_planar(pout, y, B, T, C, Ts, st));
+    return MICLOC_OK;
+}
+
+// ---- covariance-form power and membrane covariance ------------------------------------------------------------
+int micloc_lif_covariance_f64(const micloc_plan *p, const int8_t *spikes, int B, int T, int t_start, double *cov,
+                              double *power, int32_t *argmax, void *ws, size_t ws_bytes, void *stream)
+{
+    if (!p || !spikes || B < 1 || T < 1 || t_start < 0 || t_start >= T || (!cov && !power && !argmax))
+        return MICLOC_ERR_INVALID;
+    if (!p->d_ntab) return MICLOC_ERR_NOT_SET;
+    const bool want_power = power || argmax;
+    if (want_power && (!p->d_W || p->W_is_complex)) return p->d_W ? MICLOC_ERR_SHAPE : MICLOC_ERR_NOT_SET;
+    const int CT = pad_ct(p->C);
+    if (CT > 4) return MICLOC_ERR_SHAPE;  // more than 64 channels: not built yet
+    if (bad_ws(ws, ws_bytes, cov_partial_bytes(B, T, CT))) return MICLOC_ERR_WORKSPACE;
+    double *partial = reinterpret_cast<double *>(ws);
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(launch_lif_cov(p->ntab, spikes, B, T, p->C, CT, t_start, partial, st));
+    HIP_TRY(launch_cov_power(partial, B, T, CT, p->C, T - t_start, want_power ? p->W.Wp : nullptr,
+                             want_power ? 16 * p->W.GT : 16, want_power ? p->G_out : 0, cov, power, argmax, st));
+    return MICLOC_OK;
+}
+
+int micloc_snn_pipeline_cov_f64(const micloc_plan *p, const double *x, int B, int T, int t_start, int8_t *spikes,
+                                double *cov, double *power, int32_t *argmax, void *ws, size_t ws_bytes, void *stream)
+{
+    if (!p || !x || B < 1 || T < 1 || t_start < 0 || t_start >= T || (!cov && !power && !argmax))
+        return MICLOC_ERR_INVALID;
+    if (!p->d_ntab) return MICLOC_ERR_NOT_SET;
+    const bool want_power = power || argmax;
+    if (want_power && (!p->d_W || p->W_is_complex)) return p->d_W ? MICLOC_ERR_SHAPE : MICLOC_ERR_NOT_SET;
+    const int CT = pad_ct(p->C);
+    if (CT > 4) return MICLOC_ERR_SHAPE;
+    const WsLayout w = ws_layout(p, B, T);
+    if (bad_ws(ws, ws_bytes, w.total)) return MICLOC_ERR_WORKSPACE;
+    unsigned char *base = reinterpret_cast<unsigned char *>(ws);
+    double *h = reinterpret_cast<double *>(base + w.h);
+    int8_t *spk = spikes ? spikes : reinterpret_cast<int8_t *>(base + w.spikes);
+    const int Ts = micloc_padded_T(T);
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(launch_stht(p->taps, x, h, B, T, p->M, Ts, st));
+    HIP_TRY(launch_bandpass_rzcc(p->iir, h, B * p->C, p->C, T, Ts, p->robust_width, p->bipolar, nullptr, spk,
+                                 base + w.scratch, st));
+    double *partial = reinterpret_cast<double *>(base + w.partial);
+    HIP_TRY(launch_lif_cov(p->ntab, spk, B, T, p->C, CT, t_start, partial, st));
+    HIP_TRY(launch_cov_power(partial, B, T, CT, p->C, T - t_start, want_power ? p->W.Wp : nullptr,
+                             want_power ? 16 * p->W.GT : 16, want_power ? p->G_out : 0, cov, power, argmax, st));
     return MICLOC_OK;
 }
 

@@ -1,0 +1,251 @@
+// Covariance-form power: power[g] = mean_t (sum_c vmem[t][c] W[c][g])^2 = w_g^T (V^T V / T) w_g.
+// Algebraically identical to beamforming followed by mean |y|^2 (snn_beamformer.py:368 +
+// target_snn_localization.py:462), but the T x G product is never formed: per frame 2 C^2 flops instead of
+// 2 C G (25x fewer at C = 14, G = 360).  Reported as a separate algorithmic variant, never as the headline number.
+// The same kernel yields the membrane covariance C = V^T V / T' over the last 3/4 of the signal that
+// design_from_template needs (snn_beamformer.py:176-191).
+//
+// lif_cov_kernel: LIF in the *non-transposed* orientation  V = N S  (A = Toeplitz nir lookup, B = int8 spikes):
+// the accumulator of k-step r, lane l holds V[t = (l>>4)+4r][c = l&15], which is simultaneously the A fragment
+// (A[i=c][k=t]) and the B fragment (B[k=t][j=c']) of the Gram product  R += V^T V  -- one register feeds both
+// operands of v_mfma_f64_16x16x4_f64.  The LIF summation order (chronological) is unchanged, so V is bit-identical
+// to the beamforming kernel's.
+#include "micloc_internal.h"
+
+namespace micloc {
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+constexpr int CV_THREADS = BF_WAVES * 64;
+
+template <int CT>
+__global__ __launch_bounds__(CV_THREADS) void lif_cov_kernel(const int8_t *__restrict__ spikes,
+                                                              const double *__restrict__ ntab_g, int NK, int C, int T,
+                                                              int t_start, double *__restrict__ partial)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int Cs = 16 * CT;
+    constexpr int NP = CT * (CT + 1) / 2;  // upper-triangular 16x16 tiles of R
+    const int tid = threadIdx.x;
+    const int wv = tid >> 6;
+    const int l = tid & 63;
+    const int lc = l & 15;
+    const int q = l >> 4;
+    const int chunk = blockIdx.x;
+    const int nchunks = gridDim.x;
+    const int b = blockIdx.y;
+    const int cs = chunk * BF_CHUNK;
+
+    double *ntab = reinterpret_cast<double *>(smem);
+    const int ntab_len = 4 * NK + 16;
+    double *red = ntab + ntab_len;                       // [BF_WAVES][NP][4][64]
+    int8_t *spk = reinterpret_cast<int8_t *>(red);        // aliases red (barrier in between)
+    const int R = BF_CHUNK + 4 * NK - 16;
+
+    for (int e = tid; e < ntab_len; e += CV_THREADS) ntab[e] = ntab_g[e];
+    {
+        const int8_t *sb = spikes + (size_t)b * T * C;
+        const int tau0 = cs + 16 - 4 * NK;
+        for (int e = tid; e < R * Cs; e += CV_THREADS) {
+            const int rho = e / Cs, c = e % Cs;
+            const int tau = tau0 + rho;
+            int8_t v = 0;
+            if (c < C && tau >= 0 && tau < T) v = sb[(size_t)tau * C + c];
+            spk[e] = v;
+        }
+    }
+    __syncthreads();
+
+    const int tb0 = cs + wv * BF_NT * 16;
+    double4_t Racc[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) Racc[p] = double4_t{0.0, 0.0, 0.0, 0.0};
+
+    if (tb0 < T) {
+        // ---- LIF for the 4 time tiles of this wave, all channel tiles ----
+        double4_t V[BF_NT][CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            double4_t acc[BF_NT];
+#pragma unroll
+            for (int tt = 0; tt < BF_NT; ++tt) acc[tt] = double4_t{0.0, 0.0, 0.0, 0.0};
+            const int8_t *sp = spk + (size_t)(tb0 - cs + q) * Cs + 16 * ct + lc;
+            const double *np_ = ntab + (lc - q + 4 * NK - 16 + 15);
+            double bn_n = np_[0];
+            int an[BF_NT];
+#pragma unroll
+            for (int tt = 0; tt < BF_NT; ++tt) an[tt] = sp[(size_t)(16 * tt) * Cs];
+            for (int ks = 0; ks < NK; ++ks) {
+                const double bn = bn_n;
+                double a[BF_NT];
+#pragma unroll
+                for (int tt = 0; tt < BF_NT; ++tt) a[tt] = (double)an[tt];
+                if (ks + 1 < NK) {
+                    bn_n = np_[-4 * (ks + 1)];
+#pragma unroll
+                    for (int tt = 0; tt < BF_NT; ++tt) an[tt] = sp[(size_t)(16 * tt + 4 * (ks + 1)) * Cs];
+                }
+#pragma unroll
+                for (int tt = 0; tt < BF_NT; ++tt)
+                    acc[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(bn, a[tt], acc[tt], 0, 0, 0);  // A = nir, B = spikes
+            }
+#pragma unroll
+            for (int tt = 0; tt < BF_NT; ++tt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int t = tb0 + 16 * tt + q + 4 * r;  // row of this accumulator element
+                    acc[tt][r] = (t < T && t >= t_start) ? acc[tt][r] : 0.0;
+                }
+                V[tt][ct] = acc[tt];
+            }
+        }
+        // ---- Gram accumulation: R(ct, ct') += V_ct^T V_ct'  (upper triangle) ----
+        int p = 0;
+#pragma unroll
+        for (int c1 = 0; c1 < CT; ++c1)
+#pragma unroll
+            for (int c2 = c1; c2 < CT; ++c2) {
+#pragma unroll
+                for (int tt = 0; tt < BF_NT; ++tt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        Racc[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(V[tt][c1][r], V[tt][c2][r], Racc[p], 0, 0, 0);
+                ++p;
+            }
+    }
+    __syncthreads();  // spike tile is dead: red may overwrite it
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[(((size_t)wv * NP + p) * 4 + r) * 64 + l] = Racc[p][r];
+    __syncthreads();
+    double *pout = partial + ((size_t)b * nchunks + chunk) * (NP * 256);
+    for (int e = tid; e < NP * 256; e += CV_THREADS) {
+        double s = 0.0;
+#pragma unroll
+        for (int w8 = 0; w8 < BF_WAVES; ++w8) s += red[(size_t)w8 * NP * 256 + e];
+        pout[e] = s;
+    }
+}
+
+// One workgroup per trial: R = sum over chunks (fixed order), symmetric fill, optional normalised output, and
+// power[g] = w_g^T R w_g / Tn for every DoA; arg-max.
+__global__ __launch_bounds__(256) void cov_power_kernel(const double *__restrict__ partial, int nchunks, int CT, int C,
+                                                         int Tn, const double *__restrict__ Wp, int Gp, int G,
+                                                         double *__restrict__ cov_out, double *__restrict__ power,
+                                                         int32_t *__restrict__ argmax)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];
+    double *Rs = reinterpret_cast<double *>(smem2);  // [Cp][Cp]
+    __shared__ double sv[256];
+    __shared__ int si[256];
+    const int Cp = 16 * CT;
+    const int NP = CT * (CT + 1) / 2;
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x;
+    const double *pb = partial + (size_t)b * nchunks * NP * 256;
+    for (int e = tid; e < NP * 256; e += 256) {
+        double s = 0.0;
+        for (int ch = 0; ch < nchunks; ++ch) s += pb[(size_t)ch * NP * 256 + e];
+        // decode: e = (p*4 + r)*64 + l ; tile p = (c1, c2), row i = (l>>4) + 4r, col j = l&15
+        const int l = e & 63, r = (e >> 6) & 3, p = e >> 8;
+        int c1 = 0, rem = p;
+        while (rem >= CT - c1) {
+            rem -= CT - c1;
+            ++c1;
+        }
+        const int c2 = c1 + rem;
+        const int i = 16 * c1 + (l >> 4) + 4 * r, j = 16 * c2 + (l & 15);
+        Rs[(size_t)i * Cp + j] = s;
+        if (c1 != c2) Rs[(size_t)j * Cp + i] = s;
+    }
+    __syncthreads();
+    const double inv = 1.0 / (double)Tn;
+    if (cov_out) {
+        for (int e = tid; e < C * C; e += 256) {
+            const int i = e / C, j = e % C;
+            cov_out[(size_t)b * C * C + e] = Rs[(size_t)i * Cp + j] * inv;
+        }
+    }
+    double best = -1.0;
+    int bi = 0x7fffffff;
+    if (power || argmax) {
+        for (int g = tid; g < G; g += 256) {
+            double p = 0.0;
+            for (int i = 0; i < C; ++i) {
+                double u = 0.0;
+                for (int j = 0; j < C; ++j) u = __builtin_fma(Rs[(size_t)i * Cp + j], Wp[(size_t)j * Gp + g], u);
+                p = __builtin_fma(Wp[(size_t)i * Gp + g], u, p);
+            }
+            p = p * inv;
+            if (power) power[(size_t)b * G + g] = p;
+            if (p > best) {
+                best = p;
+                bi = g;
+            }
+        }
+    }
+    sv[tid] = best;
+    si[tid] = bi;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) {
+            const double ov = sv[tid + s];
+            const int oi = si[tid + s];
+            if (ov > sv[tid] || (ov == sv[tid] && oi < si[tid])) {
+                sv[tid] = ov;
+                si[tid] = oi;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0 && argmax) argmax[b] = si[0] == 0x7fffffff ? 0 : si[0];
+}
+
+size_t cov_partial_bytes(int B, int T, int CT)
+{
+    const size_t NP = (size_t)CT * (CT + 1) / 2;
+    return ((size_t)B * beamform_nchunks(T) * NP * 256 * sizeof(double) + 255) & ~(size_t)255;
+}
+
+template <int CT>
+static hipError_t launch_cov_ct(const NeuronTab &nt, const int8_t *spikes, int B, int T, int C, int t_start,
+                                double *partial, hipStream_t stream)
+{
+    constexpr int NP = CT * (CT + 1) / 2;
+    size_t red = (size_t)BF_WAVES * NP * 256 * sizeof(double);
+    const size_t tile = (size_t)(BF_CHUNK + 4 * nt.NK - 16) * 16 * CT;
+    size_t lds = (red > tile ? red : tile) + (size_t)(4 * nt.NK + 16) * sizeof(double);
+    lds = (lds + 15) & ~(size_t)15;
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    auto k = &lif_cov_kernel<CT>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       160 * 1024);
+    if (e != hipSuccess) return e;
+    dim3 grid(beamform_nchunks(T), B), block(CV_THREADS);
+    hipLaunchKernelGGL(k, grid, block, lds, stream, spikes, nt.tab, nt.NK, C, T, t_start, partial);
+    return hipGetLastError();
+}
+
+hipError_t launch_lif_cov(const NeuronTab &nt, const int8_t *spikes, int B, int T, int C, int CT, int t_start,
+                          double *partial, hipStream_t stream)
+{
+    switch (CT) {
+        case 1: return launch_cov_ct<1>(nt, spikes, B, T, C, t_start, partial, stream);
+        case 2: return launch_cov_ct<2>(nt, spikes, B, T, C, t_start, partial, stream);
+        case 3: return launch_cov_ct<3>(nt, spikes, B, T, C, t_start, partial, stream);
+        case 4: return launch_cov_ct<4>(nt, spikes, B, T, C, t_start, partial, stream);
+        default: return hipErrorInvalidValue;  // C > 64: needs the LDS-shared variant (not built yet)
+    }
+}
+
+hipError_t launch_cov_power(const double *partial, int B, int T, int CT, int C, int Tn, const double *Wp, int Gp, int G,
+                            double *cov_out, double *power, int32_t *argmax, hipStream_t stream)
+{
+    const size_t lds = (size_t)(16 * CT) * (16 * CT) * sizeof(double);
+    hipLaunchKernelGGL(cov_power_kernel, dim3(B), dim3(256), lds, stream, partial, beamform_nchunks(T), CT, C, Tn, Wp, Gp,
+                       G, cov_out, power, argmax);
+    return hipGetLastError();
+}
+
+}  // namespace micloc

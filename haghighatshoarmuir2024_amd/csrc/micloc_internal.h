@@ -70,6 +70,13 @@ hipError_t launch_power_argmax(const double *partial, int B, int T, int nchunks,
                                int Ghalf_pad, double *power, int32_t *argmax, hipStream_t stream);
 int beamform_nchunks(int T);
 
+// ---- covariance-form power / membrane covariance ------------------------------------------------------------
+size_t cov_partial_bytes(int B, int T, int CT);
+hipError_t launch_lif_cov(const NeuronTab &nt, const int8_t *spikes, int B, int T, int C, int CT, int t_start,
+                          double *partial, hipStream_t stream);
+hipError_t launch_cov_power(const double *partial, int B, int T, int CT, int C, int Tn, const double *Wp, int Gp, int G,
+                            double *cov_out, double *power, int32_t *argmax, hipStream_t stream);
+
 // ---- Xylo integer LIF (parity unpinned) ------------------------------------------------------------------
 size_t xylo_ws_bytes(int Cin, int N);
 hipError_t launch_xylo(const uint8_t *spikes_in, int B, int T, int Cin, const int8_t *W_in_host, int N, int w_rec,

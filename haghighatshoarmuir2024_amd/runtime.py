@@ -176,6 +176,25 @@ class Plan:
         out.update(spikes=spikes, y=y, power=power, argmax=argmax)
         return out
 
+    def snn_pipeline_cov(self, x, t_start=0, want_spikes=False, want_cov=False, want_power=True):
+        """Covariance-form tail: power = w^T (V^T V / T') w, optionally the membrane covariance itself
+        (frames t >= t_start).  Algebraically identical to snn_pipeline's power; supports up to 64 channels."""
+        torch = _torch()
+        B, T, M = x.shape
+        if M != self.num_mic:
+            raise ValueError(f"number of channels in the input siganl {M} should be the same as the number of microphones {self.num_mic}!")
+        spikes = torch.empty((B, T, self.C), dtype=torch.int8, device=self.device) if want_spikes else None
+        cov = torch.empty((B, self.C, self.C), dtype=torch.float64, device=self.device) if want_cov else None
+        power = torch.empty((B, self.G), dtype=torch.float64, device=self.device) if want_power else None
+        argmax = torch.empty((B,), dtype=torch.int32, device=self.device) if want_power else None
+        ws, nbytes = self.workspace(B, T)
+        _lib.check(
+            self.lib.micloc_snn_pipeline_cov_f64(self.handle, _ptr(x), B, T, int(t_start), _ptr(spikes), _ptr(cov), _ptr(power), _ptr(argmax),
+                                                  _ptr(ws), nbytes, _stream(self.device)),
+            "snn_pipeline_cov",
+        )
+        return dict(spikes=spikes, cov=cov, power=power, argmax=argmax)
+
     def beamformer_pipeline(self, x, want_y=False, want_power=True):
         torch = _torch()
         B, T, M = x.shape

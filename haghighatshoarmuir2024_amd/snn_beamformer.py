@@ -155,7 +155,7 @@ class SNNBeamformer:
         return time_in, runtime.synth_delay(time_in, sig_in, delays, self.fs, device=self.device)
 
     # ---- batched device entry points (not in the reference) --------------------------------------------------
-    def localize_batch(self, bf_mat, sig_batch, time_vec=None, return_spikes=False):
+    def localize_batch(self, bf_mat, sig_batch, time_vec=None, return_spikes=False, power_mode="direct"):
         """sig_batch [B, T, M] (numpy or device tensor, already on the fs grid) -> dict of device tensors:
         power [B, G] = mean_t |apply_to_signal|^2, argmax [B] (int32), optionally spikes [B, T, 2M] int8."""
         B, T, M = sig_batch.shape
@@ -167,7 +167,21 @@ class SNNBeamformer:
         plan.set_neuron_kernel(neuron_impulse_response(time_vec, self.tau_vec))
         plan.set_bf_mat(np.asarray(bf_mat, dtype=np.float64))
         x = plan.to_device(sig_batch)
+        if power_mode == "covariance":
+            # algebraically identical variant: w^T (V^T V / T) w instead of mean_t (V w)^2  (SURVEY 8f.4)
+            return plan.snn_pipeline_cov(x, want_spikes=return_spikes, want_power=True)
+        if power_mode != "direct":
+            raise ValueError("power_mode must be 'direct' or 'covariance'")
         return plan.snn_pipeline(x, want_spikes=return_spikes, want_power=True)
+
+    def membrane_covariance_batch(self, sig_batch, time_vec=None, t_start=0):
+        """[B, T, M] -> device tensor [B, 2M, 2M]: V^T V / (T - t_start) of the membrane signal over frames >= t_start."""
+        B, T, M = sig_batch.shape
+        if time_vec is None:
+            time_vec = np.arange(T) / self.fs
+        plan = self.plan()
+        plan.set_neuron_kernel(neuron_impulse_response(time_vec, self.tau_vec))
+        return plan.snn_pipeline_cov(plan.to_device(sig_batch), t_start=t_start, want_cov=True, want_power=False)["cov"]
 
     def membrane_batch(self, sig_batch, time_vec=None):
         """[B, T, M] -> device tensor [B, T, 2M]: the membrane signal vmem (bf_mat = identity)."""
@@ -200,10 +214,14 @@ class SNNBeamformer:
             np.maximum(time_delayed, time_temp.min(), out=time_delayed)
             sig = np.interp(time_delayed.ravel(), time_temp, sig_temp).reshape(time_delayed.shape)
             sig = np.ascontiguousarray(np.transpose(sig, (0, 2, 1)))  # [n, T, M]
-            vmem = self.membrane_batch(sig, time_vec=time_temp)
-            stable = vmem.shape[1] // 4
-            v = vmem[:, stable:, :]
-            cov = (v.transpose(1, 2) @ v / v.shape[1]).cpu().numpy()  # [n, 2M, 2M]
+            if sig.shape[2] * 2 <= 64:
+                # membrane covariance over the last 3/4 on the device (MFMA Gram kernel)
+                cov = self.membrane_covariance_batch(sig, time_vec=time_temp, t_start=sig.shape[1] // 4).cpu().numpy()
+            else:
+                vmem = self.membrane_batch(sig, time_vec=time_temp)
+                stable = vmem.shape[1] // 4
+                v = vmem[:, stable:, :]
+                cov = (v.transpose(1, 2) @ v / v.shape[1]).cpu().numpy()  # [n, 2M, 2M]
             for C in cov:
                 if not self.spk_encoder.bipolar:
                     bf_mat.append(self._find_dc_removed_sing_vec(C, rel_prec=0.00000001))

@@ -123,6 +123,19 @@ size_t micloc_lfilter_workspace_bytes(int B, int T, int C);
 int micloc_lfilter_f64(const double *b, const double *a, int n, const double *x, int B, int T, int C, double *y,
                        void *ws, size_t ws_bytes, void *stream);
 
+/* ---- covariance form ------------------------------------------------------------------ */
+/* cov[b] = V^T V / (T - t_start) over frames t >= t_start of the membrane signal V = lfilter(nir,[1],spikes)
+ * (the matrix design_from_template needs, snn_beamformer.py:176-191, with t_start = T // 4), and
+ * power[b][g] = w_g^T (V^T V / T') w_g  ==  mean_t (V @ bf_mat)^2  without forming T x G.  An algebraically
+ * identical VARIANT of micloc_lif_beamform_f64's power (2 C^2 instead of 2 C G flops per frame); it agrees to
+ * ~1e-15 relative but is reported separately.  cov [B][C][C], power [B][G], argmax [B] may each be NULL.
+ * Supports C <= 64 channels. */
+int micloc_lif_covariance_f64(const micloc_plan *plan, const int8_t *spikes, int B, int T, int t_start, double *cov,
+                              double *power, int32_t *argmax, void *ws, size_t ws_bytes, void *stream);
+/* whole chain (STHT, band-pass, RZCC, LIF) with the covariance-form tail */
+int micloc_snn_pipeline_cov_f64(const micloc_plan *plan, const double *x, int B, int T, int t_start, int8_t *spikes,
+                                double *cov, double *power, int32_t *argmax, void *ws, size_t ws_bytes, void *stream);
+
 /* ---- array-signal synthesis ------------------------------------------------------------------- */
 /* Noise-free part of SNNBeamformer.apply_to_template for a constant DoA per trial (snn_beamformer.py:246-267):
  * x[b][t][m] = np.interp(max(time[t] - delays[b][m], time[0]), time, sig), bit-exact with NumPy.  All pointers are

@@ -268,3 +268,47 @@ def test_many_mic_shapes_vs_oracle(torch, M, G, T):
         np.testing.assert_array_equal(out["y"][i].cpu().numpy(), ref["y"])
         np.testing.assert_allclose(out["power"][i].cpu().numpy(), ref["power"], rtol=1e-12)
         assert int(out["argmax"][i]) == ref["argmax"]
+
+
+def test_covariance_form_power_and_membrane_covariance(plan2, cfg2):
+    """w^T (V^T V / T) w == mean_t (V w)^2; the Gram kernel also returns V^T V / T' for the design path."""
+    z = golden("trials_cfg2.npz")
+    x = plan2.to_device(z["sig_in"])
+    direct = plan2.snn_pipeline(x, want_power=True)
+    cov = plan2.snn_pipeline_cov(x, want_cov=True, want_power=True, want_spikes=True)
+    np.testing.assert_array_equal(cov["spikes"].cpu().numpy(), z["spikes"])
+    np.testing.assert_allclose(cov["power"].cpu().numpy(), direct["power"].cpu().numpy(), rtol=1e-12, atol=0)
+    np.testing.assert_allclose(cov["power"].cpu().numpy(), z["power"], rtol=1e-10, atol=0)
+    np.testing.assert_array_equal(cov["argmax"].cpu().numpy(), z["argmax"])
+    T = x.shape[1]
+    stable = T // 4
+    part = plan2.snn_pipeline_cov(x, t_start=stable, want_cov=True, want_power=False)["cov"].cpu().numpy()
+    for b in range(3):
+        ref = O.snn_chain(z["sig_in"][b], cfg2["kernel"], cfg2["b"], cfg2["a"], cfg2["robust_width"], True, cfg2["nir"], cfg2["bf_mat"], want=("vmem",))
+        v = ref["vmem"]
+        np.testing.assert_allclose(cov["cov"][b].cpu().numpy(), v.T @ v / T, rtol=1e-12, atol=1e-18)
+        np.testing.assert_allclose(part[b], v[stable:].T @ v[stable:] / (T - stable), rtol=1e-12, atol=1e-18)
+
+
+def test_covariance_form_wide(torch):
+    """C = 32 and C = 48 channels (two / three channel tiles -> 3 / 6 Gram tiles)."""
+    from haghighatshoarmuir2024_amd.runtime import Plan
+
+    for M, G, T in [(16, 40, 900), (24, 20, 530)]:
+        fs = 96_000
+        rng = np.random.RandomState(M)
+        ker = O.stht_kernel(fs, 10e-3)
+        b, a = O.bandpass(fs, [1000.0, 2000.0])
+        tau = 1 / (2 * np.pi * 2000.0)
+        nir = O.neuron_kernel(np.arange(T) / fs, [tau, tau])
+        W = rng.randn(2 * M, G)
+        x = np.sin(2 * np.pi * 1500 * np.arange(T)[None, :, None] / fs + rng.rand(2, 1, M) * 6) + 0.3 * rng.randn(2, T, M)
+        p = Plan(M, ker, b, a, O.robust_width(fs, 2000.0), True)
+        p.set_neuron_kernel(nir)
+        p.set_bf_mat(W)
+        xd = p.to_device(x)
+        d = p.snn_pipeline(xd, want_power=True)
+        c = p.snn_pipeline_cov(xd, want_cov=True, want_power=True)
+        np.testing.assert_allclose(c["power"].cpu().numpy(), d["power"].cpu().numpy(), rtol=1e-11)
+        ref = O.snn_chain(x[1], ker, b, a, O.robust_width(fs, 2000.0), True, nir, W, want=("vmem",))
+        np.testing.assert_allclose(c["cov"][1].cpu().numpy(), ref["vmem"].T @ ref["vmem"] / T, rtol=1e-11, atol=1e-18)
