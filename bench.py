@@ -172,8 +172,12 @@ def main():
         args.gpus = world
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+    # MICLOC_FORCE_DIST=1 runs the collective code path with a 1-rank RCCL group (to exercise it on a 1-GPU box)
+    use_dist = world > 1 or os.environ.get("MICLOC_FORCE_DIST") == "1"
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     wl = build_workload(args, rank, device)
     step, pipe = make_step(wl, max(1, args.streams))
@@ -182,7 +186,7 @@ def main():
 
     def barrier():
         pipe.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -195,7 +199,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         # the sweep's one exchange step: gather the per-rank MAE curves (RCCL)
         gathered = [torch.empty_like(mae) for _ in range(world)]
@@ -216,7 +220,7 @@ def main():
             out_c, mae_c = step(cov=True)
         barrier()
         dtc = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
-        if world > 1:
+        if use_dist:
             dist.all_reduce(dtc, op=dist.ReduceOp.MAX)
         dtc = float(dtc.item())
         cov_variant = {"value": frames / dtc, "unit": "frames/s", "ms_per_step": dtc / args.steps * 1e3,
@@ -273,10 +277,19 @@ def main():
             am_gpu = out["argmax"][: len(am_cpu)].cpu().numpy()
             cb["argmax_equal_to_gpu"] = bool(np.array_equal(am_cpu, am_gpu))
             result["cpu_baseline"] = cb
-        print(json.dumps(result), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL prints a version banner through C stdio on stdout; flush it first so the JSON line is the last line
+        import ctypes
+
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(result), flush=True)
 
 
 if __name__ == "__main__":

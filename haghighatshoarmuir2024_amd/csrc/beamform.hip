@@ -29,6 +29,23 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 
 constexpr int BF_THREADS = BF_WAVES * 64;
 
+typedef unsigned uint2_t __attribute__((ext_vector_type(2)));
+
+// Sum over the four 16-lane rows of a wave, result in every lane: gfx950's v_permlane16_swap / v_permlane32_swap
+// exchange rows between two registers in the VALU (no LDS round trip as with ds_bpermute-based __shfl_xor).
+__device__ __forceinline__ double row_sum4(double x)
+{
+    unsigned lo = __double2loint(x), hi = __double2hiint(x);
+    uint2_t a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    uint2_t b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    const double s = __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);  // rows (0+1, 0+1, 2+3, 2+3)
+    lo = __double2loint(s);
+    hi = __double2hiint(s);
+    a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+}
+
 int beamform_nchunks(int T) { return (T + BF_CHUNK - 1) / BF_CHUNK; }
 
 size_t beamform_partial_bytes(int B, int T, int Gp)
@@ -72,19 +89,45 @@ __global__ __launch_bounds__(BF_THREADS) void beamform_kernel(const int8_t *__re
     if (W_LDS) {
         const double2 *src2 = reinterpret_cast<const double2 *>(Wp);
         double2 *dst2 = reinterpret_cast<double2 *>(Wl);
-        for (int e = tid; e < (C * Gp) / 2; e += BF_THREADS) dst2[e] = src2[e];
+        const int n2 = (C * Gp) / 2;
+        for (int e0 = tid; e0 < n2; e0 += BF_THREADS * 4) {
+            double2 v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int e = e0 + i * BF_THREADS;
+                v[i] = src2[e < n2 ? e : n2 - 1];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int e = e0 + i * BF_THREADS;
+                if (e < n2) dst2[e] = v[i];
+            }
+        }
         for (int e = tid; e < Gp; e += BF_THREADS) Wl[(size_t)C * Gp + e] = 0.0;
     }
     if (SRC_SPIKES) {
         for (int e = tid; e < ntab_len; e += BF_THREADS) ntab[e] = ntab_g[e];
         const int8_t *sb = spikes + (size_t)b * T * C;
         const int tau0 = cs + 16 - 4 * NK;
-        for (int e = tid; e < R * Cs; e += BF_THREADS) {
-            const int rho = e / Cs, c = e % Cs;
-            const int tau = tau0 + rho;
-            int8_t v = 0;
-            if (c < C && tau >= 0 && tau < T) v = sb[(size_t)tau * C + c];
-            spk[e] = v;
+        // all loads of a batch are issued (clamped addresses, hence unconditional) before the first LDS write, so
+        // the workgroup pays the memory latency once per batch instead of once per element
+        for (int e0 = tid; e0 < R * Cs; e0 += BF_THREADS * 8) {
+            int8_t v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int e = e0 + i * BF_THREADS;
+                const int rho = e / Cs, c = e % Cs;
+                int tau = tau0 + rho;
+                tau = tau < 0 ? 0 : (tau >= T ? T - 1 : tau);
+                v[i] = sb[(size_t)tau * C + (c < C ? c : C - 1)];
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int e = e0 + i * BF_THREADS;
+                const int rho = e / Cs, c = e % Cs;
+                const int tau = tau0 + rho;
+                if (e < R * Cs) spk[e] = (c < C && tau >= 0 && tau < T) ? v[i] : (int8_t)0;
+            }
         }
     }
     __syncthreads();
@@ -209,8 +252,7 @@ __global__ __launch_bounds__(BF_THREADS) void beamform_kernel(const int8_t *__re
                 }
             }
         }
-        sq += __shfl_xor(sq, 16);
-        sq += __shfl_xor(sq, 32);
+        sq = row_sum4(sq);  // lanes l, l^16, l^32, l^48 hold the same DoA column
         if (l < 16) red[(size_t)wv * Gp + 16 * gt + l] = sq;
     };
 
@@ -220,20 +262,22 @@ __global__ __launch_bounds__(BF_THREADS) void beamform_kernel(const int8_t *__re
     } else {
         double WfA[KS], WfB[KS];
         double4_t accA[BF_NT], accB[BF_NT];
+        // W fragments are fetched one whole DoA tile ahead of the MFMAs that consume them
+        auto load_w_clamped = [&](int gt, double (&Wf)[KS]) { load_w(gt < GT ? gt : GT - 1, Wf); };
         load_w(0, WfA);
+        load_w_clamped(1, WfB);
         issue(WfA, accA);
         int gt = 0;
         for (; gt + 2 < GT; gt += 2) {
-            load_w(gt + 1, WfB);
             issue(WfB, accB);
+            load_w_clamped(gt + 2, WfA);
             epilogue(gt, accA);
-            load_w(gt + 2, WfA);
             issue(WfA, accA);
+            load_w_clamped(gt + 3, WfB);
             epilogue(gt + 1, accB);
         }
-        // tail: gt is the last issued-into-A tile; one or two tiles remain
+        // tail: tile gt sits in A; one or two tiles remain
         if (gt + 1 < GT) {
-            load_w(gt + 1, WfB);
             issue(WfB, accB);
             epilogue(gt, accA);
             epilogue(gt + 1, accB);

@@ -46,12 +46,25 @@ __global__ __launch_bounds__(CV_THREADS) void lif_cov_kernel(const int8_t *__res
     {
         const int8_t *sb = spikes + (size_t)b * T * C;
         const int tau0 = cs + 16 - 4 * NK;
-        for (int e = tid; e < R * Cs; e += CV_THREADS) {
-            const int rho = e / Cs, c = e % Cs;
-            const int tau = tau0 + rho;
-            int8_t v = 0;
-            if (c < C && tau >= 0 && tau < T) v = sb[(size_t)tau * C + c];
-            spk[e] = v;
+        // all loads of a batch are issued (clamped addresses, hence unconditional) before the first LDS write, so
+        // the workgroup pays the memory latency once per batch instead of once per element
+        for (int e0 = tid; e0 < R * Cs; e0 += CV_THREADS * 8) {
+            int8_t v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int e = e0 + i * CV_THREADS;
+                const int rho = e / Cs, c = e % Cs;
+                int tau = tau0 + rho;
+                tau = tau < 0 ? 0 : (tau >= T ? T - 1 : tau);
+                v[i] = sb[(size_t)tau * C + (c < C ? c : C - 1)];
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int e = e0 + i * CV_THREADS;
+                const int rho = e / Cs, c = e % Cs;
+                const int tau = tau0 + rho;
+                if (e < R * Cs) spk[e] = (c < C && tau >= 0 && tau < T) ? v[i] : (int8_t)0;
+            }
         }
     }
     __syncthreads();

@@ -12,6 +12,8 @@
 // Arithmetic contract (== oracle/micloc_oracle.c oracle_stht): acc = +0; for taps k ascending:
 // acc = fma(ker[k], x[t-k], acc); exact-zero taps contribute nothing (skipped when every second tap
 // is zero, which is the case for every even-length Hilbert kernel).
+#include <stdlib.h>
+
 #include "micloc_internal.h"
 
 namespace micloc {
@@ -167,6 +169,9 @@ hipError_t launch_stht(const SthtTaps &tp, const double *x, double *h, int B, in
     const int MB = M < STHT_MAX_MB ? M : STHT_MAX_MB;
     const int rowstride = stht_rowstride(tp);
     const size_t lds = (size_t)MB * rowstride * sizeof(double);
+    SthtTaps tpx = tp;
+    if (const char *e = getenv("MICLOC_STHT_NGROUPS")) tpx.ngroups = atoi(e);  // experiment knob (wrong results)
+    const SthtTaps &tp2 = tpx;
     dim3 grid((T + STHT_TILE - 1) / STHT_TILE, (M + MB - 1) / MB, B);
     dim3 block(64 * MB);
     if (tp.kstep == 2) {
@@ -177,7 +182,7 @@ hipError_t launch_stht(const SthtTaps &tp, const double *x, double *h, int B, in
             if (e != hipSuccess) return e;
             attr2 = true;
         }
-        hipLaunchKernelGGL(stht_kernel<2>, grid, block, lds, stream, x, h, tp.taps, tp.ngroups, tp.klo, tp.halo,
+        hipLaunchKernelGGL(stht_kernel<2>, grid, block, lds, stream, x, h, tp.taps, tp2.ngroups, tp.klo, tp.halo,
                            tp.shift, T, M, Ts, MB, rowstride);
     } else {
         static bool attr1 = false;
@@ -187,7 +192,7 @@ hipError_t launch_stht(const SthtTaps &tp, const double *x, double *h, int B, in
             if (e != hipSuccess) return e;
             attr1 = true;
         }
-        hipLaunchKernelGGL(stht_kernel<1>, grid, block, lds, stream, x, h, tp.taps, tp.ngroups, tp.klo, tp.halo,
+        hipLaunchKernelGGL(stht_kernel<1>, grid, block, lds, stream, x, h, tp.taps, tp2.ngroups, tp.klo, tp.halo,
                            tp.shift, T, M, Ts, MB, rowstride);
     }
     return hipGetLastError();
