@@ -369,9 +369,10 @@ int micloc_snn_pipeline_f64(const micloc_plan *p, const double *x, int B, int T,
     int8_t *spk = spikes ? spikes : reinterpret_cast<int8_t *>(base + w.spikes);
     const int Ts = micloc_padded_T(T);
     hipStream_t st = (hipStream_t)stream;
-    HIP_TRY(launch_stht(p->taps, x, h, B, T, p->M, Ts, st));
+    // the in-phase channels are the rolled input frames: the band-pass kernel reads them from x directly
+    HIP_TRY(launch_stht(p->taps, x, h, B, T, p->M, Ts, st, false));
     HIP_TRY(launch_bandpass_rzcc(p->iir, h, B * p->C, p->C, T, Ts, p->robust_width, p->bipolar, nullptr, spk,
-                                 base + w.scratch, st));
+                                 base + w.scratch, st, x, p->M, p->taps.shift));
     if (want_bf) {
         const int Gp = 16 * p->W.GT;
         const bool want_power = power || argmax;
@@ -396,9 +397,9 @@ int micloc_beamformer_pipeline_f64(const micloc_plan *p, const double *x, int B,
     double *pre = reinterpret_cast<double *>(base + w.pre);
     const int Ts = micloc_padded_T(T);
     hipStream_t st = (hipStream_t)stream;
-    HIP_TRY(launch_stht(p->taps, x, h, B, T, p->M, Ts, st));
+    HIP_TRY(launch_stht(p->taps, x, h, B, T, p->M, Ts, st, false));
     HIP_TRY(launch_bandpass_rzcc(p->iir, h, B * p->C, p->C, T, Ts, p->robust_width, p->bipolar, pre, nullptr,
-                                 nullptr, st));
+                                 nullptr, st, x, p->M, p->taps.shift));
     const int Gp = 16 * p->W.GT;
     const bool want_power = power || argmax;
     double *partial = want_power ? reinterpret_cast<double *>(base + w.partial) : nullptr;
@@ -503,9 +504,10 @@ int micloc_snn_pipeline_cov_f64(const micloc_plan *p, const double *x, int B, in
     int8_t *spk = spikes ? spikes : reinterpret_cast<int8_t *>(base + w.spikes);
     const int Ts = micloc_padded_T(T);
     hipStream_t st = (hipStream_t)stream;
-    HIP_TRY(launch_stht(p->taps, x, h, B, T, p->M, Ts, st));
+    // the in-phase channels are the rolled input frames: the band-pass kernel reads them from x directly
+    HIP_TRY(launch_stht(p->taps, x, h, B, T, p->M, Ts, st, false));
     HIP_TRY(launch_bandpass_rzcc(p->iir, h, B * p->C, p->C, T, Ts, p->robust_width, p->bipolar, nullptr, spk,
-                                 base + w.scratch, st));
+                                 base + w.scratch, st, x, p->M, p->taps.shift));
     double *partial = reinterpret_cast<double *>(base + w.partial);
     HIP_TRY(launch_lif_cov(p->ntab, spk, B, T, p->C, CT, t_start, partial, st));
     HIP_TRY(launch_cov_power(partial, B, T, CT, p->C, T - t_start, want_power ? p->W.Wp : nullptr,

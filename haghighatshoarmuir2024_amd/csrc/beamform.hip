@@ -62,7 +62,6 @@ __global__ __launch_bounds__(BF_THREADS) void beamform_kernel(const int8_t *__re
                                                                double *__restrict__ partial)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int Kp = 16 * CT;
     constexpr int Cs = 16 * CT;  // padded spike row (bytes)
     constexpr int KS = 4 * CT;   // beamforming k-steps
     const int Gp = 16 * GT;

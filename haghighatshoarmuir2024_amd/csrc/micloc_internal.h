@@ -23,7 +23,7 @@ struct SthtTaps {
 };
 
 hipError_t launch_stht(const SthtTaps &tp, const double *x, double *h, int B, int T, int M, int Ts,
-                       hipStream_t stream);
+                       hipStream_t stream, bool write_re = true);
 size_t stht_lds_bytes(const SthtTaps &tp, int M);
 
 // ---- band-pass + RZCC ---------------------------------------------------------------------------
@@ -37,7 +37,7 @@ struct IirCoef {
 size_t rzcc_scratch_bytes(int nlanes, int T);
 hipError_t launch_bandpass_rzcc(const IirCoef &coef, const double *h, int nlanes, int C, int T, int Ts,
                                 int robust_width, int bipolar, double *pre, int8_t *spikes, void *scratch,
-                                hipStream_t stream);
+                                hipStream_t stream, const double *xin = nullptr, int M = 0, int shift = 0);
 // row-major [B][T][C] <-> planar [B][C][Ts]
 hipError_t launch_pack_planar(const double *src, double *dst, int B, int T, int C, int Ts, hipStream_t stream);
 hipError_t launch_unpack_planar(const double *src, double *dst, int B, int T, int C, int Ts, hipStream_t stream);

@@ -121,7 +121,8 @@ __global__ __launch_bounds__(256) void bandpass_rzcc_fast_kernel(const double *_
                                                                   int8_t *__restrict__ spikes,
                                                                   int *__restrict__ flag_count,
                                                                   int *__restrict__ flag_list, IirCoef coef,
-                                                                  int nlanes, int C, int T, int Ts, int w, int bipolar)
+                                                                  int nlanes, int C, int T, int Ts, int w, int bipolar,
+                                                                  const double *__restrict__ xin, int M, int shift)
 {
     __shared__ __attribute__((aligned(16))) double X[3][RZ_MT][RZ_ROW];
     __shared__ double Y[WANT_PRE ? 2 : 1][WANT_PRE ? RZ_MT : 1][WANT_PRE ? RZ_ROW : 1];
@@ -143,21 +144,27 @@ __global__ __launch_bounds__(256) void bandpass_rzcc_fast_kernel(const double *_
         const int sq = lane >> 4;  // stream slot 0..3 of each group of four
         const bool full_block = base + 64 <= nlanes;
         double v[16];
+        // Per-stream source.  Quadrature channels (and everything when xin == nullptr) come from the planar STHT
+        // buffer h; with xin != nullptr the in-phase channels c < M are read straight from the input frames,
+        // x[b][(t - L/2) mod T][c]  (np.roll, snn_beamformer.py:325), so the STHT kernel need not write them.
+        const double *pb[16];
+        bool rolled[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            int g = base + 4 * j + sq;
+            g = g < nlanes ? g : nlanes - 1;
+            const int bb = g / C, cc = g - bb * C;
+            rolled[j] = xin != nullptr && cc < M;
+            pb[j] = rolled[j] ? xin + (size_t)bb * T * M + cc : h + (size_t)g * Ts;
+        }
+        const int sh = shift % T;
         auto issue_loads = [&](int m) {
-            int t = m * RZ_MT + tl;
-            t = t < Ts ? t : Ts - 1;  // clamp: samples past T are never used
-            if (full_block) {
-                const double *p = h + (size_t)(base + sq) * Ts + t;
+            const int t = m * RZ_MT + tl;
+            const int tc = t < Ts ? t : Ts - 1;  // clamp: samples past T are never used
+            int tr = (t < T ? t : T - 1) - sh;
+            tr = tr < 0 ? tr + T : tr;
 #pragma unroll
-                for (int j = 0; j < 16; ++j) v[j] = p[(size_t)(4 * j) * Ts];
-            } else {
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    int g = base + 4 * j + sq;
-                    g = g < nlanes ? g : nlanes - 1;
-                    v[j] = h[(size_t)g * Ts + t];
-                }
-            }
+            for (int j = 0; j < 16; ++j) v[j] = rolled[j] ? pb[j][(size_t)tr * M] : pb[j][tc];
         };
         auto write_tile = [&](int buf) {
 #pragma unroll
@@ -338,12 +345,17 @@ __global__ __launch_bounds__(64) void rzcc_fallback_kernel(const double *__restr
                                                             const int *__restrict__ flag_count,
                                                             const int *__restrict__ flag_list, int *__restrict__ plist,
                                                             double *__restrict__ vlist, IirCoef coef, int nlanes,
-                                                            int C, int T, int Ts, int w, int bipolar)
+                                                            int C, int T, int Ts, int w, int bipolar,
+                                                            const double *__restrict__ xin, int M, int shift)
 {
     const int idx = blockIdx.x * 64 + threadIdx.x;
     if (idx >= *flag_count) return;
     const int lane_g = flag_list[idx];
-    const double *src = h + (size_t)lane_g * Ts;
+    const int b = lane_g / C;
+    const int ch = lane_g - b * C;
+    const bool rolled = xin != nullptr && ch < M;
+    const double *src = rolled ? xin + (size_t)b * T * M + ch : h + (size_t)lane_g * Ts;
+    const int sh = shift % T;
     const size_t NL = (size_t)nlanes;
     int *P = plist + idx;
     double *V = vlist + idx;
@@ -353,7 +365,9 @@ __global__ __launch_bounds__(64) void rzcc_fallback_kernel(const double *__restr
     double c = 0.0, prev = __builtin_nan("");
     int left = 0, dir = 0, n = 0;
     for (int t = 0; t < T; ++t) {
-        const double y = iir.step(coef, src[t]);
+        int tr = t - sh;
+        tr = tr < 0 ? tr + T : tr;
+        const double y = iir.step(coef, rolled ? src[(size_t)tr * M] : src[t]);
         c = c + y;
         const bool rise = c > prev;
         const bool fall = c < prev;
@@ -367,8 +381,6 @@ __global__ __launch_bounds__(64) void rzcc_fallback_kernel(const double *__restr
         prev = c;
     }
 
-    const int b = lane_g / C;
-    const int ch = lane_g - b * C;
     int8_t *sp = spikes + (size_t)b * T * C + ch;
     const int stride = bipolar ? 2 : 1;
     auto word_at = [&](int i) { return P + (size_t)i * NL; };
@@ -414,26 +426,26 @@ size_t rzcc_scratch_bytes(int nlanes, int T)
 template <int N>
 static void launch_rz(const IirCoef &coef, const double *h, int nlanes, int C, int T, int Ts, int w, int bipolar,
                       double *pre, int8_t *spikes, int *flag_count, int *flag_list, int *plist, double *vlist,
-                      hipStream_t stream)
+                      const double *xin, int M, int shift, hipStream_t stream)
 {
     dim3 grid((nlanes + 63) / 64), block(spikes ? 256 : 128);
     if (pre && spikes)
         hipLaunchKernelGGL((bandpass_rzcc_fast_kernel<N, true, true>), grid, block, 0, stream, h, pre, spikes,
-                           flag_count, flag_list, coef, nlanes, C, T, Ts, w, bipolar);
+                           flag_count, flag_list, coef, nlanes, C, T, Ts, w, bipolar, xin, M, shift);
     else if (spikes)
         hipLaunchKernelGGL((bandpass_rzcc_fast_kernel<N, false, true>), grid, block, 0, stream, h, pre, spikes,
-                           flag_count, flag_list, coef, nlanes, C, T, Ts, w, bipolar);
+                           flag_count, flag_list, coef, nlanes, C, T, Ts, w, bipolar, xin, M, shift);
     else
         hipLaunchKernelGGL((bandpass_rzcc_fast_kernel<N, true, false>), grid, block, 0, stream, h, pre, spikes,
-                           flag_count, flag_list, coef, nlanes, C, T, Ts, w, bipolar);
+                           flag_count, flag_list, coef, nlanes, C, T, Ts, w, bipolar, xin, M, shift);
     if (spikes)
         hipLaunchKernelGGL((rzcc_fallback_kernel<N>), grid, dim3(64), 0, stream, h, spikes, flag_count, flag_list,
-                           plist, vlist, coef, nlanes, C, T, Ts, w, bipolar);
+                           plist, vlist, coef, nlanes, C, T, Ts, w, bipolar, xin, M, shift);
 }
 
 hipError_t launch_bandpass_rzcc(const IirCoef &coef, const double *h, int nlanes, int C, int T, int Ts,
                                 int robust_width, int bipolar, double *pre, int8_t *spikes, void *scratch,
-                                hipStream_t stream)
+                                hipStream_t stream, const double *xin, int M, int shift)
 {
     if (!pre && !spikes) return hipErrorInvalidValue;
     int *flag_count = nullptr, *flag_list = nullptr, *plist = nullptr;
@@ -452,7 +464,7 @@ hipError_t launch_bandpass_rzcc(const IirCoef &coef, const double *h, int nlanes
 #define RZ_CASE(NN)                                                                                       \
     case NN:                                                                                              \
         launch_rz<NN>(coef, h, nlanes, C, T, Ts, robust_width, bipolar, pre, spikes, flag_count, flag_list, \
-                      plist, vlist, stream);                                                              \
+                      plist, vlist, xin, M, shift, stream);                                               \
         break;
     switch (coef.n) {
         RZ_CASE(1)

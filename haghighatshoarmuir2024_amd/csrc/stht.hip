@@ -20,7 +20,7 @@ namespace micloc {
 
 __device__ __forceinline__ int skew(int q) { return q + 2 * (q >> 3); }
 
-template <int S>
+template <int S, bool WRITE_RE>
 __global__ __launch_bounds__(64 * STHT_MAX_MB) void stht_kernel(const double *__restrict__ x,
                                                                  double *__restrict__ h,
                                                                  const double *__restrict__ taps, int ngroups,
@@ -124,6 +124,8 @@ __global__ __launch_bounds__(64 * STHT_MAX_MB) void stht_kernel(const double *__
     }
 
     // ---- in-phase: np.roll(x, shift, axis=0) --------------------------------------------------------
+    // (skipped in the fused pipelines: the band-pass kernel's loader reads the rolled input frames itself)
+    if (!WRITE_RE) return;
     const int sh = shift % T;
     double re[8];
 #pragma unroll
@@ -164,7 +166,7 @@ size_t stht_lds_bytes(const SthtTaps &tp, int M)
 }
 
 hipError_t launch_stht(const SthtTaps &tp, const double *x, double *h, int B, int T, int M, int Ts,
-                       hipStream_t stream)
+                       hipStream_t stream, bool write_re)
 {
     const int MB = M < STHT_MAX_MB ? M : STHT_MAX_MB;
     const int rowstride = stht_rowstride(tp);
@@ -174,27 +176,27 @@ hipError_t launch_stht(const SthtTaps &tp, const double *x, double *h, int B, in
     const SthtTaps &tp2 = tpx;
     dim3 grid((T + STHT_TILE - 1) / STHT_TILE, (M + MB - 1) / MB, B);
     dim3 block(64 * MB);
+#define STHT_LAUNCH(SS, WR)                                                                                        \
+    do {                                                                                                           \
+        auto k = &stht_kernel<SS, WR>;                                                                             \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),                                      \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                \
+        if (e != hipSuccess) return e;                                                                             \
+        hipLaunchKernelGGL(k, grid, block, lds, stream, x, h, tp.taps, tp2.ngroups, tp.klo, tp.halo, tp.shift, T,  \
+                           M, Ts, MB, rowstride);                                                                  \
+    } while (0)
     if (tp.kstep == 2) {
-        static bool attr2 = false;
-        if (!attr2) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&stht_kernel<2>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) return e;
-            attr2 = true;
-        }
-        hipLaunchKernelGGL(stht_kernel<2>, grid, block, lds, stream, x, h, tp.taps, tp2.ngroups, tp.klo, tp.halo,
-                           tp.shift, T, M, Ts, MB, rowstride);
+        if (write_re)
+            STHT_LAUNCH(2, true);
+        else
+            STHT_LAUNCH(2, false);
     } else {
-        static bool attr1 = false;
-        if (!attr1) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&stht_kernel<1>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) return e;
-            attr1 = true;
-        }
-        hipLaunchKernelGGL(stht_kernel<1>, grid, block, lds, stream, x, h, tp.taps, tp2.ngroups, tp.klo, tp.halo,
-                           tp.shift, T, M, Ts, MB, rowstride);
+        if (write_re)
+            STHT_LAUNCH(1, true);
+        else
+            STHT_LAUNCH(1, false);
     }
+#undef STHT_LAUNCH
     return hipGetLastError();
 }
 
