@@ -19,8 +19,6 @@
 //
 // Summation order (== oracle): LIF over past samples in chronological order (tau ascending),
 // beamforming over channels ascending; both as fused multiply-add chains starting from +0.
-#include <stdlib.h>
-
 #include "micloc_internal.h"
 
 namespace micloc {
@@ -309,7 +307,6 @@ static hipError_t launch_bf(const BeamformW &W, const NeuronTab *nt, const int8_
         lds = lds > tile ? lds : tile;  // red aliases the nir table + spike tile
     }
     lds = (lds + 15) & ~(size_t)15;
-    if (const char *pad = getenv("MICLOC_BF_LDS_PAD")) lds += (size_t)atoi(pad) * 1024;  // experiment knob
     const size_t wbytes = (size_t)(W.C + 1) * Gp * sizeof(double);
     (void)Kp;
     const bool w_lds = (lds + wbytes) <= 150 * 1024 && wbytes <= 96 * 1024;

@@ -12,8 +12,6 @@
 // Arithmetic contract (== oracle/micloc_oracle.c oracle_stht): acc = +0; for taps k ascending:
 // acc = fma(ker[k], x[t-k], acc); exact-zero taps contribute nothing (skipped when every second tap
 // is zero, which is the case for every even-length Hilbert kernel).
-#include <stdlib.h>
-
 #include "micloc_internal.h"
 
 namespace micloc {
@@ -171,9 +169,6 @@ hipError_t launch_stht(const SthtTaps &tp, const double *x, double *h, int B, in
     const int MB = M < STHT_MAX_MB ? M : STHT_MAX_MB;
     const int rowstride = stht_rowstride(tp);
     const size_t lds = (size_t)MB * rowstride * sizeof(double);
-    SthtTaps tpx = tp;
-    if (const char *e = getenv("MICLOC_STHT_NGROUPS")) tpx.ngroups = atoi(e);  // experiment knob (wrong results)
-    const SthtTaps &tp2 = tpx;
     dim3 grid((T + STHT_TILE - 1) / STHT_TILE, (M + MB - 1) / MB, B);
     dim3 block(64 * MB);
 #define STHT_LAUNCH(SS, WR)                                                                                        \
@@ -182,7 +177,7 @@ hipError_t launch_stht(const SthtTaps &tp, const double *x, double *h, int B, in
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),                                      \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                \
         if (e != hipSuccess) return e;                                                                             \
-        hipLaunchKernelGGL(k, grid, block, lds, stream, x, h, tp.taps, tp2.ngroups, tp.klo, tp.halo, tp.shift, T,  \
+        hipLaunchKernelGGL(k, grid, block, lds, stream, x, h, tp.taps, tp.ngroups, tp.klo, tp.halo, tp.shift, T,  \
                            M, Ts, MB, rowstride);                                                                  \
     } while (0)
     if (tp.kstep == 2) {
