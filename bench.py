@@ -25,6 +25,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# HBM bytes per launch of the dominant kernel for the DEFAULT workload (1100 trials, T=4799, G=360), from separate
+# rocprofv3 --pmc passes (profiles/r1/pmc_summary.csv): 2 x FETCH_SIZE (gfx950 counts wide reads at half,
+# MI355X_MICROARCH.md "HBM") + WRITE_SIZE, both reported in KiB: 2 * 52798 + 31625 KiB.
+BEAMFORM_TRAFFIC_BYTES_DEFAULT = (2 * 52798 + 31625) * 1024
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X datasheet fp64 matrix = fp64 vector = 1/2 of the 157.3 TF fp32 rate in MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
 
@@ -247,8 +251,11 @@ def main():
                         traffic=args.traffic_bytes)
         else:
             achieved = frames_launch * flops[dom] / (st[dom] * 1e-3) / 1e12
+            traffic = args.traffic_bytes
+            if traffic is None and dom == "beamform_kernel" and (B, T, M, G) == (1100, 4799, 7, 360):
+                traffic = float(BEAMFORM_TRAFFIC_BYTES_DEFAULT)
             roof = dict(kernel=dom, bound="mfma", achieved=achieved, peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
-                        frac=achieved / FP64_MFMA_PEAK_TFLOPS, traffic=args.traffic_bytes)
+                        frac=achieved / FP64_MFMA_PEAK_TFLOPS, traffic=traffic)
         roof["avg_launch_ms"] = st[dom]
         roof["stages_ms"] = st
         result = {
