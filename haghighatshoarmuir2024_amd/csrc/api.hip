@@ -262,7 +262,8 @@ int micloc_plan_set_bf_mat(micloc_plan *p, const double *W, int C, int G)
     if (C != p->C) return MICLOC_ERR_SHAPE;
     const int CT = pad_ct(C);
     if (CT > 8) return MICLOC_ERR_INVALID;
-    const int GT = (G + 15) / 16;
+    int GT = (G + 15) / 16;
+    if (CT > 4) GT = (GT + 1) & ~1;  // the many-channel kernel streams bf_mat in slabs of two DoA tiles
     const int Gp = 16 * GT;
     std::vector<double> Wp((size_t)16 * CT * Gp, 0.0);
     for (int c = 0; c < C; ++c)
@@ -277,7 +278,7 @@ int micloc_plan_set_bf_mat_c128(micloc_plan *p, const double *Wre, const double 
     const int C = 2 * M;
     const int CT = pad_ct(C);
     if (CT > 8) return MICLOC_ERR_INVALID;
-    const int Ghp = 16 * ((G + 15) / 16);
+    const int Ghp = 16 * ((G + 15) / 16);  // Gp / 16 is even by construction
     const int Gp = 2 * Ghp;
     // (hr + j hi)(wr - j wi):  re = [hr hi] . [wr; wi]   im = [hr hi] . [-wi; wr]
     std::vector<double> Wp((size_t)16 * CT * Gp, 0.0);
@@ -331,7 +332,7 @@ int micloc_lif_beamform_f64(const micloc_plan *p, const int8_t *spikes, int B, i
     double *partial = want_power ? reinterpret_cast<double *>(ws) : nullptr;
     HIP_TRY(launch_lif_beamform(p->W, p->ntab, spikes, B, T, y, partial, (hipStream_t)stream));
     if (want_power)
-        HIP_TRY(launch_power_argmax(partial, B, T, beamform_nchunks(T), Gp, p->G_out, 0, 0, power, argmax,
+        HIP_TRY(launch_power_argmax(partial, B, T, beamform_nchunks_ct(T, p->W.CT), Gp, p->G_out, 0, 0, power, argmax,
                                     (hipStream_t)stream));
     return MICLOC_OK;
 }
@@ -349,7 +350,7 @@ int micloc_beamform_c128_f64(const micloc_plan *p, const double *pre, int B, int
     double *partial = want_power ? reinterpret_cast<double *>(ws) : nullptr;
     HIP_TRY(launch_planar_beamform(p->W, pre, B, T, Ts, y, 1, partial, (hipStream_t)stream));
     if (want_power)
-        HIP_TRY(launch_power_argmax(partial, B, T, beamform_nchunks(T), Gp, p->G_out, 1, Gp / 2, power, argmax,
+        HIP_TRY(launch_power_argmax(partial, B, T, beamform_nchunks_ct(T, p->W.CT), Gp, p->G_out, 1, Gp / 2, power, argmax,
                                     (hipStream_t)stream));
     return MICLOC_OK;
 }
@@ -379,7 +380,7 @@ int micloc_snn_pipeline_f64(const micloc_plan *p, const double *x, int B, int T,
         double *partial = want_power ? reinterpret_cast<double *>(base + w.partial) : nullptr;
         HIP_TRY(launch_lif_beamform(p->W, p->ntab, spk, B, T, y, partial, st));
         if (want_power)
-            HIP_TRY(launch_power_argmax(partial, B, T, beamform_nchunks(T), Gp, p->G_out, 0, 0, power, argmax, st));
+            HIP_TRY(launch_power_argmax(partial, B, T, beamform_nchunks_ct(T, p->W.CT), Gp, p->G_out, 0, 0, power, argmax, st));
     }
     return MICLOC_OK;
 }
@@ -405,7 +406,7 @@ int micloc_beamformer_pipeline_f64(const micloc_plan *p, const double *x, int B,
     double *partial = want_power ? reinterpret_cast<double *>(base + w.partial) : nullptr;
     HIP_TRY(launch_planar_beamform(p->W, pre, B, T, Ts, y, 1, partial, st));
     if (want_power)
-        HIP_TRY(launch_power_argmax(partial, B, T, beamform_nchunks(T), Gp, p->G_out, 1, Gp / 2, power, argmax, st));
+        HIP_TRY(launch_power_argmax(partial, B, T, beamform_nchunks_ct(T, p->W.CT), Gp, p->G_out, 1, Gp / 2, power, argmax, st));
     return MICLOC_OK;
 }
 

@@ -46,9 +46,18 @@ __device__ __forceinline__ double row_sum4(double x)
 
 int beamform_nchunks(int T) { return (T + BF_CHUNK - 1) / BF_CHUNK; }
 
+// more than 64 channels: the slab kernel below works on 256-frame chunks
+constexpr int SL_NT = 2;                          // 16-frame tiles per wave
+constexpr int SL_CHUNK = BF_WAVES * SL_NT * 16;   // 256 frames per workgroup
+constexpr int SL_COLS = 32;                       // DoA columns per W slab (two 16-column tiles)
+constexpr int SL_ROW = 48;                        // padded slab row (doubles): 384 B keeps q = 0/1 on disjoint banks
+
+int beamform_nchunks_ct(int T, int CT) { return CT > 4 ? (T + SL_CHUNK - 1) / SL_CHUNK : beamform_nchunks(T); }
+
 size_t beamform_partial_bytes(int B, int T, int Gp)
 {
-    return ((size_t)B * beamform_nchunks(T) * Gp * sizeof(double) + 255) & ~(size_t)255;
+    // sized for the finer (256-frame) chunking of the slab kernel, which is an upper bound for both families
+    return ((size_t)B * ((T + SL_CHUNK - 1) / SL_CHUNK) * Gp * sizeof(double) + 255) & ~(size_t)255;
 }
 
 template <int CT, bool SRC_SPIKES, bool W_LDS, bool WANT_Y>
@@ -294,6 +303,244 @@ __global__ __launch_bounds__(BF_THREADS) void beamform_kernel(const int8_t *__re
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Many-channel variant (C > 64, e.g. the 64-microphone stress configuration): bf_mat no longer fits in LDS and the
+// membrane fragments of 4 time tiles no longer fit in registers.  Workgroup = 8 waves x 2 time tiles (256 frames);
+// the membrane fragments stay in registers (2 x CT x 4 doubles per lane), bf_mat is streamed through LDS in
+// double-buffered slabs of 32 DoA columns shared by the 8 waves (each byte leaves L2 once per workgroup), and the
+// per-slab column sums are combined across waves right away, so no G-sized reduction buffer is needed.
+// ---------------------------------------------------------------------------------------------------------------
+template <int CT, bool SRC_SPIKES, bool WANT_Y>
+__global__ __launch_bounds__(BF_THREADS, 2) void beamform_slab_kernel(const int8_t *__restrict__ spikes,
+                                                                      const double *__restrict__ pre,
+                                                                      const double *__restrict__ ntab_g, int NK,
+                                                                      const double *__restrict__ Wp, int GT, int C, int G,
+                                                                      int T, int Ts, double *__restrict__ y, int y_complex,
+                                                                      double *__restrict__ partial)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int Kp = 16 * CT;
+    constexpr int Cs = 16 * CT;
+    constexpr int KS = 4 * CT;
+    const int Gp = 16 * GT;  // even number of tiles (host pads)
+    const int NSL = GT / 2;
+    const int tid = threadIdx.x;
+    const int wv = tid >> 6;
+    const int l = tid & 63;
+    const int lc = l & 15;
+    const int q = l >> 4;
+    const int chunk = blockIdx.x;
+    const int nchunks = gridDim.x;
+    const int b = blockIdx.y;
+    const int cs = chunk * SL_CHUNK;
+
+    double *slab = reinterpret_cast<double *>(smem);                 // [2][Kp][SL_ROW]
+    double *red = slab + (size_t)2 * Kp * SL_ROW;                    // [2][BF_WAVES][SL_COLS]
+    double *ntab = red + 2 * BF_WAVES * SL_COLS;
+    const int ntab_len = SRC_SPIKES ? 4 * NK + 16 : 0;
+    int8_t *spk = reinterpret_cast<int8_t *>(ntab + ntab_len);
+    const int R = SL_CHUNK + 4 * NK - 16;
+
+    // slab loads: Kp rows x 32 columns = Kp * 16 double2; 512 threads -> Kp / 32 double2 each
+    constexpr int NV = (Kp * (SL_COLS / 2) + BF_THREADS - 1) / BF_THREADS;
+    double2 wreg[NV];
+    auto issue_slab = [&](int sl) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int e = tid + i * BF_THREADS;  // double2 index: row = e / 16, pair = e % 16
+            const int row = e >> 4, pr = e & 15;
+            const int rr = row < Kp ? row : Kp - 1;
+            wreg[i] = *reinterpret_cast<const double2 *>(Wp + (size_t)rr * Gp + SL_COLS * sl + 2 * pr);
+        }
+    };
+    auto write_slab = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int e = tid + i * BF_THREADS;
+            const int row = e >> 4, pr = e & 15;
+            if (row < Kp) *reinterpret_cast<double2 *>(slab + ((size_t)buf * Kp + row) * SL_ROW + 2 * pr) = wreg[i];
+        }
+    };
+
+    issue_slab(0);
+    if (SRC_SPIKES) {
+        for (int e = tid; e < ntab_len; e += BF_THREADS) ntab[e] = ntab_g[e];
+        const int8_t *sb = spikes + (size_t)b * T * C;
+        const int tau0 = cs + 16 - 4 * NK;
+        for (int e0 = tid; e0 < R * Cs; e0 += BF_THREADS * 8) {
+            int8_t v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int e = e0 + i * BF_THREADS;
+                const int rho = e / Cs, c = e % Cs;
+                int tau = tau0 + rho;
+                tau = tau < 0 ? 0 : (tau >= T ? T - 1 : tau);
+                v[i] = sb[(size_t)tau * C + (c < C ? c : C - 1)];
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int e = e0 + i * BF_THREADS;
+                const int rho = e / Cs, c = e % Cs;
+                const int tau = tau0 + rho;
+                if (e < R * Cs) spk[e] = (c < C && tau >= 0 && tau < T) ? v[i] : (int8_t)0;
+            }
+        }
+    }
+    write_slab(0);
+    if (NSL > 1) issue_slab(1);
+    __syncthreads();
+
+    // ---- membrane fragments for the 2 time tiles of this wave ----
+    const int tb0 = cs + wv * SL_NT * 16;
+    double4_t Vf[SL_NT][CT];
+    if (SRC_SPIKES) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            double4_t acc[SL_NT];
+#pragma unroll
+            for (int tt = 0; tt < SL_NT; ++tt) acc[tt] = double4_t{0.0, 0.0, 0.0, 0.0};
+            if (tb0 < T) {
+                const int8_t *sp = spk + (size_t)(tb0 - cs + q) * Cs + 16 * ct + lc;
+                const double *np_ = ntab + (lc - q + 4 * NK - 16 + 15);
+                double bn_n = np_[0];
+                int an[SL_NT];
+#pragma unroll
+                for (int tt = 0; tt < SL_NT; ++tt) an[tt] = sp[(size_t)(16 * tt) * Cs];
+                for (int ks = 0; ks < NK; ++ks) {
+                    const double bn = bn_n;
+                    double a[SL_NT];
+#pragma unroll
+                    for (int tt = 0; tt < SL_NT; ++tt) a[tt] = (double)an[tt];
+                    if (ks + 1 < NK) {
+                        bn_n = np_[-4 * (ks + 1)];
+#pragma unroll
+                        for (int tt = 0; tt < SL_NT; ++tt) an[tt] = sp[(size_t)(16 * tt + 4 * (ks + 1)) * Cs];
+                    }
+#pragma unroll
+                    for (int tt = 0; tt < SL_NT; ++tt)
+                        acc[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tt], bn, acc[tt], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int tt = 0; tt < SL_NT; ++tt) {
+                const bool tvalid = (tb0 + 16 * tt + lc) < T;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[tt][r] = tvalid ? acc[tt][r] : 0.0;
+                Vf[tt][ct] = acc[tt];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int tt = 0; tt < SL_NT; ++tt) {
+            const int tb = tb0 + 16 * tt;
+            const bool tvalid = (tb + lc) < T;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                double4_t acc;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int c = 16 * ct + 4 * r + q;
+                    double v = 0.0;
+                    if (tvalid && c < C) v = pre[((size_t)b * C + c) * Ts + tb + lc];
+                    acc[r] = v;
+                }
+                Vf[tt][ct] = acc;
+            }
+        }
+    }
+
+    const int Ghp = Gp >> 1;
+    double *pout = partial ? partial + ((size_t)b * nchunks + chunk) * Gp : nullptr;
+    for (int sl = 0; sl < NSL; ++sl) {
+        const int buf = sl & 1;
+        const double *sbuf = slab + (size_t)buf * Kp * SL_ROW;
+#pragma unroll
+        for (int gl = 0; gl < 2; ++gl) {
+            const int gt = 2 * sl + gl;
+            double4_t acc[SL_NT];
+#pragma unroll
+            for (int tt = 0; tt < SL_NT; ++tt) acc[tt] = double4_t{0.0, 0.0, 0.0, 0.0};
+            if (tb0 < T) {
+                const double *wp = sbuf + (size_t)q * SL_ROW + 16 * gl + lc;
+#pragma unroll
+                for (int k = 0; k < KS; ++k) {
+                    const double wk = wp[(size_t)(4 * k) * SL_ROW];
+#pragma unroll
+                    for (int tt = 0; tt < SL_NT; ++tt)
+                        acc[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(Vf[tt][k >> 2][k & 3], wk, acc[tt], 0, 0, 0);
+                }
+            }
+            double sq = 0.0;
+#pragma unroll
+            for (int tt = 0; tt < SL_NT; ++tt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sq = __builtin_fma(acc[tt][r], acc[tt][r], sq);
+            if (WANT_Y) {
+                const int gcol = 16 * gt + lc;
+#pragma unroll
+                for (int tt = 0; tt < SL_NT; ++tt) {
+                    const int tb = tb0 + 16 * tt;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int t = tb + q + 4 * r;
+                        if (t < T) {
+                            if (!y_complex) {
+                                if (gcol < G) y[((size_t)b * T + t) * G + gcol] = acc[tt][r];
+                            } else {
+                                const int part = gcol >= Ghp;
+                                const int g = gcol - (part ? Ghp : 0);
+                                if (g < (G >> 1)) y[(((size_t)b * T + t) * (G >> 1) + g) * 2 + part] = acc[tt][r];
+                            }
+                        }
+                    }
+                }
+            }
+            sq = row_sum4(sq);
+            if (l < 16) red[((size_t)buf * BF_WAVES + wv) * SL_COLS + 16 * gl + l] = sq;
+        }
+        if (sl + 1 < NSL) write_slab(buf ^ 1);  // registers hold slab sl+1 (issued one iteration ago)
+        if (sl + 2 < NSL) issue_slab(sl + 2);
+        __syncthreads();
+        if (pout && tid < SL_COLS) {
+            double s = 0.0;
+#pragma unroll
+            for (int w8 = 0; w8 < BF_WAVES; ++w8) s += red[((size_t)buf * BF_WAVES + w8) * SL_COLS + tid];
+            pout[SL_COLS * sl + tid] = s;
+        }
+    }
+}
+
+template <int CT, bool SRC_SPIKES>
+static hipError_t launch_slab(const BeamformW &W, const NeuronTab *nt, const int8_t *spikes, const double *pre, int B,
+                              int T, int Ts, double *y, int y_complex, double *partial, hipStream_t stream)
+{
+    if (W.GT & 1) return hipErrorInvalidValue;  // the host pads the DoA tiles to an even count for this kernel
+    const int NK = SRC_SPIKES ? nt->NK : 0;
+    size_t lds = (size_t)2 * 16 * CT * SL_ROW * sizeof(double) + (size_t)2 * BF_WAVES * SL_COLS * sizeof(double);
+    if (SRC_SPIKES) lds += (size_t)(4 * NK + 16) * sizeof(double) + (size_t)(SL_CHUNK + 4 * NK - 16) * 16 * CT;
+    lds = (lds + 15) & ~(size_t)15;
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    dim3 grid((T + SL_CHUNK - 1) / SL_CHUNK, B), block(BF_THREADS);
+    const double *tab = SRC_SPIKES ? nt->tab : nullptr;
+    hipError_t e;
+#define SL_LAUNCH(WY)                                                                                               \
+    do {                                                                                                            \
+        auto k = &beamform_slab_kernel<CT, SRC_SPIKES, WY>;                                                         \
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,      \
+                                160 * 1024);                                                                        \
+        if (e != hipSuccess) return e;                                                                              \
+        hipLaunchKernelGGL(k, grid, block, lds, stream, spikes, pre, tab, NK, W.Wp, W.GT, W.C, W.G, T, Ts, y,       \
+                           y_complex, partial);                                                                     \
+    } while (0)
+    if (y)
+        SL_LAUNCH(true);
+    else
+        SL_LAUNCH(false);
+#undef SL_LAUNCH
+    return hipGetLastError();
+}
+
 template <int CT, bool SRC_SPIKES>
 static hipError_t launch_bf(const BeamformW &W, const NeuronTab *nt, const int8_t *spikes, const double *pre, int B,
                             int T, int Ts, double *y, int y_complex, double *partial, hipStream_t stream)
@@ -347,7 +594,7 @@ static hipError_t dispatch_ct(const BeamformW &W, const NeuronTab *nt, const int
         case 2: return launch_bf<2, SRC_SPIKES>(W, nt, spikes, pre, B, T, Ts, y, y_complex, partial, stream);
         case 3: return launch_bf<3, SRC_SPIKES>(W, nt, spikes, pre, B, T, Ts, y, y_complex, partial, stream);
         case 4: return launch_bf<4, SRC_SPIKES>(W, nt, spikes, pre, B, T, Ts, y, y_complex, partial, stream);
-        case 8: return launch_bf<8, SRC_SPIKES>(W, nt, spikes, pre, B, T, Ts, y, y_complex, partial, stream);
+        case 8: return launch_slab<8, SRC_SPIKES>(W, nt, spikes, pre, B, T, Ts, y, y_complex, partial, stream);
         default: return hipErrorInvalidValue;
     }
 }

@@ -69,6 +69,7 @@ hipError_t launch_planar_beamform(const BeamformW &W, const double *pre, int B, 
 hipError_t launch_power_argmax(const double *partial, int B, int T, int nchunks, int Gp, int G, int complex_pairs,
                                int Ghalf_pad, double *power, int32_t *argmax, hipStream_t stream);
 int beamform_nchunks(int T);
+int beamform_nchunks_ct(int T, int CT);  // chunking of the kernel family that serves CT channel tiles
 
 // ---- covariance-form power / membrane covariance ------------------------------------------------------------
 size_t cov_partial_bytes(int B, int T, int CT);

@@ -312,3 +312,23 @@ def test_covariance_form_wide(torch):
         np.testing.assert_allclose(c["power"].cpu().numpy(), d["power"].cpu().numpy(), rtol=1e-11)
         ref = O.snn_chain(x[1], ker, b, a, O.robust_width(fs, 2000.0), True, nir, W, want=("vmem",))
         np.testing.assert_allclose(c["cov"][1].cpu().numpy(), ref["vmem"].T @ ref["vmem"] / T, rtol=1e-11, atol=1e-18)
+
+
+def test_many_mic_complex_beamformer(torch):
+    """Complex Beamformer with 40 mics (80 stacked channels -> the slab kernel with the planar source)."""
+    from haghighatshoarmuir2024_amd.runtime import Plan
+
+    fs, M, G, T = 48_000, 40, 21, 600
+    rng = np.random.RandomState(8)
+    ker = O.stht_kernel(fs, 10e-3)
+    b, a = O.bandpass(fs, [1000.0, 2000.0])
+    W = rng.randn(M, G) + 1j * rng.randn(M, G)
+    x = rng.randn(2, T, M)
+    p = Plan(M, ker, b, a, 1, False)
+    p.set_bf_mat(W)
+    out = p.beamformer_pipeline(p.to_device(x), want_y=True)
+    for i in range(2):
+        ref = O.beamformer_chain(x[i], ker, b, a, W)
+        np.testing.assert_allclose(out["y"][i].cpu().numpy(), ref["y"], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(out["power"][i].cpu().numpy(), ref["power"], rtol=1e-12)
+        assert int(out["argmax"][i]) == ref["argmax"]
