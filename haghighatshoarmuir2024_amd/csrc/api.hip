@@ -106,6 +106,9 @@ WsLayout ws_layout(const micloc_plan *p, int B, int T)
     return w;
 }
 
+// trials map to gridDim.y / gridDim.z, which HIP limits to 65535
+bool bad_batch(int B) { return B < 1 || B > 65535; }
+
 bool bad_ws(const void *ws, size_t have, size_t need)
 {
     return ws == nullptr || have < need || (reinterpret_cast<uintptr_t>(ws) & 255) != 0;
@@ -295,14 +298,14 @@ int micloc_plan_set_bf_mat_c128(micloc_plan *p, const double *Wre, const double 
 
 size_t micloc_workspace_bytes(const micloc_plan *p, int B, int T)
 {
-    if (!p || B < 1 || T < 1) return 0;
+    if (!p || bad_batch(B) || T < 1) return 0;
     return ws_layout(p, B, T).total;
 }
 
 // ---- stages ----------------------------------------------------------------------------------------------
 int micloc_stht_f64(const micloc_plan *p, const double *x, int B, int T, double *h, int Ts, void *stream)
 {
-    if (!p || !x || !h || B < 1 || T < 1) return MICLOC_ERR_INVALID;
+    if (!p || !x || !h || bad_batch(B) || T < 1) return MICLOC_ERR_INVALID;
     if (Ts != micloc_padded_T(T)) return MICLOC_ERR_SHAPE;
     HIP_TRY(launch_stht(p->taps, x, h, B, T, p->M, Ts, (hipStream_t)stream));
     return MICLOC_OK;
@@ -311,7 +314,7 @@ int micloc_stht_f64(const micloc_plan *p, const double *x, int B, int T, double 
 int micloc_bandpass_rzcc_f64(const micloc_plan *p, const double *h, int B, int T, int Ts, double *pre,
                              int8_t *spikes, void *ws, size_t ws_bytes, void *stream)
 {
-    if (!p || !h || B < 1 || T < 1 || (!pre && !spikes)) return MICLOC_ERR_INVALID;
+    if (!p || !h || bad_batch(B) || T < 1 || (!pre && !spikes)) return MICLOC_ERR_INVALID;
     if (Ts != micloc_padded_T(T)) return MICLOC_ERR_SHAPE;
     const int nl = B * p->C;
     if (spikes && bad_ws(ws, ws_bytes, rzcc_scratch_bytes(nl, T))) return MICLOC_ERR_WORKSPACE;
@@ -323,7 +326,7 @@ int micloc_bandpass_rzcc_f64(const micloc_plan *p, const double *h, int B, int T
 int micloc_lif_beamform_f64(const micloc_plan *p, const int8_t *spikes, int B, int T, double *y, double *power,
                             int32_t *argmax, void *ws, size_t ws_bytes, void *stream)
 {
-    if (!p || !spikes || B < 1 || T < 1 || (!y && !power && !argmax)) return MICLOC_ERR_INVALID;
+    if (!p || !spikes || bad_batch(B) || T < 1 || (!y && !power && !argmax)) return MICLOC_ERR_INVALID;
     if (!p->d_ntab || !p->d_W) return MICLOC_ERR_NOT_SET;
     if (p->W_is_complex) return MICLOC_ERR_SHAPE;
     const int Gp = 16 * p->W.GT;
@@ -340,7 +343,7 @@ int micloc_lif_beamform_f64(const micloc_plan *p, const int8_t *spikes, int B, i
 int micloc_beamform_c128_f64(const micloc_plan *p, const double *pre, int B, int T, int Ts, double *y, double *power,
                              int32_t *argmax, void *ws, size_t ws_bytes, void *stream)
 {
-    if (!p || !pre || B < 1 || T < 1 || (!y && !power && !argmax)) return MICLOC_ERR_INVALID;
+    if (!p || !pre || bad_batch(B) || T < 1 || (!y && !power && !argmax)) return MICLOC_ERR_INVALID;
     if (Ts != micloc_padded_T(T)) return MICLOC_ERR_SHAPE;
     if (!p->d_W) return MICLOC_ERR_NOT_SET;
     if (!p->W_is_complex) return MICLOC_ERR_SHAPE;
@@ -359,7 +362,7 @@ int micloc_beamform_c128_f64(const micloc_plan *p, const double *pre, int B, int
 int micloc_snn_pipeline_f64(const micloc_plan *p, const double *x, int B, int T, int8_t *spikes, double *y,
                             double *power, int32_t *argmax, void *ws, size_t ws_bytes, void *stream)
 {
-    if (!p || !x || B < 1 || T < 1 || (!spikes && !y && !power && !argmax)) return MICLOC_ERR_INVALID;
+    if (!p || !x || bad_batch(B) || T < 1 || (!spikes && !y && !power && !argmax)) return MICLOC_ERR_INVALID;
     const bool want_bf = y || power || argmax;
     if (want_bf && (!p->d_ntab || !p->d_W)) return MICLOC_ERR_NOT_SET;
     if (want_bf && p->W_is_complex) return MICLOC_ERR_SHAPE;
@@ -388,7 +391,7 @@ int micloc_snn_pipeline_f64(const micloc_plan *p, const double *x, int B, int T,
 int micloc_beamformer_pipeline_f64(const micloc_plan *p, const double *x, int B, int T, double *y, double *power,
                                    int32_t *argmax, void *ws, size_t ws_bytes, void *stream)
 {
-    if (!p || !x || B < 1 || T < 1 || (!y && !power && !argmax)) return MICLOC_ERR_INVALID;
+    if (!p || !x || bad_batch(B) || T < 1 || (!y && !power && !argmax)) return MICLOC_ERR_INVALID;
     if (!p->d_W) return MICLOC_ERR_NOT_SET;
     if (!p->W_is_complex) return MICLOC_ERR_SHAPE;
     const WsLayout w = ws_layout(p, B, T);
@@ -421,7 +424,7 @@ size_t micloc_rzcc_workspace_bytes(int B, int T, int C)
 int micloc_rzcc_encode_f64(const double *sig, int B, int T, int C, int robust_width, int bipolar, int8_t *spikes,
                            void *ws, size_t ws_bytes, void *stream)
 {
-    if (!sig || !spikes || B < 1 || T < 1 || C < 1 || robust_width < 1) return MICLOC_ERR_INVALID;
+    if (!sig || !spikes || bad_batch(B) || T < 1 || C < 1 || robust_width < 1) return MICLOC_ERR_INVALID;
     if (bad_ws(ws, ws_bytes, micloc_rzcc_workspace_bytes(B, T, C))) return MICLOC_ERR_WORKSPACE;
     const int Ts = micloc_padded_T(T);
     unsigned char *base = reinterpret_cast<unsigned char *>(ws);
@@ -447,7 +450,7 @@ size_t micloc_lfilter_workspace_bytes(int B, int T, int C)
 int micloc_lfilter_f64(const double *b, const double *a, int n, const double *x, int B, int T, int C, double *y,
                        void *ws, size_t ws_bytes, void *stream)
 {
-    if (!b || !a || !x || !y || n < 1 || n > MICLOC_MAX_IIR || B < 1 || T < 1 || C < 1 || a[0] == 0.0)
+    if (!b || !a || !x || !y || n < 1 || n > MICLOC_MAX_IIR || bad_batch(B) || T < 1 || C < 1 || a[0] == 0.0)
         return MICLOC_ERR_INVALID;
     if (bad_ws(ws, ws_bytes, micloc_lfilter_workspace_bytes(B, T, C))) return MICLOC_ERR_WORKSPACE;
     const int Ts = micloc_padded_T(T);
@@ -472,7 +475,7 @@ int micloc_lfilter_f64(const double *b, const double *a, int n, const double *x,
 int micloc_lif_covariance_f64(const micloc_plan *p, const int8_t *spikes, int B, int T, int t_start, double *cov,
                               double *power, int32_t *argmax, void *ws, size_t ws_bytes, void *stream)
 {
-    if (!p || !spikes || B < 1 || T < 1 || t_start < 0 || t_start >= T || (!cov && !power && !argmax))
+    if (!p || !spikes || bad_batch(B) || T < 1 || t_start < 0 || t_start >= T || (!cov && !power && !argmax))
         return MICLOC_ERR_INVALID;
     if (!p->d_ntab) return MICLOC_ERR_NOT_SET;
     const bool want_power = power || argmax;
@@ -491,7 +494,7 @@ int micloc_lif_covariance_f64(const micloc_plan *p, const int8_t *spikes, int B,
 int micloc_snn_pipeline_cov_f64(const micloc_plan *p, const double *x, int B, int T, int t_start, int8_t *spikes,
                                 double *cov, double *power, int32_t *argmax, void *ws, size_t ws_bytes, void *stream)
 {
-    if (!p || !x || B < 1 || T < 1 || t_start < 0 || t_start >= T || (!cov && !power && !argmax))
+    if (!p || !x || bad_batch(B) || T < 1 || t_start < 0 || t_start >= T || (!cov && !power && !argmax))
         return MICLOC_ERR_INVALID;
     if (!p->d_ntab) return MICLOC_ERR_NOT_SET;
     const bool want_power = power || argmax;
@@ -520,7 +523,7 @@ int micloc_snn_pipeline_cov_f64(const micloc_plan *p, const double *x, int B, in
 int micloc_synth_delay_f64(const double *time, const double *sig, const double *slopes, int T, const double *delays,
                            int B, int M, double fs, double *x, void *stream)
 {
-    if (!time || !sig || !slopes || !delays || !x || T < 2 || B < 1 || M < 1 || !(fs > 0.0)) return MICLOC_ERR_INVALID;
+    if (!time || !sig || !slopes || !delays || !x || T < 2 || bad_batch(B) || M < 1 || !(fs > 0.0)) return MICLOC_ERR_INVALID;
     HIP_TRY(launch_synth(time, sig, slopes, T, delays, B, M, fs, x, (hipStream_t)stream));
     return MICLOC_OK;
 }
@@ -536,7 +539,7 @@ int micloc_xylo_lif_i16(const uint8_t *spikes_in, int B, int T, int Cin, const i
                         const uint8_t *dash_syn, const uint8_t *dash_mem, const int16_t *thr, int max_spikes,
                         uint8_t *spikes_out, int32_t *rate, void *ws, size_t ws_bytes, void *stream)
 {
-    if (!spikes_in || !W_in || !dash_syn || !dash_mem || !thr || B < 1 || T < 1 || Cin < 1 || N < 1 || max_spikes < 1 ||
+    if (!spikes_in || !W_in || !dash_syn || !dash_mem || !thr || bad_batch(B) || T < 1 || Cin < 1 || N < 1 || max_spikes < 1 ||
         (!spikes_out && !rate))
         return MICLOC_ERR_INVALID;
     if (Cin > 64 || (w_rec != 0 && N > 1024)) return MICLOC_ERR_SHAPE;

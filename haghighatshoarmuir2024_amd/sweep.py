@@ -127,3 +127,50 @@ def noisy_target_sweep(beamf, bf_mat, doa_list, snr_db_vec=None, num_sim=100, se
     shape = (len(snr_db_vec), num_sim)
     return dict(doa=doa_all.reshape(shape), argmax=full["argmax"].reshape(shape), pmax=full["pmax"].reshape(shape), err=err.reshape(shape),
                 mae_deg=np.mean(err.reshape(shape), axis=1) * 180 / np.pi, snr_db_vec=snr_db_vec)
+
+
+def main(argv=None):
+    """`python -m haghighatshoarmuir2024_amd.sweep`: the noisy-target accuracy sweep of
+    paper_plots/target_snn_localization.py:309-520 (design + 11 SNRs x num_sim trials), printing what the script prints."""
+    import argparse
+    import os
+
+    ap = argparse.ArgumentParser(description=main.__doc__)
+    ap.add_argument("--num-sim", type=int, default=100)
+    ap.add_argument("--grid", type=int, default=64 * 7 + 1)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--mode", choices=["parity", "throughput"], default="parity")
+    args = ap.parse_args(argv)
+
+    from .array_geometry import CenterCircularArray
+    from .snn_beamformer import SNNBeamformer
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
+        dist.init_process_group("nccl")
+    fs, freq_design = 48_000, 2000.0
+    freq_range = [0.5 * freq_design, freq_design]
+    tau = 1.0 / (2 * np.pi * freq_design)
+    beamf = SNNBeamformer(CenterCircularArray(radius=4.5e-2, num_mic=7), kernel_duration=10.0e-3, tau_vec=np.asarray([tau, tau]),
+                          freq_range=freq_range, fs=fs, bipolar_spikes=True)
+    time_temp = np.arange(0, 1.0, step=1 / fs)
+    period = time_temp[-1]
+    freq_inst = freq_range[0] + (freq_range[1] - freq_range[0]) * (time_temp % period) / period
+    sig_temp = np.sin(2 * np.pi * np.cumsum(freq_inst) / fs)
+    doa_list = np.linspace(-np.pi, np.pi, args.grid)
+    bf_mat = beamf.design_from_template((time_temp, sig_temp), doa_list)
+    res = noisy_target_sweep(beamf, bf_mat, doa_list, num_sim=args.num_sim, seed=args.seed, mode=args.mode, rank=rank, world_size=world)
+    if rank == 0:
+        print(f"SNR: {res['snr_db_vec']}")
+        print(f"Mean aboslute errors: {res['mae_deg']}")
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
