@@ -322,6 +322,32 @@ def gen_sweep_seed0():
          mae_deg=np.mean(err, axis=1) * 180 / np.pi)
 
 
+def gen_sweep_full():
+    """The complete accuracy sweep of paper_plots/target_snn_localization.py:435-467: 11 SNRs x 100 trials, seed 0."""
+    beamf, geometry, fs, fd, fr = cfg2_beamformer(True)
+    z = np.load(os.path.join(OUT, "bf_mat_chirp449_bipolar.npz"))
+    bf_mat, doa_list = z["bf_mat"], z["doa_list"]
+    snr_gain = (fs / 2) / (fr[1] - fr[0])
+    snr_db_vec = np.linspace(-10, 20, 11)
+    num_sim = 100
+    time_test = np.arange(0, 100e-3, step=1 / fs)
+    sig_test = np.sin(2 * np.pi * fd * time_test)
+    np.random.seed(0)
+    shape = (len(snr_db_vec), num_sim)
+    doa, amax, err, pmax = np.zeros(shape), np.zeros(shape, dtype=np.int64), np.zeros(shape), np.zeros(shape)
+    for i, snr_db in enumerate(snr_db_vec):
+        snr_t = snr_db - 10 * np.log10(snr_gain)
+        for sim in range(num_sim):
+            d = np.random.rand(1)[0] * 2 * np.pi
+            y = beamf.apply_to_template(bf_mat=bf_mat, template=(time_test, sig_test, d), snr_db=snr_t)
+            power = np.mean(np.abs(y) ** 2, axis=0)
+            k = int(np.argmax(power))
+            doa[i, sim], amax[i, sim], pmax[i, sim] = d, k, power[k]
+            err[i, sim] = np.arcsin(np.abs(np.sin(doa_list[k] - d)))
+    save("sweep_full_seed0.npz", seed=np.int64(0), snr_db_vec=snr_db_vec, doa=doa, argmax=amax, err=err, pmax=pmax,
+         mae_deg=np.mean(err, axis=1) * 180 / np.pi)
+
+
 def gen_rzcc_edge():
     rng = np.random.RandomState(42)
     cases = {}
@@ -577,6 +603,7 @@ GENS = {
     "synth": gen_synth,
     "filterbank": gen_filterbank,
     "speech": gen_speech,
+    "sweep_full": gen_sweep_full,
 }
 
 if __name__ == "__main__":

@@ -175,3 +175,60 @@ def test_throughput_sweep_statistics(cfg2):
     res = noisy_target_sweep(bf, cfg2["bf_mat"], cfg2["doa_list"], snr_db_vec=[-10.0, 5.0, 20.0], num_sim=200, seed=11, mode="throughput")
     mae = res["mae_deg"]
     assert 6.0 < mae[0] < 25.0 and 0.5 < mae[1] < 2.5 and 0.5 < mae[2] < 2.0 and mae[0] > 3 * mae[1]
+
+
+def test_full_sweep_1100_trials_matches_reference(cfg2):
+    """BASELINE config 2 end to end: 11 SNRs x 100 trials on the reference's RNG stream -> identical arg-max for all
+    1100 trials and the reference's MAE curve to the printed digits."""
+    from haghighatshoarmuir2024_amd.sweep import noisy_target_sweep
+
+    z = golden("sweep_full_seed0.npz")
+    bf = make_beamformer()
+    res = noisy_target_sweep(bf, cfg2["bf_mat"], cfg2["doa_list"], num_sim=100, seed=0, mode="parity")
+    np.testing.assert_array_equal(res["snr_db_vec"], z["snr_db_vec"])
+    np.testing.assert_array_equal(res["doa"], z["doa"])
+    np.testing.assert_array_equal(res["argmax"], z["argmax"])
+    np.testing.assert_allclose(res["pmax"], z["pmax"], rtol=1e-10)
+    np.testing.assert_allclose(res["mae_deg"], z["mae_deg"], rtol=0, atol=1e-9)
+    # covariance-form variant: same decisions
+    from haghighatshoarmuir2024_amd.sweep import device_localizer
+
+    def cov_localizer(sig_batch, time_vec):
+        out = bf.localize_batch(cfg2["bf_mat"], sig_batch, time_vec=time_vec, power_mode="covariance")
+        a = out["argmax"].cpu().numpy().astype(np.int64)
+        return a, out["power"].cpu().numpy()[np.arange(len(a)), a]
+
+    res2 = noisy_target_sweep(bf, cfg2["bf_mat"], cfg2["doa_list"], snr_db_vec=z["snr_db_vec"][:3], num_sim=100, seed=0, mode="parity",
+                              localizer=cov_localizer)
+    np.testing.assert_array_equal(res2["argmax"], z["argmax"][:3])
+
+
+def test_full_design_bipolar_449_and_config1_unipolar_225(cfg2):
+    """design_from_template for the complete DoA grids of config 2 (449, bipolar, 1 s chirp) and config 1
+    (array_resolution_snn.py: 225, unipolar, 0.4 s sine) against the reference's bf_mat, plus config 1's beam pattern."""
+    from micloc.array_geometry import CenterCircularArray
+    from micloc.snn_beamformer import SNNBeamformer
+
+    z = golden("bf_mat_chirp449_bipolar.npz")
+    bf = make_beamformer()
+    fs = 48_000
+    time_temp = np.arange(0, 1.0, step=1 / fs)
+    period = time_temp[-1]
+    sig_temp = np.sin(2 * np.pi * np.cumsum(1000 + 1000 * (time_temp % period) / period) / fs)
+    W = bf.design_from_template((time_temp, sig_temp), z["doa_list"])
+    assert W.shape == (14, 449)
+    Wc, Rc = W[:7] + 1j * W[7:], z["bf_mat"][:7] + 1j * z["bf_mat"][7:]
+    phase = np.sum(np.conj(Wc) * Rc, axis=0)
+    np.testing.assert_allclose(Wc * (phase / np.abs(phase)), Rc, rtol=0, atol=1e-8)  # up to the phase of U[:, 0]
+    np.testing.assert_allclose(np.abs(W.T @ W), np.abs(z["bf_mat"].T @ z["bf_mat"]), rtol=0, atol=1e-7)
+
+    zu = golden("bf_mat_sin225_unipolar.npz")
+    for f in (1000, 2000, 4000):
+        tau = 1 / (2 * np.pi * f)
+        bfu = SNNBeamformer(CenterCircularArray(4.5e-2, 7), 10e-3, [0.5 * f, 2 * f], np.asarray([tau, tau]), bipolar_spikes=False, fs=fs)
+        t = np.arange(0, 0.4, step=1 / fs)
+        Wu = bfu.design_from_template((t, np.sin(2 * np.pi * f * t)), zu["doa_list"])
+        ref = zu[f"bf_mat_f{f}"]
+        np.testing.assert_allclose(Wu, ref, rtol=0, atol=2e-7)
+        # the quantity config 1 plots (array_resolution_snn.py:157-160)
+        np.testing.assert_allclose(np.abs(Wu.T @ Wu), np.abs(ref.T @ ref), rtol=0, atol=1e-6)
