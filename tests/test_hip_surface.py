@@ -232,3 +232,43 @@ def test_full_design_bipolar_449_and_config1_unipolar_225(cfg2):
         np.testing.assert_allclose(Wu, ref, rtol=0, atol=2e-7)
         # the quantity config 1 plots (array_resolution_snn.py:157-160)
         np.testing.assert_allclose(np.abs(Wu.T @ Wu), np.abs(ref.T @ ref), rtol=0, atol=1e-6)
+
+
+def test_live_demo_frame_processing(cfg2):
+    """localization_demo_snn.Demo.process_frame == filterbank -> apply_to_signal per band -> summed power -> arg-max,
+    checked against the oracle composition; weak packs give NaN (reference :153-159)."""
+    from micloc.array_geometry import CenterCircularArray
+    from micloc.localization_demo_snn import Demo
+    from micloc.xylo_snn_localization import signal_from_template
+    from oracle import oracle as O
+
+    fs = 48_000
+    geo = CenterCircularArray(4.5e-2, 7)
+    doa_list = np.linspace(-np.pi, np.pi, 57)
+    bands = [[1600, 2000], [2000, 2300]]
+    demo = Demo(geometry=geo, freq_bands=bands, doa_list=doa_list, recording_duration=0.1, kernel_duration=10e-3, bipolar_spikes=True, fs=fs)
+    t = np.arange(0, 0.1, 1 / fs)
+    rng = np.random.RandomState(2)
+    doa = 0.9
+    sig = signal_from_template(geo, (t, np.sin(2 * np.pi * 1900 * t) + 0.7 * np.sin(2 * np.pi * 2150 * t), doa))
+    sig = sig + 0.05 * rng.randn(*sig.shape)
+    pack = np.zeros((len(t), 8), dtype=np.int32)
+    pack[:, :7] = np.round(sig * 2**28).astype(np.int32)
+    got = demo.process_frame(pack)
+    # oracle composition
+    data = pack[:, :-1].astype(np.float64)
+    power = 0
+    for (b1, a1), bf_mat, beamf in zip(demo.filterbank.ba_list, demo.bf_mats, demo.beamfs):
+        filt = O.iir(b1, a1, data)
+        bb, aa = beamf.bandpass_filter
+        tau = beamf.tau_vec[0]
+        nir = O.neuron_kernel(np.arange(len(t)) / fs, [tau, tau])
+        out = O.snn_chain(filt, beamf.kernel, bb, aa, beamf.spk_encoder.robust_width, True, nir, bf_mat, want=("power",))
+        power = power + out["power"]
+    np.testing.assert_allclose(demo.power_grid(data), power, rtol=1e-12)
+    assert got == doa_list[int(np.argmax(power))] * 180 / np.pi
+    assert abs(np.degrees(np.arcsin(abs(np.sin(np.radians(got) - doa))))) < 12
+    assert np.isnan(demo.process_frame(np.ones((4800, 8), dtype=np.int32)))
+    seen = []
+    demo.run([pack, np.ones((4800, 8), dtype=np.int32)], sink=seen.append)
+    assert seen[0] == got and np.isnan(seen[1])
