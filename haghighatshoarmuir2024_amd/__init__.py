@@ -5,5 +5,6 @@ resolves to thin re-exports of these modules so the paper_plots scripts run unch
 """
 from . import _lib  # noqa: F401
 
-__all__ = ["array_geometry", "beamformer", "filterbank", "snn_beamformer", "spike_encoder", "utils", "runtime", "sweep"]
+__all__ = ["array_geometry", "beamformer", "filterbank", "snn_beamformer", "spike_encoder", "utils", "runtime", "sweep", "flac",
+           "xylo_snn_localization", "localization_demo_snn"]
 __version__ = "0.1.0"

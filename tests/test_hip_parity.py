@@ -332,3 +332,30 @@ def test_many_mic_complex_beamformer(torch):
         np.testing.assert_allclose(out["y"][i].cpu().numpy(), ref["y"], rtol=0, atol=1e-12)
         np.testing.assert_allclose(out["power"][i].cpu().numpy(), ref["power"], rtol=1e-12)
         assert int(out["argmax"][i]) == ref["argmax"]
+
+
+@pytest.mark.parametrize("T", [2, 3, 16, 17, 31, 100, 511, 512, 513, 1025])
+def test_pipeline_short_and_boundary_lengths(plan2, cfg2, T):
+    """Ragged lengths around every tile size in the kernels (16-step RZCC tiles, 512-frame beamforming chunks)."""
+    rng = np.random.RandomState(T)
+    x = rng.randn(2, T, 7)
+    out = plan2.snn_pipeline(plan2.to_device(x), want_spikes=True, want_y=True, want_power=True)
+    cov = plan2.snn_pipeline_cov(plan2.to_device(x), want_power=True)
+    for i in range(2):
+        ref = O.snn_chain(x[i], cfg2["kernel"], cfg2["b"], cfg2["a"], cfg2["robust_width"], True, cfg2["nir"], cfg2["bf_mat"])
+        np.testing.assert_array_equal(out["spikes"][i].cpu().numpy(), ref["spikes"])
+        np.testing.assert_array_equal(out["y"][i].cpu().numpy(), ref["y"])
+        np.testing.assert_allclose(out["power"][i].cpu().numpy(), ref["power"], rtol=1e-12, atol=1e-300)
+        np.testing.assert_allclose(cov["power"][i].cpu().numpy(), ref["power"], rtol=1e-11, atol=1e-300)
+        assert int(out["argmax"][i]) == ref["argmax"]
+
+
+def test_empty_and_invalid_inputs(plan2, torch):
+    from haghighatshoarmuir2024_amd import _lib, runtime
+
+    assert runtime.rzcc_encode(np.zeros((0, 3)), 3, True).shape == (0, 3)
+    assert runtime.rzcc_encode(np.zeros((5, 0)), 3, True).shape == (5, 0)
+    with pytest.raises(ValueError):
+        plan2.snn_pipeline(plan2.to_device(np.zeros((1, 50, 6))))
+    with pytest.raises((_lib.MiclocError, ValueError)):
+        plan2.set_bf_mat(np.zeros((12, 5)))
