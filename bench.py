@@ -114,8 +114,12 @@ def make_step(wl, nstreams):
         mae = err.reshape(S, -1).mean(dim=1)
         return out, mae
 
+    # one HIP graph per stream (pipeline kernels + the DoA-error / MAE ops), replayed round-robin
+    replay_direct = pipe.capture(lambda plan: body(plan, False))
+    replay_cov = pipe.capture(lambda plan: body(plan, True)) if x.shape[2] * 2 <= 64 else None
+
     def step(cov=False):
-        return pipe.submit(lambda plan: body(plan, cov))
+        return replay_cov() if cov else replay_direct()
 
     return step, pipe
 
@@ -212,6 +216,7 @@ def main():
     dt = float(tmax.item())
     frames = world * B * T * args.steps
     value = frames / dt
+    argmax_direct = out["argmax"].clone()  # graph outputs are static buffers: keep a copy for the comparisons below
 
     # separately reported algorithmic variant: covariance-form power, same K steps, same inputs
     cov_variant = None
@@ -228,7 +233,7 @@ def main():
             dist.all_reduce(dtc, op=dist.ReduceOp.MAX)
         dtc = float(dtc.item())
         cov_variant = {"value": frames / dtc, "unit": "frames/s", "ms_per_step": dtc / args.steps * 1e3,
-                       "argmax_equal_to_direct": bool(torch.equal(out_c["argmax"], out["argmax"])),
+                       "argmax_equal_to_direct": bool(torch.equal(out_c["argmax"], argmax_direct)),
                        "note": "power = w^T (V^T V / T) w instead of mean_t (V w)^2: algebraically identical, 2C^2 instead of 2CG flops per frame; not the headline"}
 
     result = None
@@ -274,14 +279,14 @@ def main():
             "config": {"workload": f"target_snn_localization noisy sweep: 7-mic centre-circular, 48 kHz, T={T}, {B} trials/GPU/step (11 SNR x {B // 11}), "
                                    f"{G}-DoA grid, bipolar RZCC, bf_mat designed on device from the 1 s chirp",
                        "trials_per_gpu": B, "frames_per_trial": T, "num_mic": M, "num_doa": G, "mic_samples_per_s": value * M,
-                       "parallelism": f"trial-sharded x{world}", "hip_streams": max(1, args.streams)},
+                       "parallelism": f"trial-sharded x{world}", "hip_streams": max(1, args.streams), "hip_graphs": True},
             "mae_deg_per_snr": [float(v) for v in (mae * 180 / np.pi).cpu().numpy()],
             "roofline": roof,
             "variants": {"covariance_power": cov_variant},
         }
         if not args.no_cpu_baseline and world == 1:
             cb, am_cpu = cpu_baseline(wl, min(args.cpu_sample, B))
-            am_gpu = out["argmax"][: len(am_cpu)].cpu().numpy()
+            am_gpu = argmax_direct[: len(am_cpu)].cpu().numpy()
             cb["argmax_equal_to_gpu"] = bool(np.array_equal(am_cpu, am_gpu))
             result["cpu_baseline"] = cb
     if use_dist:

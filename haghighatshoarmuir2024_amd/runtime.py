@@ -345,6 +345,32 @@ class StreamPipeline:
         with torch.cuda.stream(s):
             return fn(self.plans[i])
 
+    def capture(self, fn):
+        """Capture fn(plan) once per stream into a HIP graph (the C-ABI stage calls neither allocate nor synchronise,
+        include/micloc_hip.h).  Returns a callable `replay()` that launches the next stream's graph round-robin and
+        returns that stream's (static) outputs.  fn must read its inputs from tensors that outlive the graphs."""
+        torch = _torch()
+        graphs = []
+        for plan, s in zip(self.plans, self.streams):
+            s.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(s):
+                fn(plan)  # warm-up outside capture: workspaces and lazily-set kernel attributes
+            s.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=s):
+                out = fn(plan)
+            graphs.append((g, out))
+        state = {"next": 0}
+
+        def replay():
+            i = state["next"] % len(graphs)
+            state["next"] += 1
+            with torch.cuda.stream(self.streams[i]):
+                graphs[i][0].replay()
+            return graphs[i][1]
+
+        return replay
+
     def synchronize(self):
         torch = _torch()
         cur = torch.cuda.current_stream(self.device)

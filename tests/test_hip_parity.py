@@ -359,3 +359,27 @@ def test_empty_and_invalid_inputs(plan2, torch):
         plan2.snn_pipeline(plan2.to_device(np.zeros((1, 50, 6))))
     with pytest.raises((_lib.MiclocError, ValueError)):
         plan2.set_bf_mat(np.zeros((12, 5)))
+
+
+def test_pipeline_is_graph_capturable(plan2, cfg2, torch):
+    """include/micloc_hip.h promises that the stage calls neither allocate nor synchronise: capture the fused
+    pipeline in a HIP graph, replay it on new input data, compare with the eager result."""
+    z = golden("trials_cfg2.npz")
+    x = plan2.to_device(z["sig_in"])
+    eager = plan2.snn_pipeline(x, want_spikes=True, want_power=True)
+    static_x = x.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        plan2.snn_pipeline(static_x, want_spikes=True, want_power=True)  # warm-up: workspace is allocated here
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = plan2.snn_pipeline(static_x, want_spikes=True, want_power=True)
+    static_x.copy_(x.flip(0))
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out["spikes"], eager["spikes"].flip(0))
+    assert torch.equal(out["power"], eager["power"].flip(0))
+    assert torch.equal(out["argmax"], eager["argmax"].flip(0))
