@@ -108,7 +108,10 @@ def make_step(wl, nstreams):
     pipe = StreamPipeline(plans)
 
     def body(plan, cov=False):
-        out = plan.snn_pipeline_cov(x, want_power=True) if cov else plan.snn_pipeline(x, want_power=True)
+        if cov == "f32":
+            out = plan.snn_pipeline_f32bf(x)
+        else:
+            out = plan.snn_pipeline_cov(x, want_power=True) if cov else plan.snn_pipeline(x, want_power=True)
         est = doa_list[out["argmax"].long()]
         err = torch.arcsin(torch.abs(torch.sin(est - doa)))
         mae = err.reshape(S, -1).mean(dim=1)
@@ -118,7 +121,11 @@ def make_step(wl, nstreams):
     replay_direct = pipe.capture(lambda plan: body(plan, False))
     replay_cov = pipe.capture(lambda plan: body(plan, True)) if x.shape[2] * 2 <= 64 else None
 
+    replay_f32 = pipe.capture(lambda plan: body(plan, "f32")) if x.shape[2] * 2 <= 64 else None
+
     def step(cov=False):
+        if cov == "f32":
+            return replay_f32()
         return replay_cov() if cov else replay_direct()
 
     return step, pipe
@@ -236,6 +243,26 @@ def main():
                        "argmax_equal_to_direct": bool(torch.equal(out_c["argmax"], argmax_direct)),
                        "note": "power = w^T (V^T V / T) w instead of mean_t (V w)^2: algebraically identical, 2C^2 instead of 2CG flops per frame; not the headline"}
 
+    # second separately reported variant: fp32-MFMA beamforming tail (fp64 up to the spikes)
+    f32_variant = None
+    if M * 2 <= 64:
+        for _ in range(args.warmup):
+            step(cov="f32")
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out_f, mae_f = step(cov="f32")
+        barrier()
+        dtf = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+        if use_dist:
+            dist.all_reduce(dtf, op=dist.ReduceOp.MAX)
+        dtf = float(dtf.item())
+        relerr = float((out_f["power"] / out["power"] - 1).abs().max().item())
+        f32_variant = {"value": frames / dtf, "unit": "frames/s", "ms_per_step": dtf / args.steps * 1e3,
+                       "argmax_equal_to_f64": int((out_f["argmax"] == argmax_direct).sum().item()), "trials": int(B),
+                       "max_rel_power_err_vs_f64": relerr,
+                       "note": "LIF + beamforming + power on v_mfma_f32_16x16x4_f32 (157 TF peak); STHT / band-pass / RZCC stay fp64; not the headline"}
+
     result = None
     if rank == 0:
         st = stage_times(wl, max(5, min(args.steps, 20)))
@@ -282,7 +309,7 @@ def main():
                        "parallelism": f"trial-sharded x{world}", "hip_streams": max(1, args.streams), "hip_graphs": True},
             "mae_deg_per_snr": [float(v) for v in (mae * 180 / np.pi).cpu().numpy()],
             "roofline": roof,
-            "variants": {"covariance_power": cov_variant},
+            "variants": {"covariance_power": cov_variant, "f32_mfma_beamform": f32_variant},
         }
         if not args.no_cpu_baseline and world == 1:
             cb, am_cpu = cpu_baseline(wl, min(args.cpu_sample, B))

@@ -471,6 +471,22 @@ int micloc_lfilter_f64(const double *b, const double *a, int n, const double *x,
     return MICLOC_OK;
 }
 
+// ---- fp32-MFMA variant of the beamforming tail ---------------------------------------------------------------------
+int micloc_lif_beamform_f32(const micloc_plan *p, const int8_t *spikes, int B, int T, double *power, int32_t *argmax,
+                            void *ws, size_t ws_bytes, void *stream)
+{
+    if (!p || !spikes || bad_batch(B) || T < 1 || (!power && !argmax)) return MICLOC_ERR_INVALID;
+    if (!p->d_ntab || !p->d_W) return MICLOC_ERR_NOT_SET;
+    if (p->W_is_complex || p->W.CT > 4) return MICLOC_ERR_SHAPE;
+    const int Gp = 16 * p->W.GT;
+    if (bad_ws(ws, ws_bytes, beamform_partial_bytes(B, T, Gp))) return MICLOC_ERR_WORKSPACE;
+    double *partial = reinterpret_cast<double *>(ws);
+    HIP_TRY(launch_lif_beamform_f32(p->W, p->ntab, spikes, B, T, partial, (hipStream_t)stream));
+    HIP_TRY(launch_power_argmax(partial, B, T, beamform_nchunks(T), Gp, p->G_out, 0, 0, power, argmax,
+                                (hipStream_t)stream));
+    return MICLOC_OK;
+}
+
 // ---- covariance-form power and membrane covariance ------------------------------------------------------------
 int micloc_lif_covariance_f64(const micloc_plan *p, const int8_t *spikes, int B, int T, int t_start, double *cov,
                               double *power, int32_t *argmax, void *ws, size_t ws_bytes, void *stream)

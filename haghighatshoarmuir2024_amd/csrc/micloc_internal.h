@@ -71,6 +71,10 @@ hipError_t launch_power_argmax(const double *partial, int B, int T, int nchunks,
 int beamform_nchunks(int T);
 int beamform_nchunks_ct(int T, int CT);  // chunking of the kernel family that serves CT channel tiles
 
+// fp32-MFMA variant of LIF + beamforming + power (up to 64 channels, bf_mat must fit in LDS)
+hipError_t launch_lif_beamform_f32(const BeamformW &W, const NeuronTab &nt, const int8_t *spikes, int B, int T,
+                                   double *partial, hipStream_t stream);
+
 // ---- covariance-form power / membrane covariance ------------------------------------------------------------
 size_t cov_partial_bytes(int B, int T, int CT);
 hipError_t launch_lif_cov(const NeuronTab &nt, const int8_t *spikes, int B, int T, int C, int CT, int t_start,

@@ -414,6 +414,30 @@ __global__ __launch_bounds__(64) void rzcc_fallback_kernel(const double *__restr
     }
 }
 
+// Zero fill as an ordinary kernel.  hipMemsetAsync is avoided on purpose: captured into a HIP graph (ROCm 7.x) the
+// memset NODE was observed not to be ordered before the kernel nodes that follow it -- the fallback kernel then read a
+// stale flagged-stream counter and faulted on the third replay -- whereas kernel -> kernel edges are honoured.
+__global__ __launch_bounds__(256) void zero_fill_kernel(uint4 *__restrict__ p16, size_t n16, unsigned char *__restrict__ tail,
+                                                         int ntail)
+{
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride) p16[i] = make_uint4(0, 0, 0, 0);
+    if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = 0;
+}
+
+static hipError_t zero_fill(void *ptr, size_t bytes, hipStream_t stream)
+{
+    // torch / hipMalloc buffers are at least 16-byte aligned; the scatter target [B][T][C] int8 may have any size
+    const size_t n16 = bytes / 16;
+    const int ntail = (int)(bytes - n16 * 16);
+    size_t blocks = (n16 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, reinterpret_cast<uint4 *>(ptr), n16,
+                       reinterpret_cast<unsigned char *>(ptr) + n16 * 16, ntail);
+    return hipGetLastError();
+}
+
 size_t rzcc_scratch_bytes(int nlanes, int T)
 {
     size_t bytes = 256;                                         // flagged-stream counter
@@ -456,9 +480,9 @@ hipError_t launch_bandpass_rzcc(const IirCoef &coef, const double *h, int nlanes
         flag_list = reinterpret_cast<int *>(base + 256);
         vlist = reinterpret_cast<double *>(base + 256 + (((size_t)nlanes * sizeof(int) + 255) & ~(size_t)255));
         plist = reinterpret_cast<int *>(vlist + (size_t)T * nlanes);
-        hipError_t e = hipMemsetAsync(flag_count, 0, 256, stream);
+        hipError_t e = zero_fill(flag_count, 256, stream);
         if (e != hipSuccess) return e;
-        e = hipMemsetAsync(spikes, 0, (size_t)nlanes * T, stream);
+        e = zero_fill(spikes, (size_t)nlanes * T, stream);
         if (e != hipSuccess) return e;
     }
 #define RZ_CASE(NN)                                                                                       \

@@ -176,6 +176,30 @@ class Plan:
         out.update(spikes=spikes, y=y, power=power, argmax=argmax)
         return out
 
+    def snn_pipeline_f32bf(self, x, want_spikes=False):
+        """VARIANT: fp64 up to the spikes (STHT, band-pass, RZCC), then LIF + beamforming + power on the fp32 MFMA units
+        (micloc_lif_beamform_f32).  Returns spikes / power / argmax like snn_pipeline; power agrees to ~1e-6 relative."""
+        torch = _torch()
+        B, T, M = x.shape
+        if M != self.num_mic:
+            raise ValueError(f"number of channels in the input siganl {M} should be the same as the number of microphones {self.num_mic}!")
+        ws, nbytes = self.workspace(B, T)
+        Ts = self.padded_T(T)
+        key = (B, T)
+        if getattr(self, "_f32_key", None) != key:  # stage buffers, allocated once per shape
+            self._f32_h = torch.empty((B, self.C, Ts), dtype=torch.float64, device=self.device)
+            self._f32_spk = torch.empty((B, T, self.C), dtype=torch.int8, device=self.device)
+            self._f32_key = key
+        h, spikes = self._f32_h, self._f32_spk
+        st = _stream(self.device)
+        _lib.check(self.lib.micloc_stht_f64(self.handle, _ptr(x), B, T, _ptr(h), Ts, st), "stht")
+        _lib.check(self.lib.micloc_bandpass_rzcc_f64(self.handle, _ptr(h), B, T, Ts, None, _ptr(spikes), _ptr(ws), nbytes, st), "bandpass_rzcc")
+        power = torch.empty((B, self.G), dtype=torch.float64, device=self.device)
+        argmax = torch.empty((B,), dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.micloc_lif_beamform_f32(self.handle, _ptr(spikes), B, T, _ptr(power), _ptr(argmax), _ptr(ws), nbytes, st),
+                   "lif_beamform_f32")
+        return dict(spikes=spikes.clone() if want_spikes else None, y=None, power=power, argmax=argmax)
+
     def snn_pipeline_cov(self, x, t_start=0, want_spikes=False, want_cov=False, want_power=True):
         """Covariance-form tail: power = w^T (V^T V / T') w, optionally the membrane covariance itself
         (frames t >= t_start).  Algebraically identical to snn_pipeline's power; supports up to 64 channels."""

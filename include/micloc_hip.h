@@ -123,6 +123,13 @@ size_t micloc_lfilter_workspace_bytes(int B, int T, int C);
 int micloc_lfilter_f64(const double *b, const double *a, int n, const double *x, int B, int T, int C, double *y,
                        void *ws, size_t ws_bytes, void *stream);
 
+/* ---- fp32-MFMA variant of the beamforming tail ------------------------------------------------------ */
+/* Same contract as micloc_lif_beamform_f64 (power / arg-max only, real bf_mat, up to 64 channels) with the LIF filter
+ * and the contraction on v_mfma_f32_16x16x4_f32: the spikes are exact in fp32, the power agrees with the fp64 path to
+ * ~1e-6 relative (BASELINE's north star allows 1e-5 float32 for this stage).  A VARIANT, reported separately. */
+int micloc_lif_beamform_f32(const micloc_plan *plan, const int8_t *spikes, int B, int T, double *power, int32_t *argmax,
+                            void *ws, size_t ws_bytes, void *stream);
+
 /* ---- covariance form ------------------------------------------------------------------ */
 /* cov[b] = V^T V / (T - t_start) over frames t >= t_start of the membrane signal V = lfilter(nir,[1],spikes)
  * (the matrix design_from_template needs, snn_beamformer.py:176-191, with t_start = T // 4), and

@@ -88,3 +88,31 @@ def test_negation_swaps_polarity(big):
     neg = p.snn_pipeline(-x[:64].contiguous(), want_spikes=True, want_power=True)
     assert torch.equal(neg["spikes"], -out["spikes"][:64])
     torch.testing.assert_close(neg["power"], out["power"][:64], rtol=1e-12, atol=0)
+
+
+def test_graph_replays_full_size(big):
+    """Regression: a captured hipMemsetAsync node was not ordered before the kernels that follow it (stale
+    flagged-stream counter -> wild scatter / GPU memory fault on the third replay at this size).  The zero fill is a
+    kernel now; replay the stage-API composition (shared workspace head) and the fused pipeline several times."""
+    import torch
+
+    p, x, out = big
+    variants = {"f32": lambda: p.snn_pipeline_f32bf(x), "direct": lambda: p.snn_pipeline(x, want_power=True),
+                "cov": lambda: p.snn_pipeline_cov(x, want_power=True)}
+    ref = {k: fn() for k, fn in variants.items()}
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    for name, fn in variants.items():
+        with torch.cuda.stream(s):
+            fn()
+        s.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            o = fn()
+        for _ in range(5):
+            with torch.cuda.stream(s):
+                g.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(o["argmax"], ref[name]["argmax"]), name
+            assert torch.equal(o["power"], ref[name]["power"]), name
+    assert torch.equal(ref["direct"]["argmax"], out["argmax"])

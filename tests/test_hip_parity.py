@@ -383,3 +383,31 @@ def test_pipeline_is_graph_capturable(plan2, cfg2, torch):
     assert torch.equal(out["spikes"], eager["spikes"].flip(0))
     assert torch.equal(out["power"], eager["power"].flip(0))
     assert torch.equal(out["argmax"], eager["argmax"].flip(0))
+
+
+def test_f32_mfma_beamform_variant(plan2, cfg2):
+    """fp32-MFMA tail (variant): spikes untouched (fp64 front end), power within 1e-5 of the fp64 path and of the
+    reference (BASELINE north star: 'within 1e-5 float32'), arg-max equal on the golden trials."""
+    z = golden("trials_cfg2.npz")
+    x = plan2.to_device(z["sig_in"])
+    d = plan2.snn_pipeline(x, want_power=True)
+    f = plan2.snn_pipeline_f32bf(x, want_spikes=True)
+    np.testing.assert_array_equal(f["spikes"].cpu().numpy(), z["spikes"])
+    np.testing.assert_allclose(f["power"].cpu().numpy(), d["power"].cpu().numpy(), rtol=1e-5, atol=0)
+    np.testing.assert_allclose(f["power"].cpu().numpy(), z["power"], rtol=1e-5, atol=0)
+    rel = np.abs(f["power"].cpu().numpy() / d["power"].cpu().numpy() - 1).max()
+    assert rel < 5e-6, rel
+    np.testing.assert_array_equal(f["argmax"].cpu().numpy(), z["argmax"])
+    # ragged length + two channel tiles
+    from haghighatshoarmuir2024_amd.runtime import Plan
+
+    w = golden("wide_case.npz")
+    fs = int(w["fs"])
+    b, a = O.bandpass(fs, [1000.0, 2000.0])
+    tau = 1 / (2 * np.pi * 2000.0)
+    p = Plan(16, O.stht_kernel(fs, 10e-3), b, a, O.robust_width(fs, 2000.0), True)
+    p.set_neuron_kernel(O.neuron_kernel(w["time_vec"], [tau, tau]))
+    p.set_bf_mat(w["bf_mat"])
+    f2 = p.snn_pipeline_f32bf(p.to_device(w["sig_in"][None]))
+    np.testing.assert_allclose(f2["power"][0].cpu().numpy(), w["power"], rtol=1e-5)
+    assert int(f2["argmax"][0]) == int(w["argmax"])
