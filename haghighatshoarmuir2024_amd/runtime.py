@@ -381,7 +381,8 @@ class StreamPipeline:
                 fn(plan)  # warm-up outside capture: workspaces and lazily-set kernel attributes
             s.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=s):
+            # thread_local: other threads (e.g. the RCCL watchdog) may touch the runtime while this thread captures
+            with torch.cuda.graph(g, stream=s, capture_error_mode="thread_local"):
                 out = fn(plan)
             graphs.append((g, out))
         state = {"next": 0}
