@@ -29,6 +29,8 @@ if ROOT not in sys.path:
 # rocprofv3 --pmc passes (profiles/r1/pmc_summary.csv): 2 x FETCH_SIZE (gfx950 counts wide reads at half,
 # MI355X_MICROARCH.md "HBM") + WRITE_SIZE, both reported in KiB: 2 * 52798 + 31625 KiB.
 BEAMFORM_TRAFFIC_BYTES_DEFAULT = (2 * 52798 + 31625) * 1024
+# stage key in `stages_ms` -> device symbol that dominates it (what rocprofv3 lists)
+KERNEL_SYMBOL = {"beamform_kernel": "beamform_ws_kernel", "stht_kernel": "stht_kernel", "bandpass_rzcc_kernel": "bandpass_rzcc_fast_kernel"}
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X datasheet fp64 matrix = fp64 vector = 1/2 of the 157.3 TF fp32 rate in MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
 
@@ -286,7 +288,7 @@ def main():
             traffic = args.traffic_bytes
             if traffic is None and dom == "beamform_kernel" and (B, T, M, G) == (1100, 4799, 7, 360):
                 traffic = float(BEAMFORM_TRAFFIC_BYTES_DEFAULT)
-            roof = dict(kernel=dom, bound="mfma", achieved=achieved, peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+            roof = dict(kernel=KERNEL_SYMBOL.get(dom, dom), bound="mfma", achieved=achieved, peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                         frac=achieved / FP64_MFMA_PEAK_TFLOPS, traffic=traffic)
         roof["avg_launch_ms"] = st[dom]
         roof["stages_ms"] = st

@@ -305,6 +305,281 @@ __global__ __launch_bounds__(BF_THREADS) void beamform_kernel(const int8_t *__re
 
 
 // ---------------------------------------------------------------------------------------------------------------
+// bf_mat-stationary form for up to 16 channels and power-only output (the sweep configuration, C = 14).
+// Same arithmetic as beamform_kernel, different ownership: a wave keeps the bf_mat fragments of its own NGW DoA tiles
+// in registers for the whole workgroup lifetime and walks over ALL 32 time tiles of the 512-frame chunk, whose membrane
+// fragments the eight waves produced (4 tiles each) and parked in LDS in fragment order.  Per (time tile, DoA tile) the
+// wave issues 4 MFMAs and 4 FMAs (running per-lane sum of squares); cross-lane reduction and the store happen once per
+// workgroup instead of once per DoA tile, there is no cross-wave reduction at all (a DoA column belongs to one wave),
+// and bf_mat never goes through LDS.  VALU/LDS instructions per 16 MFMAs: ~25 instead of ~50.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int WS_TILES = BF_CHUNK / 16;  // 32 time tiles per workgroup
+
+template <int NG>
+__device__ __forceinline__ void ws_stage2(const double *Vl, const double *__restrict__ Wp, int Gp, int wv, int l,
+                                          int ntile, double *__restrict__ pout)
+{
+    if constexpr (NG > 0) {
+        const int lc = l & 15;
+        const int q = l >> 4;
+        // bf_mat fragments of this wave's DoA tiles (gt = wv, wv + 8, ...): straight from L2, once
+        double Wf[NG][4];
+#pragma unroll
+        for (int j = 0; j < NG; ++j) {
+            const double *wp = Wp + 16 * (wv + BF_WAVES * j) + lc;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) Wf[j][k] = wp[(size_t)(4 * k + q) * Gp];
+        }
+        double sq[NG];
+#pragma unroll
+        for (int j = 0; j < NG; ++j) sq[j] = 0.0;
+
+        auto ldv = [&](int tile, double (&V)[4]) {
+            const double *p = Vl + (size_t)(tile < WS_TILES ? tile : WS_TILES - 1) * 256 + l;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) V[k] = p[64 * k];
+        };
+        auto mm = [&](const double (&V)[4], double4_t (&acc)[NG]) {
+#pragma unroll
+            for (int j = 0; j < NG; ++j) acc[j] = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int j = 0; j < NG; ++j)
+                    acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(V[k], Wf[j][k], acc[j], 0, 0, 0);
+        };
+        auto sqr = [&](const double4_t (&acc)[NG]) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int j = 0; j < NG; ++j) sq[j] = __builtin_fma(acc[j][r], acc[j][r], sq[j]);
+        };
+
+        if (ntile > 0) {
+            double VA[4], VB[4];
+            double4_t accA[NG], accB[NG];
+            ldv(0, VA);
+            ldv(1, VB);
+            mm(VA, accA);
+            int t = 0;
+            // Each half of the loop body = 4 NG MFMAs of one time tile + the 4 NG squares of the previous one + the
+            // fragment loads of the next.  Left alone the compiler folds both accumulator sets into one and runs
+            // MFMAs -> s_nop -> squares back to back; the group barriers pin the interleaving (one VALU op in the
+            // shadow of every 64-cycle MFMA), the full barriers keep the two halves apart.
+            auto pin = [&]() {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);       // DS read (next tile's fragments)
+                __builtin_amdgcn_sched_group_barrier(0x008, 4 * NG - 1, 0);  // the remaining MFMAs, back to back
+                __builtin_amdgcn_sched_group_barrier(0x002, 4 * NG, 0);  // then the squares of the previous tile
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            __builtin_amdgcn_sched_barrier(0);
+            for (; t + 2 < ntile; t += 2) {
+                mm(VB, accB);
+                ldv(t + 2, VA);
+                sqr(accA);
+                pin();
+                mm(VA, accA);
+                ldv(t + 3, VB);
+                sqr(accB);
+                pin();
+            }
+            if (t + 1 < ntile) {
+                mm(VB, accB);
+                sqr(accA);
+                pin();
+                sqr(accB);
+            } else {
+                sqr(accA);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NG; ++j) {
+            const double s = row_sum4(sq[j]);
+            if (l < 16) pout[16 * (wv + BF_WAVES * j) + l] = s;
+        }
+    }
+}
+
+template <int NGW>
+__global__ __launch_bounds__(BF_THREADS, 4) void beamform_ws_kernel(const int8_t *__restrict__ spikes,
+                                                                    const double *__restrict__ ntab_g, int NK,
+                                                                    const double *__restrict__ Wp, int GT, int C, int T,
+                                                                    double *__restrict__ partial)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int Gp = 16 * GT;
+    const int tid = threadIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform, in an SGPR
+    const int l = tid & 63;
+    const int lc = l & 15;
+    const int q = l >> 4;
+    const int chunk = blockIdx.x;
+    const int nchunks = gridDim.x;
+    const int b = blockIdx.y;
+    const int cs = chunk * BF_CHUNK;
+
+    // [ union{ spike tile as fp64 [R][16] , V fragments [32 tiles][4 k-steps][64 lanes] } ][ nir table ]
+    // The spikes are converted to fp64 once, while they are staged (each row feeds ~3 time tiles of the Toeplitz
+    // product): the LIF loop is then LDS reads + MFMAs only.  VALU instructions do not overlap MFMAs on a gfx950 SIMD
+    // (tools/mfma_valu_overlap.hip), so every conversion saved is matrix-pipe time won.
+    const int R = BF_CHUNK + 4 * NK - 16;
+    double *S = reinterpret_cast<double *>(smem);
+    double *Vl = S;
+    double *ntab = S + (R * 16 > WS_TILES * 256 ? R * 16 : WS_TILES * 256);
+    const int ntab_len = 4 * NK + 16;
+
+    for (int e = tid; e < ntab_len; e += BF_THREADS) ntab[e] = ntab_g[e];
+    {
+        const int8_t *sb = spikes + (size_t)b * T * C;
+        const int tau0 = cs + 16 - 4 * NK;
+        const int c = tid & 15;
+        constexpr int RP = BF_THREADS / 16;  // rows per pass
+        const int rr = tid >> 4;
+        if (c >= C) {
+            for (int rho = rr; rho < R; rho += RP) S[rho * 16 + c] = 0.0;  // channel padding
+        } else if (tau0 >= 0 && tau0 + R <= T) {
+            // interior chunk (workgroup-uniform): no clamping, constant strides
+            const int8_t *p = sb + (size_t)(tau0 + rr) * C + c;
+            double *d = S + rr * 16 + c;
+            int rho = rr;
+            for (; rho + 5 * RP < R; rho += 6 * RP) {
+                int8_t v[6];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) v[i] = p[(size_t)i * RP * C];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) d[i * RP * 16] = (double)v[i];
+                p += (size_t)6 * RP * C;
+                d += 6 * RP * 16;
+            }
+            for (; rho < R; rho += RP) {
+                *d = (double)*p;
+                p += (size_t)RP * C;
+                d += RP * 16;
+            }
+        } else {
+            // first / last chunk of a trial: rows outside [0, T) are zero
+            for (int r0 = rr; r0 < R; r0 += RP * 6) {
+                int8_t v[6];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    int tau = tau0 + r0 + RP * i;
+                    tau = tau < 0 ? 0 : (tau >= T ? T - 1 : tau);
+                    v[i] = sb[(size_t)tau * C + c];
+                }
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    const int rho = r0 + RP * i;
+                    const int tau = tau0 + rho;
+                    if (rho < R) S[rho * 16 + c] = (tau >= 0 && tau < T) ? (double)v[i] : 0.0;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- stage 1: membrane fragments of this wave's 4 time tiles ---------------------------------------------
+    const int tb0 = cs + wv * BF_NT * 16;
+    const bool active = tb0 < T;  // wave-uniform
+    double4_t vacc[BF_NT];
+#pragma unroll
+    for (int tt = 0; tt < BF_NT; ++tt) vacc[tt] = double4_t{0.0, 0.0, 0.0, 0.0};
+    if (active) {
+        const double *sp = S + (size_t)(tb0 - cs + q) * 16 + lc;
+        const double *np_ = ntab + (lc - q + 4 * NK - 16 + 15 - 12);  // 12 below the tap row of k-step 0
+        // no register double-buffering here: it costs v_mov's (VALU time = MFMA time lost); the other waves of the
+        // SIMD cover the LDS latency
+        auto kstep = [&](const double *spk_, const double *nir_, int u) {
+            const double bn = nir_[12 - 4 * u];  // non-negative immediate offsets only
+            double a[BF_NT];
+#pragma unroll
+            for (int tt = 0; tt < BF_NT; ++tt) a[tt] = spk_[(16 * tt + 4 * u) * 16];
+#pragma unroll
+            for (int tt = 0; tt < BF_NT; ++tt)
+                vacc[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tt], bn, vacc[tt], 0, 0, 0);
+        };
+        int ks = 0;
+        for (; ks + 4 <= NK; ks += 4) {  // four k-steps per pointer update (immediate LDS offsets)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) kstep(sp, np_, u);
+            sp += 4 * 4 * 16;
+            np_ -= 4 * 4;
+        }
+        for (; ks < NK; ++ks) {
+            kstep(sp, np_, 0);
+            sp += 4 * 16;
+            np_ -= 4;
+        }
+    }
+    __syncthreads();  // every wave is done with the spike tile: the V fragments may overwrite it
+    if (active) {
+        if (tb0 + BF_NT * 16 > T) {  // only the wave that straddles the end of the trial masks
+#pragma unroll
+            for (int tt = 0; tt < BF_NT; ++tt) {
+                const bool tvalid = (tb0 + 16 * tt + lc) < T;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) vacc[tt][r] = tvalid ? vacc[tt][r] : 0.0;
+            }
+        }
+#pragma unroll
+        for (int tt = 0; tt < BF_NT; ++tt) {
+            double *vp = Vl + (size_t)(wv * BF_NT + tt) * 256 + l;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) vp[64 * r] = vacc[tt][r];
+        }
+    }
+    __syncthreads();
+
+    // ---- stage 2: this wave's DoA tiles against every time tile of the chunk --------------------------------
+    int ntile = (T - cs + 15) >> 4;
+    ntile = ntile > WS_TILES ? WS_TILES : ntile;
+    double *pout = partial + ((size_t)b * nchunks + chunk) * Gp;
+    // NGW = ceil(GT / 8): every wave owns NGW or NGW - 1 DoA tiles (wave-uniform choice of the instantiation)
+    if (wv + BF_WAVES * (NGW - 1) < GT)
+        ws_stage2<NGW>(Vl, Wp, Gp, wv, l, ntile, pout);
+    else
+        ws_stage2<NGW - 1>(Vl, Wp, Gp, wv, l, ntile, pout);
+}
+
+static size_t ws_lds_bytes(const NeuronTab &nt)
+{
+    const size_t tile = (size_t)(BF_CHUNK + 4 * nt.NK - 16) * 16, vfrag = (size_t)WS_TILES * 256;
+    return ((tile > vfrag ? tile : vfrag) + (size_t)(4 * nt.NK + 16)) * sizeof(double);
+}
+
+template <int NGW>
+static hipError_t launch_ws_n(const BeamformW &W, const NeuronTab &nt, const int8_t *spikes, int B, int T,
+                              double *partial, hipStream_t stream)
+{
+    const size_t lds = ws_lds_bytes(nt);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    auto k = &beamform_ws_kernel<NGW>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       160 * 1024);
+    if (e != hipSuccess) return e;
+    dim3 grid(beamform_nchunks(T), B), block(BF_THREADS);
+    hipLaunchKernelGGL(k, grid, block, lds, stream, spikes, nt.tab, nt.NK, W.Wp, W.GT, W.C, T, partial);
+    return hipGetLastError();
+}
+
+static bool ws_eligible(const BeamformW &W, const NeuronTab &nt)
+{
+    return W.CT == 1 && W.GT <= 4 * BF_WAVES && ws_lds_bytes(nt) <= 160 * 1024;
+}
+
+static hipError_t launch_ws(const BeamformW &W, const NeuronTab &nt, const int8_t *spikes, int B, int T,
+                            double *partial, hipStream_t stream)
+{
+    switch ((W.GT + BF_WAVES - 1) / BF_WAVES) {
+        case 1: return launch_ws_n<1>(W, nt, spikes, B, T, partial, stream);
+        case 2: return launch_ws_n<2>(W, nt, spikes, B, T, partial, stream);
+        case 3: return launch_ws_n<3>(W, nt, spikes, B, T, partial, stream);
+        case 4: return launch_ws_n<4>(W, nt, spikes, B, T, partial, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Many-channel variant (C > 64, e.g. the 64-microphone stress configuration): bf_mat no longer fits in LDS and the
 // membrane fragments of 4 time tiles no longer fit in registers.  Workgroup = 8 waves x 2 time tiles (256 frames);
 // the membrane fragments stay in registers (2 x CT x 4 doubles per lane), bf_mat is streamed through LDS in
@@ -602,6 +877,7 @@ static hipError_t dispatch_ct(const BeamformW &W, const NeuronTab *nt, const int
 hipError_t launch_lif_beamform(const BeamformW &W, const NeuronTab &nt, const int8_t *spikes, int B, int T, double *y,
                                double *partial, hipStream_t stream)
 {
+    if (!y && partial && ws_eligible(W, nt)) return launch_ws(W, nt, spikes, B, T, partial, stream);
     return dispatch_ct<true>(W, &nt, spikes, nullptr, B, T, 0, y, 0, partial, stream);
 }
 
