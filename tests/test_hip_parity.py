@@ -412,3 +412,51 @@ def test_f32_mfma_beamform_variant(plan2, cfg2):
     f2 = p.snn_pipeline_f32bf(p.to_device(w["sig_in"][None]))
     np.testing.assert_allclose(f2["power"][0].cpu().numpy(), w["power"], rtol=1e-5)
     assert int(f2["argmax"][0]) == int(w["argmax"])
+
+
+@pytest.mark.parametrize(
+    "C,G,T,n_nir",
+    [
+        (14, 5, 1, 35),       # one frame, one DoA tile (NGW = 1)
+        (14, 128, 15, 35),    # shorter than a 16-frame tile
+        (14, 200, 16, 1),     # single-tap neuron kernel, NGW = 2
+        (14, 360, 511, 35),   # one frame short of a chunk
+        (14, 360, 512, 4),    # exactly one chunk
+        (14, 360, 513, 50),   # one frame into the second chunk, 50 taps (NK = 17: unrolled part + remainder)
+        (14, 449, 1037, 35),  # NGW = 4 (script-exact DoA grid)
+        (14, 512, 700, 71),   # 32 DoA tiles (largest bf_mat-stationary shape), long kernel
+        (2, 24, 1100, 35),    # single microphone
+        (16, 100, 600, 35),   # C = 16: no channel padding
+        (14, 520, 600, 35),   # 33 DoA tiles: falls back to the time-stationary kernel
+    ],
+)
+def test_lif_beamform_stage_shapes_vs_oracle(torch, C, G, T, n_nir):
+    """Stage API `micloc_lif_beamform_f64`, power-only (bf_mat-stationary kernel where eligible) and with y stored
+    (time-stationary kernel), against the oracle's LIF FIR + beamforming + power on random ternary spike trains."""
+    from haghighatshoarmuir2024_amd.runtime import Plan
+
+    rng = np.random.default_rng(C * 1000 + G + T)
+    M = C // 2
+    B = 3
+    nir = rng.standard_normal(n_nir)
+    W = rng.standard_normal((C, G))
+    p = Plan(M, np.array([0.0, 1.0, 0.0, -1.0]), np.array([1.0]), np.array([1.0]), 2, True)
+    p.set_neuron_kernel(nir)
+    p.set_bf_mat(W)
+    spikes = (rng.integers(-1, 2, size=(B, T, C)) * (rng.random((B, T, C)) < 0.3)).astype(np.int8)
+    sd = torch.from_numpy(spikes).cuda()
+    out_p = p.lif_beamform(sd, want_y=False, want_power=True)
+    out_y = p.lif_beamform(sd, want_y=True, want_power=True)
+    for b in range(B):
+        v = O.lif_fir(spikes[b], nir)
+        y = O.beamform(v, W)
+        power = (y * y).sum(axis=0) / T
+        np.testing.assert_array_equal(out_y["y"][b].cpu().numpy(), y)
+        for out in (out_p, out_y):
+            np.testing.assert_allclose(out["power"][b].cpu().numpy(), power, rtol=1e-12, atol=1e-300)
+            assert int(out["argmax"][b]) == int(np.argmax(out["power"][b].cpu().numpy()))
+    # the two kernels agree on the arg-max unless the two best powers tie to rounding
+    pw = out_y["power"].cpu().numpy()
+    top2 = np.sort(pw, axis=1)[:, -2:]
+    clear = (top2[:, 1] - top2[:, 0]) > 1e-9 * top2[:, 1]
+    np.testing.assert_array_equal(out_p["argmax"].cpu().numpy()[clear], out_y["argmax"].cpu().numpy()[clear])
