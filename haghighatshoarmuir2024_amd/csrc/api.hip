@@ -333,10 +333,10 @@ int micloc_lif_beamform_f64(const micloc_plan *p, const int8_t *spikes, int B, i
     const bool want_power = power || argmax;
     if (want_power && bad_ws(ws, ws_bytes, beamform_partial_bytes(B, T, Gp))) return MICLOC_ERR_WORKSPACE;
     double *partial = want_power ? reinterpret_cast<double *>(ws) : nullptr;
-    HIP_TRY(launch_lif_beamform(p->W, p->ntab, spikes, B, T, y, partial, (hipStream_t)stream));
+    int nch = 0;
+    HIP_TRY(launch_lif_beamform(p->W, p->ntab, spikes, B, T, y, partial, (hipStream_t)stream, &nch));
     if (want_power)
-        HIP_TRY(launch_power_argmax(partial, B, T, beamform_nchunks_ct(T, p->W.CT), Gp, p->G_out, 0, 0, power, argmax,
-                                    (hipStream_t)stream));
+        HIP_TRY(launch_power_argmax(partial, B, T, nch, Gp, p->G_out, 0, 0, power, argmax, (hipStream_t)stream));
     return MICLOC_OK;
 }
 
@@ -381,9 +381,9 @@ int micloc_snn_pipeline_f64(const micloc_plan *p, const double *x, int B, int T,
         const int Gp = 16 * p->W.GT;
         const bool want_power = power || argmax;
         double *partial = want_power ? reinterpret_cast<double *>(base + w.partial) : nullptr;
-        HIP_TRY(launch_lif_beamform(p->W, p->ntab, spk, B, T, y, partial, st));
-        if (want_power)
-            HIP_TRY(launch_power_argmax(partial, B, T, beamform_nchunks_ct(T, p->W.CT), Gp, p->G_out, 0, 0, power, argmax, st));
+        int nch = 0;
+        HIP_TRY(launch_lif_beamform(p->W, p->ntab, spk, B, T, y, partial, st, &nch));
+        if (want_power) HIP_TRY(launch_power_argmax(partial, B, T, nch, Gp, p->G_out, 0, 0, power, argmax, st));
     }
     return MICLOC_OK;
 }

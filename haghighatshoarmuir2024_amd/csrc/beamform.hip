@@ -313,9 +313,8 @@ __global__ __launch_bounds__(BF_THREADS) void beamform_kernel(const int8_t *__re
 // workgroup instead of once per DoA tile, there is no cross-wave reduction at all (a DoA column belongs to one wave),
 // and bf_mat never goes through LDS.  VALU/LDS instructions per 16 MFMAs: ~25 instead of ~50.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int WS_TILES = BF_CHUNK / 16;  // 32 time tiles per workgroup
 
-template <int NG>
+template <int NG, int TILES>
 __device__ __forceinline__ void ws_stage2(const double *Vl, const double *__restrict__ Wp, int Gp, int wv, int l,
                                           int ntile, double *__restrict__ pout)
 {
@@ -335,7 +334,7 @@ __device__ __forceinline__ void ws_stage2(const double *Vl, const double *__rest
         for (int j = 0; j < NG; ++j) sq[j] = 0.0;
 
         auto ldv = [&](int tile, double (&V)[4]) {
-            const double *p = Vl + (size_t)(tile < WS_TILES ? tile : WS_TILES - 1) * 256 + l;
+            const double *p = Vl + (size_t)(tile < TILES ? tile : TILES - 1) * 256 + l;
 #pragma unroll
             for (int k = 0; k < 4; ++k) V[k] = p[64 * k];
         };
@@ -401,7 +400,7 @@ __device__ __forceinline__ void ws_stage2(const double *Vl, const double *__rest
     }
 }
 
-template <int NGW>
+template <int NGW, int NT>
 __global__ __launch_bounds__(BF_THREADS, 4) void beamform_ws_kernel(const int8_t *__restrict__ spikes,
                                                                     const double *__restrict__ ntab_g, int NK,
                                                                     const double *__restrict__ Wp, int GT, int C, int T,
@@ -417,16 +416,18 @@ __global__ __launch_bounds__(BF_THREADS, 4) void beamform_ws_kernel(const int8_t
     const int chunk = blockIdx.x;
     const int nchunks = gridDim.x;
     const int b = blockIdx.y;
-    const int cs = chunk * BF_CHUNK;
+    constexpr int CH = BF_WAVES * NT * 16;  // frames per workgroup
+    constexpr int TILES = CH / 16;
+    const int cs = chunk * CH;
 
     // [ union{ spike tile as fp64 [R][16] , V fragments [32 tiles][4 k-steps][64 lanes] } ][ nir table ]
     // The spikes are converted to fp64 once, while they are staged (each row feeds ~3 time tiles of the Toeplitz
     // product): the LIF loop is then LDS reads + MFMAs only.  VALU instructions do not overlap MFMAs on a gfx950 SIMD
     // (tools/mfma_valu_overlap.hip), so every conversion saved is matrix-pipe time won.
-    const int R = BF_CHUNK + 4 * NK - 16;
+    const int R = CH + 4 * NK - 16;
     double *S = reinterpret_cast<double *>(smem);
     double *Vl = S;
-    double *ntab = S + (R * 16 > WS_TILES * 256 ? R * 16 : WS_TILES * 256);
+    double *ntab = S + (R * 16 > TILES * 256 ? R * 16 : TILES * 256);
     const int ntab_len = 4 * NK + 16;
 
     for (int e = tid; e < ntab_len; e += BF_THREADS) ntab[e] = ntab_g[e];
@@ -479,11 +480,11 @@ __global__ __launch_bounds__(BF_THREADS, 4) void beamform_ws_kernel(const int8_t
     __syncthreads();
 
     // ---- stage 1: membrane fragments of this wave's 4 time tiles ---------------------------------------------
-    const int tb0 = cs + wv * BF_NT * 16;
+    const int tb0 = cs + wv * NT * 16;
     const bool active = tb0 < T;  // wave-uniform
-    double4_t vacc[BF_NT];
+    double4_t vacc[NT];
 #pragma unroll
-    for (int tt = 0; tt < BF_NT; ++tt) vacc[tt] = double4_t{0.0, 0.0, 0.0, 0.0};
+    for (int tt = 0; tt < NT; ++tt) vacc[tt] = double4_t{0.0, 0.0, 0.0, 0.0};
     if (active) {
         const double *sp = S + (size_t)(tb0 - cs + q) * 16 + lc;
         const double *np_ = ntab + (lc - q + 4 * NK - 16 + 15 - 12);  // 12 below the tap row of k-step 0
@@ -491,11 +492,11 @@ __global__ __launch_bounds__(BF_THREADS, 4) void beamform_ws_kernel(const int8_t
         // SIMD cover the LDS latency
         auto kstep = [&](const double *spk_, const double *nir_, int u) {
             const double bn = nir_[12 - 4 * u];  // non-negative immediate offsets only
-            double a[BF_NT];
+            double a[NT];
 #pragma unroll
-            for (int tt = 0; tt < BF_NT; ++tt) a[tt] = spk_[(16 * tt + 4 * u) * 16];
+            for (int tt = 0; tt < NT; ++tt) a[tt] = spk_[(16 * tt + 4 * u) * 16];
 #pragma unroll
-            for (int tt = 0; tt < BF_NT; ++tt)
+            for (int tt = 0; tt < NT; ++tt)
                 vacc[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tt], bn, vacc[tt], 0, 0, 0);
         };
         int ks = 0;
@@ -513,17 +514,17 @@ __global__ __launch_bounds__(BF_THREADS, 4) void beamform_ws_kernel(const int8_t
     }
     __syncthreads();  // every wave is done with the spike tile: the V fragments may overwrite it
     if (active) {
-        if (tb0 + BF_NT * 16 > T) {  // only the wave that straddles the end of the trial masks
+        if (tb0 + NT * 16 > T) {  // only the wave that straddles the end of the trial masks
 #pragma unroll
-            for (int tt = 0; tt < BF_NT; ++tt) {
+            for (int tt = 0; tt < NT; ++tt) {
                 const bool tvalid = (tb0 + 16 * tt + lc) < T;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) vacc[tt][r] = tvalid ? vacc[tt][r] : 0.0;
             }
         }
 #pragma unroll
-        for (int tt = 0; tt < BF_NT; ++tt) {
-            double *vp = Vl + (size_t)(wv * BF_NT + tt) * 256 + l;
+        for (int tt = 0; tt < NT; ++tt) {
+            double *vp = Vl + (size_t)(wv * NT + tt) * 256 + l;
 #pragma unroll
             for (int r = 0; r < 4; ++r) vp[64 * r] = vacc[tt][r];
         }
@@ -532,51 +533,63 @@ __global__ __launch_bounds__(BF_THREADS, 4) void beamform_ws_kernel(const int8_t
 
     // ---- stage 2: this wave's DoA tiles against every time tile of the chunk --------------------------------
     int ntile = (T - cs + 15) >> 4;
-    ntile = ntile > WS_TILES ? WS_TILES : ntile;
+    ntile = ntile > TILES ? TILES : ntile;
     double *pout = partial + ((size_t)b * nchunks + chunk) * Gp;
     // NGW = ceil(GT / 8): every wave owns NGW or NGW - 1 DoA tiles (wave-uniform choice of the instantiation)
     if (wv + BF_WAVES * (NGW - 1) < GT)
-        ws_stage2<NGW>(Vl, Wp, Gp, wv, l, ntile, pout);
+        ws_stage2<NGW, TILES>(Vl, Wp, Gp, wv, l, ntile, pout);
     else
-        ws_stage2<NGW - 1>(Vl, Wp, Gp, wv, l, ntile, pout);
+        ws_stage2<NGW - 1, TILES>(Vl, Wp, Gp, wv, l, ntile, pout);
 }
 
-static size_t ws_lds_bytes(const NeuronTab &nt)
+static size_t ws_lds_bytes(const NeuronTab &nt, int NT)
 {
-    const size_t tile = (size_t)(BF_CHUNK + 4 * nt.NK - 16) * 16, vfrag = (size_t)WS_TILES * 256;
+    const size_t tile = (size_t)(BF_WAVES * NT * 16 + 4 * nt.NK - 16) * 16, vfrag = (size_t)BF_WAVES * NT * 256;
     return ((tile > vfrag ? tile : vfrag) + (size_t)(4 * nt.NK + 16)) * sizeof(double);
 }
 
-template <int NGW>
+template <int NGW, int NT>
 static hipError_t launch_ws_n(const BeamformW &W, const NeuronTab &nt, const int8_t *spikes, int B, int T,
                               double *partial, hipStream_t stream)
 {
-    const size_t lds = ws_lds_bytes(nt);
+    const size_t lds = ws_lds_bytes(nt, NT);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    auto k = &beamform_ws_kernel<NGW>;
+    auto k = &beamform_ws_kernel<NGW, NT>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        160 * 1024);
     if (e != hipSuccess) return e;
-    dim3 grid(beamform_nchunks(T), B), block(BF_THREADS);
+    dim3 grid((T + BF_WAVES * NT * 16 - 1) / (BF_WAVES * NT * 16), B), block(BF_THREADS);
     hipLaunchKernelGGL(k, grid, block, lds, stream, spikes, nt.tab, nt.NK, W.Wp, W.GT, W.C, T, partial);
     return hipGetLastError();
 }
 
+// 16-frame tiles per wave: 4 = 512-frame workgroups (2 = 256-frame ones measured the same alone and slower in the
+// multi-stream sweep)
+constexpr int WS_NT = 4;
+
 static bool ws_eligible(const BeamformW &W, const NeuronTab &nt)
 {
-    return W.CT == 1 && W.GT <= 4 * BF_WAVES && ws_lds_bytes(nt) <= 160 * 1024;
+    return W.CT == 1 && W.GT <= 4 * BF_WAVES && ws_lds_bytes(nt, WS_NT) <= 160 * 1024;
+}
+
+template <int NT>
+static hipError_t launch_ws_nt(const BeamformW &W, const NeuronTab &nt, const int8_t *spikes, int B, int T,
+                               double *partial, hipStream_t stream)
+{
+    switch ((W.GT + BF_WAVES - 1) / BF_WAVES) {
+        case 1: return launch_ws_n<1, NT>(W, nt, spikes, B, T, partial, stream);
+        case 2: return launch_ws_n<2, NT>(W, nt, spikes, B, T, partial, stream);
+        case 3: return launch_ws_n<3, NT>(W, nt, spikes, B, T, partial, stream);
+        case 4: return launch_ws_n<4, NT>(W, nt, spikes, B, T, partial, stream);
+        default: return hipErrorInvalidValue;
+    }
 }
 
 static hipError_t launch_ws(const BeamformW &W, const NeuronTab &nt, const int8_t *spikes, int B, int T,
-                            double *partial, hipStream_t stream)
+                            double *partial, hipStream_t stream, int *nchunks)
 {
-    switch ((W.GT + BF_WAVES - 1) / BF_WAVES) {
-        case 1: return launch_ws_n<1>(W, nt, spikes, B, T, partial, stream);
-        case 2: return launch_ws_n<2>(W, nt, spikes, B, T, partial, stream);
-        case 3: return launch_ws_n<3>(W, nt, spikes, B, T, partial, stream);
-        case 4: return launch_ws_n<4>(W, nt, spikes, B, T, partial, stream);
-        default: return hipErrorInvalidValue;
-    }
+    *nchunks = (T + BF_WAVES * WS_NT * 16 - 1) / (BF_WAVES * WS_NT * 16);
+    return launch_ws_nt<WS_NT>(W, nt, spikes, B, T, partial, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -875,9 +888,10 @@ static hipError_t dispatch_ct(const BeamformW &W, const NeuronTab *nt, const int
 }
 
 hipError_t launch_lif_beamform(const BeamformW &W, const NeuronTab &nt, const int8_t *spikes, int B, int T, double *y,
-                               double *partial, hipStream_t stream)
+                               double *partial, hipStream_t stream, int *nchunks)
 {
-    if (!y && partial && ws_eligible(W, nt)) return launch_ws(W, nt, spikes, B, T, partial, stream);
+    if (!y && partial && ws_eligible(W, nt)) return launch_ws(W, nt, spikes, B, T, partial, stream, nchunks);
+    *nchunks = beamform_nchunks_ct(T, W.CT);
     return dispatch_ct<true>(W, &nt, spikes, nullptr, B, T, 0, y, 0, partial, stream);
 }
 
