@@ -5,28 +5,33 @@
 // The encoder contract is bit-exact, and both the DF2T recurrence and np.cumsum are strictly
 // sequential in time, so the time axis is NOT parallelised: one lane owns one (trial, channel) stream
 // and walks it with the exact operation order of oracle/micloc_oracle.c; parallelism comes from the
-// B x 2M independent streams.  The kernel is therefore bound by the instruction-issue latency of one
-// wave per 64 streams, and everything is arranged to keep that wave's loop short and stall-free:
+// B x 2M independent streams.  The kernel is bound by the instruction-issue latency of single waves
+// (a wave issues at most one instruction of any kind every ~4 cycles), so the work of a time step is
+// spread over a 5-stage wave pipeline (see bandpass_rzcc_fast_kernel) and every stage is written for a
+// minimal instruction count:
 //
-//   * workgroup = 2 waves.  Wave 1 is a LOADER: it streams 32-step x 64-stream input tiles from the
-//     planar [stream][Ts] layout (256-byte coalesced row segments) into a double-buffered, transposed
-//     LDS tile and (for the band-pass-only variants) stores the filtered tile back.  Wave 0 is the
-//     COMPUTE wave: it reads its sample from LDS, so no global load ever sits in front of its global
-//     stores in the in-order vmcnt queue (measured: a conditional global store in the serial loop cost
-//     a vmcnt(0) drain per chunk and 2.5x the loop time).
-//   * detection is branch-free: per step two fp64 compares maintain (dir, left) = direction and index
-//     of the last strict change of the cumulative sum; a maximum completes when c falls after a rise
-//     (scipy _local_maxima_1d: plateau -> midpoint, edges never peaks), minima mirror it.  Candidates
-//     are written unconditionally into a per-lane LDS ring; the write index only advances on an event.
-//   * scipy's _select_by_peak_distance (greedy by descending priority, later peak wins ties) only
-//     couples peaks closer than `distance`, so the candidate list splits into independent clusters at
-//     every same-polarity gap >= distance.  After each 32-step tile the compute wave walks the NEW
+//   * LOADER wave: 16-step x 64-stream input tiles from the planar [stream][Ts] layout (in-phase channels
+//     straight from the rolled input frames) into a transposed LDS tile; two register sets keep the loads
+//     of two tiles in flight.  No global load ever sits in front of a global store in another wave's
+//     in-order vmcnt queue (measured: a conditional global store in the serial loop cost a vmcnt(0) drain
+//     per chunk and 2.5x the loop time).
+//   * FILTER wave: DF2T recurrence + cumulative sum, in place in LDS.
+//   * DETECT wave: branch-free local-extremum detector.  Per step two fp64 compares give wave-level
+//     lane masks (rise / fall); the direction of the last strict change lives in lane masks too and is
+//     updated on the SALU; a maximum completes when c falls after a rise (scipy _local_maxima_1d:
+//     plateau -> midpoint, edges never peaks), minima mirror it.  Candidates are written unconditionally
+//     into a per-lane LDS ring; the write index only advances on an event (add-with-carry of the mask).
+//   * SELECT waves (one per polarity): scipy's _select_by_peak_distance (greedy by descending priority,
+//     later peak wins ties) only couples peaks closer than `distance`, so the candidate list splits into
+//     independent clusters at every same-polarity gap >= distance.  After each tile the wave walks the NEW
 //     events (not the time steps), closes finished clusters, resolves them in LDS and scatters the kept
 //     peaks as +1 / -1 bytes into the zero-initialised [B][T][C] spike tensor.
 //   * a cluster that outgrows the LDS ring (pathological inputs: long runs of close peaks) flags its
 //     stream; flagged streams are redone by a slow list-based kernel with unbounded capacity, so the
 //     result is exact for every input.
 #include "micloc_internal.h"
+
+#include <type_traits>
 
 namespace micloc {
 
@@ -60,10 +65,11 @@ struct Iir {
 };
 
 // Greedy min-distance selection inside one cluster.  Entries live at list indices s, s+stride, ... < e;
-// word = (position << 1) | polarity, complemented once decided.  `at(i)` maps a list index to storage.
+// word >> 1 = position (the low bit is free for the caller), complemented once decided; priority = sgn * value.
+// `at(i)` maps a list index to storage.
 template <typename WordAt, typename ValAt>
 __device__ __forceinline__ void resolve_cluster(int s, int e, int stride, int w, int8_t mark, int8_t *sp, int C,
-                                                WordAt word_at, ValAt val_at)
+                                                WordAt word_at, ValAt val_at, double sgn)
 {
     int remaining = (e - s + stride - 1) / stride;
     while (remaining > 0) {
@@ -72,7 +78,7 @@ __device__ __forceinline__ void resolve_cluster(int s, int e, int stride, int w,
         for (int k = s; k < e; k += stride) {
             const int wk = *word_at(k);
             if (wk < 0) continue;
-            const double vk = *val_at(k);
+            const double vk = *val_at(k) * sgn;
             if (best < 0 || vk >= bv) {  // >= : equal priority -> the later peak wins (stable sort order)
                 best = k;
                 bv = vk;
@@ -105,18 +111,141 @@ __device__ __forceinline__ void resolve_cluster(int s, int e, int stride, int w,
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Fast path: a 4-stage wave pipeline over 16-step tiles (one barrier per tile).
-//   wave L (loader)  tile k+1 -> LDS (loads issued one tile earlier, into registers), stores filtered tiles
+// Fast path: a wave pipeline over 16-step tiles (one barrier per tile).
+//   wave L (loader)  tile k+1 -> LDS (loads issued two tiles earlier, into registers), stores filtered tiles
 //   wave F (filter)  tile k  : x -> band-pass -> cumulative sum, in place in LDS
 //   wave D (detect)  tile k-1: local maxima / minima of the cumulative sum -> candidate ring
-//   wave S (select)  tile k-2: walks the new candidates, closes clusters, min-distance greedy, scatters spikes
+//   waves S0, S1 (select) tile k-2: walk the new candidates of one polarity each, close clusters, min-distance
+//                    greedy, scatter spikes
 // Each stage is a different wave of the workgroup, i.e. a different SIMD of the CU, so the serial chain of
 // one stream costs max(stage) instructions per time step instead of their sum.
 // ---------------------------------------------------------------------------------------------------
 constexpr int RZ_MT = 16;
 
+// ---- detect-stage helpers: per-lane updates driven by wave-level lane masks (SGPR pairs) ------------------------
+// v += 1 in the lanes of m (one VALU instruction: add with carry-in)
+__device__ __forceinline__ int add_lane_mask(int v, uint64_t m)
+{
+    uint64_t carry_out;
+    asm("v_addc_co_u32_e64 %0, %1, %0, 0, %2" : "+v"(v), "=s"(carry_out) : "s"(m));
+    return v;
+}
+// v = J in the lanes of m (J an inline constant: the lane mask is the only scalar operand)
+template <int J>
+__device__ __forceinline__ int set_lane_mask(int v, uint64_t m)
+{
+    asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(v) : "n"(J), "s"(m));
+    return v;
+}
+
+struct DetectState {
+    double prev;    // previous value of the cumulative sum (NaN before the first sample: no event at t = 0)
+    int lrel;       // time of the last strict change, relative to the current tile
+    int n;          // candidates appended so far
+    uint64_t dpos;  // lanes whose last strict change was a rise
+    uint64_t dneg;  // ... a fall
+    uint64_t ffall; // lanes whose FIRST strict change was a fall (their first candidate is a minimum)
+};
+
+// One time step of the branch-free local-extremum detector (scipy _local_maxima_1d semantics, see the file header).
+// 8 VALU instructions: two fp64 compares, the append counter, the plateau edge, the candidate word and three for the
+// ring address; everything that concerns the direction of the last change is SALU work on lane masks.
+template <int J, typename RingP, typename RingV>
+__device__ __forceinline__ void detect_step(DetectState &d, double c, int word_base, uint64_t bip, int lane, RingP &ringP,
+                                            RingV &ringV)
+{
+    const uint64_t rise = __builtin_amdgcn_fcmp(c, d.prev, 2);  // ordered >
+    const uint64_t fall = __builtin_amdgcn_fcmp(c, d.prev, 4);  // ordered <
+    const uint64_t ev = (fall & d.dpos) | (bip & rise & d.dneg);
+    const int slot = d.n & (RZ_RING - 1);  // unconditional store; consumed only if n advances
+    ringP[slot][lane] = d.lrel + word_base + J;  // left + t - 1; position = word >> 1 (plateau midpoint)
+    ringV[slot][lane] = d.prev;                  // plateau value; minima negate it when they compare
+    d.n = add_lane_mask(d.n, ev);
+    d.ffall |= fall & ~(d.dpos | d.dneg);
+    d.lrel = set_lane_mask<J>(d.lrel, rise | fall);
+    d.dpos = rise | (d.dpos & ~fall);
+    d.dneg = fall | (d.dneg & ~rise);
+    d.prev = c;
+}
+
+template <int J0, int U, typename RingP, typename RingV>
+__device__ __forceinline__ void detect_append(DetectState &d, const double (&c)[RZ_MT], const uint64_t (&chg)[8],
+                                              const uint64_t (&ev)[8], int word_base, int lane, RingP &ringP, RingV &ringV)
+{
+    if constexpr (U < 8) {
+        constexpr int J = J0 + U;
+        const int slot = d.n & (RZ_RING - 1);  // unconditional store; consumed only if n advances
+        ringP[slot][lane] = d.lrel + word_base + J;  // left + t - 1; position = word >> 1 (plateau midpoint)
+        ringV[slot][lane] = J ? c[J ? J - 1 : 0] : d.prev;  // plateau value; minima negate it when they compare
+        d.n = add_lane_mask(d.n, ev[U]);
+        d.lrel = set_lane_mask<J>(d.lrel, chg[U]);
+        detect_append<J0, U + 1>(d, c, chg, ev, word_base, lane, ringP, ringV);
+    }
+}
+
+// Full tile in three phases per half of 8 steps, so that the VALU -> SALU -> VALU round trip of a step (compare, mask
+// logic, per-lane update) is paid once per phase instead of once per step:
+//   A  16 fp64 compares (independent: rise / fall of step j need only c[j-1], c[j])            -> lane masks
+//   B  the direction recurrences and the event masks, pure SALU
+//   C  per-lane appends: ring address, candidate word + value, counter, plateau edge
+// MODE 0: general (some lane has not seen a strict change yet; polarity switch is a run-time mask)
+// MODE 1 / 2: every lane has a direction, so "last change was a fall" is simply ~dpos; bipolar / unipolar fixed at
+//             compile time.  6 instead of 12 SALU instructions per step -- they count: a single wave issues at most one
+//             instruction of ANY kind every ~4 cycles, and this wave is one stage of a latency-bound pipeline.
+template <int J0, int MODE, typename RingP, typename RingV>
+__device__ __forceinline__ void detect_half(DetectState &d, const double (&c)[RZ_MT], int word_base, uint64_t bip, int lane,
+                                            RingP &ringP, RingV &ringV)
+{
+    uint64_t rise[8], fall[8], ev[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const double p = (J0 + u) ? c[(J0 + u ? J0 + u : 1) - 1] : d.prev;
+        rise[u] = __builtin_amdgcn_fcmp(c[J0 + u], p, 2);  // ordered >
+        fall[u] = __builtin_amdgcn_fcmp(c[J0 + u], p, 4);  // ordered <
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        if (MODE == 0) {
+            ev[u] = (fall[u] & d.dpos) | (bip & rise[u] & d.dneg);
+            d.ffall |= fall[u] & ~(d.dpos | d.dneg);
+            d.dpos = rise[u] | (d.dpos & ~fall[u]);
+            d.dneg = fall[u] | (d.dneg & ~rise[u]);
+        } else {
+            ev[u] = MODE == 1 ? ((fall[u] & d.dpos) | (rise[u] & ~d.dpos)) : (fall[u] & d.dpos);
+            d.dpos = rise[u] | (d.dpos & ~fall[u]);
+        }
+        rise[u] |= fall[u];  // strict change
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    detect_append<J0, 0>(d, c, rise, ev, word_base, lane, ringP, ringV);
+}
+
+template <int MODE, typename RingP, typename RingV>
+__device__ __forceinline__ void detect_full(DetectState &d, const double (&c)[RZ_MT], int word_base, uint64_t bip, int lane,
+                                            RingP &ringP, RingV &ringV)
+{
+    detect_half<0, MODE>(d, c, word_base, bip, lane, ringP, ringV);
+    detect_half<8, MODE>(d, c, word_base, bip, lane, ringP, ringV);
+    if (MODE != 0) d.dneg = ~d.dpos;
+    d.prev = c[RZ_MT - 1];
+}
+
+// last, partial tile of a stream
+template <int J, typename Tile, typename RingP, typename RingV>
+__device__ __forceinline__ void detect_partial(DetectState &d, const Tile &tile, int steps, int word_base, uint64_t bip,
+                                               int lane, RingP &ringP, RingV &ringV)
+{
+    if constexpr (J < RZ_MT) {
+        if (J < steps) {  // uniform
+            detect_step<J>(d, tile[J][lane], word_base, bip, lane, ringP, ringV);
+            detect_partial<J + 1>(d, tile, steps, word_base, bip, lane, ringP, ringV);
+        }
+    }
+}
+
 template <int N, bool WANT_PRE, bool WANT_SPIKES>
-__global__ __launch_bounds__(256) void bandpass_rzcc_fast_kernel(const double *__restrict__ h,
+__global__ __launch_bounds__(320) void bandpass_rzcc_fast_kernel(const double *__restrict__ h,
                                                                   double *__restrict__ pre,
                                                                   int8_t *__restrict__ spikes,
                                                                   int *__restrict__ flag_count,
@@ -129,8 +258,11 @@ __global__ __launch_bounds__(256) void bandpass_rzcc_fast_kernel(const double *_
     __shared__ double ringV[WANT_SPIKES ? RZ_RING : 1][64];
     __shared__ int ringP[WANT_SPIKES ? RZ_RING : 1][64];
     __shared__ int nPub[64];
+    __shared__ int polPub[64];  // 1: the stream's first candidate is a minimum (candidates alternate from there)
+    __shared__ int deadPub[64];
 
-    const int wave = threadIdx.x >> 6;  // 0: filter, 1: loader, 2: detect, 3: select
+    // 0: loader, 1: filter, 2: detect, 3: select maxima, 4: select minima (wave 4 shares its SIMD with the loader)
+    const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
     const int base = blockIdx.x * 64;
     const int NM = (T + RZ_MT - 1) / RZ_MT;
@@ -138,12 +270,12 @@ __global__ __launch_bounds__(256) void bandpass_rzcc_fast_kernel(const double *_
     const int lane_g = base + lane;
     const bool active = lane_g < nlanes;
 
-    if (wave == 1) {
+    if (wave == 0) {
         // ------------------------------------ loader ---------------------------------------------------
         const int tl = lane & 15;  // time offset inside the tile
         const int sq = lane >> 4;  // stream slot 0..3 of each group of four
         const bool full_block = base + 64 <= nlanes;
-        double v[16];
+        double v[2][16];  // two register sets: the loads of tile m are issued two tiles before they are written to LDS
         // Per-stream source.  Quadrature channels (and everything when xin == nullptr) come from the planar STHT
         // buffer h; with xin != nullptr the in-phase channels c < M are read straight from the input frames,
         // x[b][(t - L/2) mod T][c]  (np.roll, snn_beamformer.py:325), so the STHT kernel need not write them.
@@ -158,17 +290,19 @@ __global__ __launch_bounds__(256) void bandpass_rzcc_fast_kernel(const double *_
             pb[j] = rolled[j] ? xin + (size_t)bb * T * M + cc : h + (size_t)g * Ts;
         }
         const int sh = shift % T;
-        auto issue_loads = [&](int m) {
+        auto issue_loads = [&](int m, auto set) {
+            constexpr int S = decltype(set)::value;
             const int t = m * RZ_MT + tl;
             const int tc = t < Ts ? t : Ts - 1;  // clamp: samples past T are never used
             int tr = (t < T ? t : T - 1) - sh;
             tr = tr < 0 ? tr + T : tr;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) v[j] = rolled[j] ? pb[j][(size_t)tr * M] : pb[j][tc];
+            for (int j = 0; j < 16; ++j) v[S][j] = rolled[j] ? pb[j][(size_t)tr * M] : pb[j][tc];
         };
-        auto write_tile = [&](int buf) {
+        auto write_tile = [&](int buf, auto set) {
+            constexpr int S = decltype(set)::value;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) X[buf][tl][4 * j + sq] = v[j];
+            for (int j = 0; j < 16; ++j) X[buf][tl][4 * j + sq] = v[S][j];
         };
         auto store_tile = [&](int m) {
             const int t = m * RZ_MT + tl;
@@ -185,20 +319,33 @@ __global__ __launch_bounds__(256) void bandpass_rzcc_fast_kernel(const double *_
                 }
             }
         };
-        issue_loads(0);
-        write_tile(0);
-        if (NM > 1) issue_loads(1);
+        using set0 = std::integral_constant<int, 0>;
+        using set1 = std::integral_constant<int, 1>;
+        // Loads and LDS writes are unconditional (tile index clamped; a tile past the end lands in a buffer nobody
+        // reads): with straight-line code the compiler's s_waitcnt vmcnt(N) leaves the younger register set in flight.
+        auto clampm = [&](int m) { return m < NM ? m : NM - 1; };
+        issue_loads(0, set0{});
+        write_tile(0, set0{});
+        issue_loads(clampm(1), set1{});
+        issue_loads(clampm(2), set0{});
         __syncthreads();
-        for (int k = 0; k < NSTEP; ++k) {
-            if (k + 1 < NM) write_tile((k + 1) % 3);
-            if (k + 2 < NM) issue_loads(k + 2);
+        // iteration k writes tile k+1 (register set (k+1) & 1) and refills that set with tile k+3
+        auto iter = [&](int k, auto set) {
+            write_tile((k + 1) % 3, set);
+            issue_loads(clampm(k + 3), set);
             if (WANT_PRE && k >= 1 && k <= NM) store_tile(k - 1);
             __syncthreads();
+        };
+        int k = 0;
+        for (; k + 1 < NSTEP; k += 2) {
+            iter(k, set1{});
+            iter(k + 1, set0{});
         }
+        if (k < NSTEP) iter(k, set1{});
         return;
     }
 
-    if (wave == 0) {
+    if (wave == 1) {
         // ------------------------------------ filter ---------------------------------------------------
         Iir<N> iir;
         iir.init();
@@ -232,41 +379,40 @@ __global__ __launch_bounds__(256) void bandpass_rzcc_fast_kernel(const double *_
 
     if (wave == 2) {
         // ------------------------------------ detect ---------------------------------------------------
-        // dir  = direction of the last strict change of c (+1 rise, -1 fall, 0 none yet); left = its time index.
         // A maximum completes when c falls after a rise: plateau [left, t-1] -> position (left+t-1)>>1, priority =
         // plateau value = prev.  Minima mirror this (priority -prev).  Maxima and minima alternate strictly, so both
-        // share one candidate list, tagged by the low bit of the stored word.
-        double prev = __builtin_nan("");  // comparisons with NaN are false: no event at t = 0
-        int left = 0, dir = 0, n = 0;
+        // share one candidate list and the polarity of candidate i is (first polarity) ^ (i & 1).
+        DetectState d;
+        d.prev = __builtin_nan("");
+        d.lrel = 0;
+        d.n = 0;
+        d.dpos = d.dneg = d.ffall = 0;
+        const uint64_t bip = bipolar ? ~0ull : 0ull;
         nPub[lane] = 0;
+        polPub[lane] = 0;
         __syncthreads();
         for (int k = 0; k < NSTEP; ++k) {
             if (k >= 1 && k <= NM) {
                 const int m = k - 1;
-                const int buf = m % 3;
                 const int tbase = m * RZ_MT;
                 const int steps = (T - tbase) < RZ_MT ? (T - tbase) : RZ_MT;
-                auto one = [&](int j) {
-                    const double c = X[buf][j][lane];
-                    const int t = tbase + j;
-                    const bool rise = c > prev;
-                    const bool fall = c < prev;
-                    const bool ev = (fall && dir > 0) || (bipolar && rise && dir < 0);
-                    const int slot = n & (RZ_RING - 1);  // unconditional store; consumed only if n advances
-                    ringP[slot][lane] = ((left + t - 1) & ~1) | (rise ? 1 : 0);
-                    ringV[slot][lane] = rise ? -prev : prev;
-                    n += ev ? 1 : 0;
-                    left = (rise || fall) ? t : left;
-                    dir = rise ? 1 : (fall ? -1 : dir);
-                    prev = c;
-                };
+                // left + t - 1 = (tbase + lrel) + (tbase + j) - 1
                 if (steps == RZ_MT) {
+                    double c[RZ_MT];
 #pragma unroll
-                    for (int j = 0; j < RZ_MT; ++j) one(j);
+                    for (int j = 0; j < RZ_MT; ++j) c[j] = X[m % 3][j][lane];
+                    if ((d.dpos | d.dneg) != ~0ull)  // uniform
+                        detect_full<0>(d, c, 2 * tbase - 1, bip, lane, ringP, ringV);
+                    else if (bipolar)
+                        detect_full<1>(d, c, 2 * tbase - 1, bip, lane, ringP, ringV);
+                    else
+                        detect_full<2>(d, c, 2 * tbase - 1, bip, lane, ringP, ringV);
                 } else {
-                    for (int j = 0; j < steps; ++j) one(j);
+                    detect_partial<0>(d, X[m % 3], steps, 2 * tbase - 1, bip, lane, ringP, ringV);
                 }
-                nPub[lane] = n;
+                d.lrel -= RZ_MT;
+                nPub[lane] = d.n;
+                polPub[lane] = (int)((d.ffall >> lane) & 1);
             }
             __syncthreads();
         }
@@ -274,62 +420,58 @@ __global__ __launch_bounds__(256) void bandpass_rzcc_fast_kernel(const double *_
     }
 
     // ---------------------------------------- select -------------------------------------------------------
-    int n_done = 0;
-    int s0 = -1, s1 = -1;  // first list index of the open cluster per polarity (-1: none)
-    int l0 = 0, l1 = 0;    // position of the last candidate per polarity
-    bool dead = !active;   // ring overflow (or lane out of range): stop selecting; redone by the fallback kernel
+    // One wave per polarity (wave 3: maxima, wave 4: minima).  Candidates alternate strictly, so a polarity owns every
+    // second ring entry from its first one on; the two waves never touch the same entry.
+    const int mypol = wave - 3;
+    const bool mine = bipolar || mypol == 0;
     const int stride = bipolar ? 2 : 1;
+    int i_next = -1;      // next own list index to examine (-1: the stream has no candidate yet)
+    int s_open = -1;      // first list index of the open cluster (-1: none)
+    int l_last = 0;       // position of the last own candidate
+    bool dead = !active;  // ring overflow (or lane out of range): stop selecting; redone by the fallback kernel
     const int b = active ? lane_g / C : 0;
     const int ch = active ? lane_g - b * C : 0;
     int8_t *sp = spikes + (size_t)b * T * C + ch;
+    const int8_t mark = mypol ? -1 : 1;
+    const double sgn = mypol ? -1.0 : 1.0;
     auto word_at = [&](int i) { return &ringP[i & (RZ_RING - 1)][lane]; };
     auto val_at = [&](int i) { return &ringV[i & (RZ_RING - 1)][lane]; };
-    auto close_cluster = [&](int s, int e, int pol, int lastpos) {
-        const int8_t mark = pol ? -1 : 1;
+    auto close_cluster = [&](int s, int e, int lastpos) {
         if (e - s <= stride)
             sp[(size_t)lastpos * C] = mark;
         else
-            resolve_cluster(s, e, stride, w, mark, sp, C, word_at, val_at);
+            resolve_cluster(s, e, stride, w, mark, sp, C, word_at, val_at, sgn);
     };
+    if (mypol == 0) deadPub[lane] = 0;
     __syncthreads();
     for (int k = 0; k < NSTEP; ++k) {
-        if (k >= 2) {
+        if (k >= 2 && mine) {
             const int n = nPub[lane];  // candidates published by the detect wave before the last barrier
-            for (int i = n_done; __any(!dead && i < n); ++i) {
-                if (!dead && i < n) {
-                    const int word = *word_at(i);
-                    const int pol = word & 1;
-                    const int pos = word >> 1;
-                    const int sp_i = pol ? s1 : s0;
-                    const int lp = pol ? l1 : l0;
-                    int snew = sp_i;
-                    if (sp_i >= 0 && pos - lp >= w) {
-                        close_cluster(sp_i, i, pol, lp);
-                        snew = i;
+            if (i_next < 0 && n > 0) i_next = bipolar ? (polPub[lane] ^ mypol) : 0;
+            while (__any(!dead && i_next >= 0 && i_next < n)) {
+                if (!dead && i_next >= 0 && i_next < n) {
+                    const int i = i_next;
+                    const int pos = *word_at(i) >> 1;
+                    if (s_open >= 0 && pos - l_last >= w) {
+                        close_cluster(s_open, i, l_last);
+                        s_open = i;
                     }
-                    if (sp_i < 0) snew = i;
-                    if (pol) {
-                        s1 = snew;
-                        l1 = pos;
-                    } else {
-                        s0 = snew;
-                        l0 = pos;
-                    }
+                    if (s_open < 0) s_open = i;
+                    l_last = pos;
+                    i_next = i + stride;
                 }
             }
-            n_done = n;
             // the detect wave runs up to two tiles ahead of what has been selected: everything still open must
             // survive 2 * RZ_MT more appends
-            const int oldest = (s0 >= 0 && (s1 < 0 || s0 < s1)) ? s0 : (s1 >= 0 ? s1 : n);
+            const int oldest = s_open >= 0 ? s_open : n;
             if (!dead && n - oldest >= RZ_RING - 2 * RZ_MT) dead = true;
         }
         __syncthreads();
     }
-    if (active) {
+    if (active && mine) {
         if (!dead) {
-            if (s0 >= 0) close_cluster(s0, n_done, 0, l0);
-            if (s1 >= 0) close_cluster(s1, n_done, 1, l1);
-        } else {
+            if (s_open >= 0) close_cluster(s_open, nPub[lane], l_last);
+        } else if (atomicExch(&deadPub[lane], 1) == 0) {  // flag the stream once, whichever polarity overflowed
             const int kk = atomicAdd(flag_count, 1);
             flag_list[kk] = lane_g;
         }
@@ -405,7 +547,7 @@ __global__ __launch_bounds__(64) void rzcc_fallback_kernel(const double *__restr
                 if (e - s <= stride)
                     sp[(size_t)plast * C] = mark;
                 else
-                    resolve_cluster(s, e, stride, w, mark, sp, C, word_at, val_at);
+                    resolve_cluster(s, e, stride, w, mark, sp, C, word_at, val_at, 1.0);
                 s = i;
             }
             if (!has) break;
@@ -452,7 +594,7 @@ static void launch_rz(const IirCoef &coef, const double *h, int nlanes, int C, i
                       double *pre, int8_t *spikes, int *flag_count, int *flag_list, int *plist, double *vlist,
                       const double *xin, int M, int shift, hipStream_t stream)
 {
-    dim3 grid((nlanes + 63) / 64), block(spikes ? 256 : 128);
+    dim3 grid((nlanes + 63) / 64), block(spikes ? 320 : 128);
     if (pre && spikes)
         hipLaunchKernelGGL((bandpass_rzcc_fast_kernel<N, true, true>), grid, block, 0, stream, h, pre, spikes,
                            flag_count, flag_list, coef, nlanes, C, T, Ts, w, bipolar, xin, M, shift);
