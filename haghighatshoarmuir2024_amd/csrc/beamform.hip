@@ -314,7 +314,7 @@ __global__ __launch_bounds__(BF_THREADS) void beamform_kernel(const int8_t *__re
 // and bf_mat never goes through LDS.  VALU/LDS instructions per 16 MFMAs: ~25 instead of ~50.
 // ---------------------------------------------------------------------------------------------------------------
 
-template <int NG, int TILES>
+template <int NG, int TILES, bool PING>
 __device__ __forceinline__ void ws_stage2(const double *Vl, const double *__restrict__ Wp, int Gp, int wv, int l,
                                           int ntile, double *__restrict__ pout)
 {
@@ -354,7 +354,26 @@ __device__ __forceinline__ void ws_stage2(const double *Vl, const double *__rest
                 for (int j = 0; j < NG; ++j) sq[j] = __builtin_fma(acc[j][r], acc[j][r], sq[j]);
         };
 
-        if (ntile > 0) {
+        if (!PING) {
+            // register-lean form (three workgroups per CU): one accumulator set; the squares wait for their own MFMAs
+            // and the other waves of the SIMD fill the gap
+            double VA[4], VB[4];
+            double4_t acc[NG];
+            if (ntile > 0) ldv(0, VA);
+            int t = 0;
+            for (; t + 1 < ntile; t += 2) {
+                ldv(t + 1, VB);
+                mm(VA, acc);
+                sqr(acc);
+                ldv(t + 2, VA);
+                mm(VB, acc);
+                sqr(acc);
+            }
+            if (t < ntile) {
+                mm(VA, acc);
+                sqr(acc);
+            }
+        } else if (ntile > 0) {
             double VA[4], VB[4];
             double4_t accA[NG], accB[NG];
             ldv(0, VA);
@@ -363,8 +382,9 @@ __device__ __forceinline__ void ws_stage2(const double *Vl, const double *__rest
             int t = 0;
             // Each half of the loop body = 4 NG MFMAs of one time tile + the 4 NG squares of the previous one + the
             // fragment loads of the next.  Left alone the compiler folds both accumulator sets into one and runs
-            // MFMAs -> s_nop -> squares back to back; the group barriers pin the interleaving (one VALU op in the
-            // shadow of every 64-cycle MFMA), the full barriers keep the two halves apart.
+            // MFMAs -> s_nop -> squares back to back; the group barriers pin "all MFMAs, then all squares of the
+            // previous tile" (VALU work is never hidden behind MFMAs on this SIMD, but batching it pays the
+            // MFMA<->VALU switch once per tile), the full barriers keep the two halves apart.
             auto pin = [&]() {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // MFMA
                 __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);       // DS read (next tile's fragments)
@@ -401,7 +421,7 @@ __device__ __forceinline__ void ws_stage2(const double *Vl, const double *__rest
 }
 
 template <int NGW, int NT>
-__global__ __launch_bounds__(BF_THREADS, 4) void beamform_ws_kernel(const int8_t *__restrict__ spikes,
+__global__ __launch_bounds__(BF_THREADS, NT == 2 ? 6 : 4) void beamform_ws_kernel(const int8_t *__restrict__ spikes,
                                                                     const double *__restrict__ ntab_g, int NK,
                                                                     const double *__restrict__ Wp, int GT, int C, int T,
                                                                     double *__restrict__ partial)
@@ -537,9 +557,9 @@ __global__ __launch_bounds__(BF_THREADS, 4) void beamform_ws_kernel(const int8_t
     double *pout = partial + ((size_t)b * nchunks + chunk) * Gp;
     // NGW = ceil(GT / 8): every wave owns NGW or NGW - 1 DoA tiles (wave-uniform choice of the instantiation)
     if (wv + BF_WAVES * (NGW - 1) < GT)
-        ws_stage2<NGW, TILES>(Vl, Wp, Gp, wv, l, ntile, pout);
+        ws_stage2<NGW, TILES, NT != 2>(Vl, Wp, Gp, wv, l, ntile, pout);
     else
-        ws_stage2<NGW - 1, TILES>(Vl, Wp, Gp, wv, l, ntile, pout);
+        ws_stage2<NGW - 1, TILES, NT != 2>(Vl, Wp, Gp, wv, l, ntile, pout);
 }
 
 static size_t ws_lds_bytes(const NeuronTab &nt, int NT)
@@ -563,9 +583,11 @@ static hipError_t launch_ws_n(const BeamformW &W, const NeuronTab &nt, const int
     return hipGetLastError();
 }
 
-// 16-frame tiles per wave: 4 = 512-frame workgroups (2 = 256-frame ones measured the same alone and slower in the
-// multi-stream sweep)
-constexpr int WS_NT = 4;
+// 16-frame tiles per wave.  2 = 256-frame workgroups, 38 KB of LDS and (with the single-accumulator stage 2) 66 VGPRs:
+// three workgroups per CU, whose staging / LIF / beamforming phases overlap better than those of two 512-frame ones
+// (1.15 ms against 1.21 ms on the sweep shape; the multi-stream sweep, where other kernels fill those gaps anyway,
+// is unchanged).
+constexpr int WS_NT = 2;
 
 static bool ws_eligible(const BeamformW &W, const NeuronTab &nt)
 {
