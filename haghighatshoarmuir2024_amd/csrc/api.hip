@@ -481,9 +481,9 @@ int micloc_lif_beamform_f32(const micloc_plan *p, const int8_t *spikes, int B, i
     const int Gp = 16 * p->W.GT;
     if (bad_ws(ws, ws_bytes, beamform_partial_bytes(B, T, Gp))) return MICLOC_ERR_WORKSPACE;
     double *partial = reinterpret_cast<double *>(ws);
-    HIP_TRY(launch_lif_beamform_f32(p->W, p->ntab, spikes, B, T, partial, (hipStream_t)stream));
-    HIP_TRY(launch_power_argmax(partial, B, T, beamform_nchunks(T), Gp, p->G_out, 0, 0, power, argmax,
-                                (hipStream_t)stream));
+    int nch = 0;
+    HIP_TRY(launch_lif_beamform_f32(p->W, p->ntab, spikes, B, T, partial, (hipStream_t)stream, &nch));
+    HIP_TRY(launch_power_argmax(partial, B, T, nch, Gp, p->G_out, 0, 0, power, argmax, (hipStream_t)stream));
     return MICLOC_OK;
 }
 

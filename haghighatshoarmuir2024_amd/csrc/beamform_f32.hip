@@ -170,6 +170,178 @@ __global__ __launch_bounds__(F32_THREADS) void beamform_f32_kernel(const int8_t 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// bf_mat-stationary form (same ownership as beamform_ws_kernel in beamform.hip) for up to 16 channels:
+// 256-frame workgroups, spikes staged as fp32, membrane fragments parked in LDS in fragment order, a wave keeps the
+// bf_mat fragments of its own DoA tiles in registers and walks over all 16 time tiles.  Per (time tile, DoA tile): 4
+// MFMAs + 2 v_pk_fma_f32 (running per-lane sum of squares in fp32 over the 64 values of a chunk, combined in fp64).
+// ---------------------------------------------------------------------------------------------------------------
+typedef float float2_t __attribute__((ext_vector_type(2)));
+constexpr int WF_NT = 2;                       // 16-frame tiles per wave
+constexpr int WF_CH = BF_WAVES * WF_NT * 16;   // 256 frames per workgroup
+constexpr int WF_TILES = WF_CH / 16;
+
+template <int NG>
+__device__ __forceinline__ void wsf_stage2(const float *Vl, const double *__restrict__ Wp, int Gp, int wv, int l, int ntile,
+                                           double *__restrict__ pout)
+{
+    if constexpr (NG > 0) {
+        const int lc = l & 15;
+        const int q = l >> 4;
+        float Wf[NG][4];  // k-step r contracts the channels 4q + r
+#pragma unroll
+        for (int j = 0; j < NG; ++j) {
+            const double *wp = Wp + 16 * (wv + BF_WAVES * j) + lc;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) Wf[j][k] = (float)wp[(size_t)(4 * q + k) * Gp];
+        }
+        float2_t sq[NG];
+#pragma unroll
+        for (int j = 0; j < NG; ++j) sq[j] = float2_t{0.f, 0.f};
+        auto ldv = [&](int tile, float (&V)[4]) {
+            const float *p = Vl + (size_t)(tile < WF_TILES ? tile : WF_TILES - 1) * 256 + l;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) V[k] = p[64 * k];
+        };
+        auto mm_sq = [&](const float (&V)[4]) {
+            float4_t acc[NG];
+#pragma unroll
+            for (int j = 0; j < NG; ++j) acc[j] = float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int j = 0; j < NG; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[k], Wf[j][k], acc[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NG; ++j) {
+                const float2_t lo = {acc[j][0], acc[j][1]}, hi = {acc[j][2], acc[j][3]};
+                sq[j] = __builtin_elementwise_fma(lo, lo, sq[j]);
+                sq[j] = __builtin_elementwise_fma(hi, hi, sq[j]);
+            }
+        };
+        float VA[4], VB[4];
+        if (ntile > 0) ldv(0, VA);
+        int t = 0;
+        for (; t + 1 < ntile; t += 2) {
+            ldv(t + 1, VB);
+            mm_sq(VA);
+            ldv(t + 2, VA);
+            mm_sq(VB);
+        }
+        if (t < ntile) mm_sq(VA);
+#pragma unroll
+        for (int j = 0; j < NG; ++j) {
+            const double s = row_sum4_d((double)sq[j][0] + (double)sq[j][1]);
+            if (l < 16) pout[16 * (wv + BF_WAVES * j) + l] = s;
+        }
+    }
+}
+
+template <int NGW>
+__global__ __launch_bounds__(F32_THREADS, 6) void beamform_wsf32_kernel(const int8_t *__restrict__ spikes,
+                                                                         const double *__restrict__ ntab_g, int NK,
+                                                                         const double *__restrict__ Wp, int GT, int C, int T,
+                                                                         double *__restrict__ partial)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int Gp = 16 * GT;
+    const int tid = threadIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l = tid & 63;
+    const int lc = l & 15;
+    const int q = l >> 4;
+    const int chunk = blockIdx.x;
+    const int nchunks = gridDim.x;
+    const int b = blockIdx.y;
+    const int cs = chunk * WF_CH;
+
+    // [ union{ spike tile as fp32 [R][16] , V fragments [16 tiles][4 k-steps][64 lanes] } ][ nir table fp32 ]
+    const int R = WF_CH + 4 * NK - 16;
+    float *S = reinterpret_cast<float *>(smem);
+    float *Vl = S;
+    float *ntab = S + (R * 16 > WF_TILES * 256 ? R * 16 : WF_TILES * 256);
+    const int ntab_len = 4 * NK + 16;
+    for (int e = tid; e < ntab_len; e += F32_THREADS) ntab[e] = (float)ntab_g[e];
+    {
+        const int8_t *sb = spikes + (size_t)b * T * C;
+        const int tau0 = cs + 16 - 4 * NK;
+        const int c = tid & 15;
+        const int cc = c < C ? c : C - 1;
+        constexpr int RP = F32_THREADS / 16;
+        for (int r0 = tid >> 4; r0 < R; r0 += RP * 5) {
+            int8_t v[5];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                int tau = tau0 + r0 + RP * i;
+                tau = tau < 0 ? 0 : (tau >= T ? T - 1 : tau);
+                v[i] = sb[(size_t)tau * C + cc];
+            }
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const int rho = r0 + RP * i;
+                const int tau = tau0 + rho;
+                if (rho < R) S[rho * 16 + c] = (c < C && tau >= 0 && tau < T) ? (float)v[i] : 0.f;
+            }
+        }
+    }
+    __syncthreads();
+
+    const int tb0 = cs + wv * WF_NT * 16;
+    const bool active = tb0 < T;
+    float4_t vacc[WF_NT];
+#pragma unroll
+    for (int tt = 0; tt < WF_NT; ++tt) vacc[tt] = float4_t{0.f, 0.f, 0.f, 0.f};
+    if (active) {
+        const float *sp = S + (size_t)(tb0 - cs + q) * 16 + lc;
+        const float *np_ = ntab + (lc - q + 4 * NK - 16 + 15);
+        for (int ks = 0; ks < NK; ++ks) {
+            const float bn = np_[-4 * ks];
+            float a[WF_NT];
+#pragma unroll
+            for (int tt = 0; tt < WF_NT; ++tt) a[tt] = sp[(16 * tt + 4 * ks) * 16];
+#pragma unroll
+            for (int tt = 0; tt < WF_NT; ++tt) vacc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tt], bn, vacc[tt], 0, 0, 0);
+        }
+    }
+    __syncthreads();  // the spike tile is dead: V fragments may overwrite it
+    if (active) {
+#pragma unroll
+        for (int tt = 0; tt < WF_NT; ++tt) {
+            const bool tvalid = (tb0 + 16 * tt + lc) < T;
+            float *vp = Vl + (size_t)(wv * WF_NT + tt) * 256 + l;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) vp[64 * r] = tvalid ? vacc[tt][r] : 0.f;  // lane: t = lc, channel 4q + r
+        }
+    }
+    __syncthreads();
+
+    int ntile = (T - cs + 15) >> 4;
+    ntile = ntile > WF_TILES ? WF_TILES : ntile;
+    double *pout = partial + ((size_t)b * nchunks + chunk) * Gp;
+    if (wv + BF_WAVES * (NGW - 1) < GT)
+        wsf_stage2<NGW>(Vl, Wp, Gp, wv, l, ntile, pout);
+    else
+        wsf_stage2<NGW - 1>(Vl, Wp, Gp, wv, l, ntile, pout);
+}
+
+static size_t wsf_lds_bytes(const NeuronTab &nt)
+{
+    const size_t tile = (size_t)(WF_CH + 4 * nt.NK - 16) * 16, vfrag = (size_t)WF_TILES * 256;
+    return ((tile > vfrag ? tile : vfrag) + (size_t)(4 * nt.NK + 16)) * sizeof(float);
+}
+
+template <int NGW>
+static hipError_t launch_wsf_n(const BeamformW &W, const NeuronTab &nt, const int8_t *spikes, int B, int T, double *partial,
+                               hipStream_t stream)
+{
+    auto k = &beamform_wsf32_kernel<NGW>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       160 * 1024);
+    if (e != hipSuccess) return e;
+    dim3 grid((T + WF_CH - 1) / WF_CH, B), block(F32_THREADS);
+    hipLaunchKernelGGL(k, grid, block, wsf_lds_bytes(nt), stream, spikes, nt.tab, nt.NK, W.Wp, W.GT, W.C, T, partial);
+    return hipGetLastError();
+}
+
 template <int CT>
 static hipError_t launch_f32_ct(const BeamformW &W, const NeuronTab &nt, const int8_t *spikes, int B, int T,
                                 double *partial, hipStream_t stream)
@@ -191,8 +363,18 @@ static hipError_t launch_f32_ct(const BeamformW &W, const NeuronTab &nt, const i
 }
 
 hipError_t launch_lif_beamform_f32(const BeamformW &W, const NeuronTab &nt, const int8_t *spikes, int B, int T,
-                                   double *partial, hipStream_t stream)
+                                   double *partial, hipStream_t stream, int *nchunks)
 {
+    if (W.CT == 1 && W.GT <= 4 * BF_WAVES && wsf_lds_bytes(nt) <= 160 * 1024) {
+        *nchunks = (T + WF_CH - 1) / WF_CH;
+        switch ((W.GT + BF_WAVES - 1) / BF_WAVES) {
+            case 1: return launch_wsf_n<1>(W, nt, spikes, B, T, partial, stream);
+            case 2: return launch_wsf_n<2>(W, nt, spikes, B, T, partial, stream);
+            case 3: return launch_wsf_n<3>(W, nt, spikes, B, T, partial, stream);
+            default: return launch_wsf_n<4>(W, nt, spikes, B, T, partial, stream);
+        }
+    }
+    *nchunks = beamform_nchunks(T);
     switch (W.CT) {
         case 1: return launch_f32_ct<1>(W, nt, spikes, B, T, partial, stream);
         case 2: return launch_f32_ct<2>(W, nt, spikes, B, T, partial, stream);

@@ -74,7 +74,7 @@ int beamform_nchunks_ct(int T, int CT);  // chunking of the kernel family that s
 
 // fp32-MFMA variant of LIF + beamforming + power (up to 64 channels, bf_mat must fit in LDS)
 hipError_t launch_lif_beamform_f32(const BeamformW &W, const NeuronTab &nt, const int8_t *spikes, int B, int T,
-                                   double *partial, hipStream_t stream);
+                                   double *partial, hipStream_t stream, int *nchunks);
 
 // ---- covariance-form power / membrane covariance ------------------------------------------------------------
 size_t cov_partial_bytes(int B, int T, int CT);
