@@ -27,9 +27,12 @@ def doa_error(doa_est, doa_true):
     return np.arcsin(np.abs(np.sin(doa_est - doa_true)))
 
 
-def gather_shards(local, total, rank, world_size, group=None):
+def gather_shards(local, total, rank, world_size, group=None, bounds=None):
     """All-gather equal-dtype 1-d arrays from contiguous shards; returns the full-length arrays on every rank.
-    `local` is a dict name -> 1-d numpy array (this rank's shard).  Uses torch.distributed when world_size > 1."""
+    `local` is a dict name -> 1-d numpy array (this rank's shard).  Uses torch.distributed when world_size > 1.
+    `bounds(r) -> (lo, hi)` overrides the default `shard_range(total, r, world_size)` partition."""
+    if bounds is None:
+        bounds = lambda r: shard_range(total, r, world_size)  # noqa: E731
     if world_size == 1:
         return {k: np.asarray(v) for k, v in local.items()}
     import torch
@@ -37,7 +40,7 @@ def gather_shards(local, total, rank, world_size, group=None):
 
     backend = dist.get_backend(group)
     dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
-    width = -(-total // world_size)  # padded shard length
+    width = max(bounds(r)[1] - bounds(r)[0] for r in range(world_size))  # padded shard length
     out = {}
     for k, v in local.items():
         v = np.asarray(v)
@@ -48,10 +51,29 @@ def gather_shards(local, total, rank, world_size, group=None):
         full = full.cpu().numpy().reshape(world_size, width)
         parts = []
         for r in range(world_size):
-            lo, hi = shard_range(total, r, world_size)
+            lo, hi = bounds(r)
             parts.append(full[r, : hi - lo])
         out[k] = np.concatenate(parts)
     return out
+
+
+def sharded_design(design_fn, doa_list, rank=0, world_size=1, group=None):
+    """`design_from_template` sharded over the DoA grid (the G columns of bf_mat are independent units):
+    every rank designs the columns of its contiguous DoA shard with `design_fn(doa_sublist) -> [2M, n_local]` and one
+    all-gather assembles the full [2M, G] matrix on every rank (RCCL when the group is "nccl")."""
+    doa_list = np.asarray(doa_list, dtype=np.float64)
+    G = len(doa_list)
+    lo, hi = shard_range(G, rank, world_size)
+    local = np.asarray(design_fn(doa_list[lo:hi]), dtype=np.float64)
+    if local.ndim != 2 or local.shape[1] != hi - lo:
+        raise ValueError(f"design_fn returned shape {local.shape} for {hi - lo} DoAs")
+    rows = local.shape[0]
+    if world_size == 1:
+        return local
+    # one gather of `rows` doubles per DoA: flatten column-major so that a shard is a contiguous run of items
+    flat = gather_shards({"cols": np.ascontiguousarray(local.T).ravel()}, G * rows, rank, world_size, group=group,
+                         bounds=lambda r: tuple(rows * v for v in shard_range(G, r, world_size)))
+    return flat["cols"].reshape(G, rows).T.copy()
 
 
 def device_localizer(beamf, bf_mat, max_batch=1100):
@@ -163,7 +185,8 @@ def main(argv=None):
     freq_inst = freq_range[0] + (freq_range[1] - freq_range[0]) * (time_temp % period) / period
     sig_temp = np.sin(2 * np.pi * np.cumsum(freq_inst) / fs)
     doa_list = np.linspace(-np.pi, np.pi, args.grid)
-    bf_mat = beamf.design_from_template((time_temp, sig_temp), doa_list)
+    # the design is sharded over the DoA grid as well (one all-gather of the columns)
+    bf_mat = sharded_design(lambda doas: beamf.design_from_template((time_temp, sig_temp), doas), doa_list, rank, world)
     res = noisy_target_sweep(beamf, bf_mat, doa_list, num_sim=args.num_sim, seed=args.seed, mode=args.mode, rank=rank, world_size=world)
     if rank == 0:
         print(f"SNR: {res['snr_db_vec']}")

@@ -100,3 +100,50 @@ def _gather_worker(rank, world, port, out_dir):
     np.savez(os.path.join(out_dir, f"g{rank}.npz"), **full)
     dist.barrier()
     dist.destroy_process_group()
+
+
+def _design_worker(rank, world, port, out_dir):
+    import sys
+
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+
+    from haghighatshoarmuir2024_amd.sweep import sharded_design
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    doa_list = np.linspace(-np.pi, np.pi, 11)
+    calls = []
+
+    def design_fn(doas):  # stands in for design_from_template: one unit-norm column per DoA
+        calls.append(len(doas))
+        cols = np.stack([np.cos(np.arange(1, 7) * d) for d in doas], axis=1)
+        return cols / np.linalg.norm(cols, axis=0, keepdims=True)
+
+    W = sharded_design(design_fn, doa_list, rank, world)
+    np.savez(os.path.join(out_dir, f"d{rank}.npz"), W=W, calls=np.asarray(calls))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_design_world3(tmp_path):
+    """bf_mat columns designed on 3 ranks (11 DoAs: shards of 4, 4, 3) and assembled by one all-gather."""
+    import torch.multiprocessing as mp
+
+    from haghighatshoarmuir2024_amd.sweep import sharded_design
+
+    port = _free_port()
+    mp.spawn(_design_worker, args=(3, port, str(tmp_path)), nprocs=3, join=True)
+    doa_list = np.linspace(-np.pi, np.pi, 11)
+    ref = np.stack([np.cos(np.arange(1, 7) * d) for d in doa_list], axis=1)
+    ref /= np.linalg.norm(ref, axis=0, keepdims=True)
+    sizes = []
+    for r in range(3):
+        got = np.load(tmp_path / f"d{r}.npz")
+        np.testing.assert_array_equal(got["W"], ref)
+        sizes.append(int(got["calls"][0]))
+    assert sizes == [4, 4, 3]
+    # single process: the plain call
+    np.testing.assert_array_equal(sharded_design(lambda d: ref[:, : len(d)], doa_list), ref)
+    with pytest.raises(ValueError):
+        sharded_design(lambda d: ref[:, :2], doa_list)
