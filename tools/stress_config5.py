@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """BASELINE config 5 (stress shape): 64-mic random planar array, 96 kHz (960-tap STHT, w = 24, 71-tap neuron kernel),
 1440-DoA grid, T = 9599 frames.  Times the fused pipeline on one GPU for --trials trials (the full sweep is 16 384
-trials over 8 GPUs = 2048 per GPU) and checks two trials against the CPU oracle.  bf_mat: random unit-norm columns
+trials over 8 GPUs = 2048 per GPU); parity of this shape against the CPU oracle is
+tests/test_hip_fullsize.py::test_config5_shape_vs_oracle.  bf_mat: random unit-norm columns
 (designing 1440 DoAs x 1 s x 64 mics is a separate, one-off cost and does not change the hot path's work)."""
 import argparse
 import os
@@ -17,7 +18,6 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--trials", type=int, default=256)
     ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--check", type=int, default=2)
     args = ap.parse_args()
     import torch
 
@@ -55,17 +55,6 @@ def main():
     flops = 2 * len(nir) * 2 * M + 2 * 2 * M * G + 2 * G
     print(f"config 5: {B} trials x {T} frames x {M} mics, G={G}: {dt * 1e3:.1f} ms/step, {B * T / dt:.3e} frames/s, "
           f"beamform+LIF algorithmic {B * T * flops / dt / 1e12:.1f} TFLOP/s (whole pipeline time)")
-    if args.check:
-        from oracle import oracle as O
-
-        full = plan.snn_pipeline(x[: args.check].contiguous(), want_spikes=True, want_power=True)
-        b, a = beamf.bandpass_filter
-        for i in range(args.check):
-            ref = O.snn_chain(x[i].cpu().numpy(), beamf.kernel, b, a, beamf.spk_encoder.robust_width, True, nir, W, want=("spikes", "power"))
-            assert np.array_equal(full["spikes"][i].cpu().numpy(), ref["spikes"])
-            np.testing.assert_allclose(full["power"][i].cpu().numpy(), ref["power"], rtol=1e-12)
-            assert int(full["argmax"][i]) == ref["argmax"]
-        print(f"oracle check ok on {args.check} trials (spikes bit-exact, power 1e-12, same arg-max)")
 
 
 if __name__ == "__main__":
