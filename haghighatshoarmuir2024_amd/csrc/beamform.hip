@@ -17,6 +17,12 @@
 //      kernel in a fixed order (deterministic, no atomics).  The T x G product is only written to
 //      HBM when the caller asks for it (API parity with apply_to_signal).
 //
+// Three kernels share these steps and differ in what a wave keeps stationary:
+//   beamform_ws_kernel    bf_mat fragments in registers, membrane fragments parked in LDS   (<= 16 channels, power
+//                         only: the sweep; the fastest form, see its header for why)
+//   beamform_kernel       membrane fragments of 4 time tiles in registers, bf_mat in LDS      (<= 64 channels, y stored)
+//   beamform_slab_kernel  membrane fragments in registers, bf_mat streamed through LDS slabs  (> 64 channels)
+//
 // Summation order (== oracle): LIF over past samples in chronological order (tau ascending),
 // beamforming over channels ascending; both as fused multiply-add chains starting from +0.
 #include "micloc_internal.h"
@@ -202,8 +208,8 @@ __global__ __launch_bounds__(BF_THREADS) void beamform_kernel(const int8_t *__re
     __syncthreads();  // all waves are done with the spike tile / nir table: `red` may now overwrite them
 
     // ---- stage 2: beamforming + power, one 16-column DoA tile at a time ------------------------------------
-    // Two accumulator sets: the MFMAs of tile gt+1 are issued before the (VALU) epilogue of tile gt, so the
-    // matrix pipe never waits for the squares / shuffles / stores.
+    // Two accumulator sets in the source; the compiler folds them and runs MFMAs -> epilogue back to back, which costs
+    // nothing extra: VALU work is not hidden behind MFMAs on a gfx950 SIMD anyway (tools/mfma_valu_overlap.hip).
     const double *Wsrc = W_LDS ? Wl : Wp;
     const int Ghp = Gp >> 1;  // complex variant: [0, Ghp) real part, [Ghp, Gp) imaginary part
 
