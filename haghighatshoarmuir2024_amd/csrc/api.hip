@@ -362,7 +362,14 @@ int micloc_beamform_c128_f64(const micloc_plan *p, const double *pre, int B, int
 int micloc_snn_pipeline_f64(const micloc_plan *p, const double *x, int B, int T, int8_t *spikes, double *y,
                             double *power, int32_t *argmax, void *ws, size_t ws_bytes, void *stream)
 {
+    return micloc_snn_pipeline_stages_f64(p, x, B, T, spikes, y, power, argmax, ws, ws_bytes, stream, MICLOC_STAGE_ALL);
+}
+
+int micloc_snn_pipeline_stages_f64(const micloc_plan *p, const double *x, int B, int T, int8_t *spikes, double *y,
+                                   double *power, int32_t *argmax, void *ws, size_t ws_bytes, void *stream, int stages)
+{
     if (!p || !x || bad_batch(B) || T < 1 || (!spikes && !y && !power && !argmax)) return MICLOC_ERR_INVALID;
+    if (stages <= 0 || (stages & ~MICLOC_STAGE_ALL)) return MICLOC_ERR_INVALID;
     const bool want_bf = y || power || argmax;
     if (want_bf && (!p->d_ntab || !p->d_W)) return MICLOC_ERR_NOT_SET;
     if (want_bf && p->W_is_complex) return MICLOC_ERR_SHAPE;
@@ -374,10 +381,11 @@ int micloc_snn_pipeline_f64(const micloc_plan *p, const double *x, int B, int T,
     const int Ts = micloc_padded_T(T);
     hipStream_t st = (hipStream_t)stream;
     // the in-phase channels are the rolled input frames: the band-pass kernel reads them from x directly
-    HIP_TRY(launch_stht(p->taps, x, h, B, T, p->M, Ts, st, false));
-    HIP_TRY(launch_bandpass_rzcc(p->iir, h, B * p->C, p->C, T, Ts, p->robust_width, p->bipolar, nullptr, spk,
-                                 base + w.scratch, st, x, p->M, p->taps.shift));
-    if (want_bf) {
+    if (stages & MICLOC_STAGE_STHT) HIP_TRY(launch_stht(p->taps, x, h, B, T, p->M, Ts, st, false));
+    if (stages & MICLOC_STAGE_ENCODE)
+        HIP_TRY(launch_bandpass_rzcc(p->iir, h, B * p->C, p->C, T, Ts, p->robust_width, p->bipolar, nullptr, spk,
+                                     base + w.scratch, st, x, p->M, p->taps.shift));
+    if (want_bf && (stages & MICLOC_STAGE_BEAMFORM)) {
         const int Gp = 16 * p->W.GT;
         const bool want_power = power || argmax;
         double *partial = want_power ? reinterpret_cast<double *>(base + w.partial) : nullptr;

@@ -155,25 +155,26 @@ class Plan:
         return x.contiguous()
 
     # ---- pipelines -----------------------------------------------------------------------------------
-    def snn_pipeline(self, x, want_spikes=False, want_y=False, want_power=True):
-        """x: device tensor [B, T, M]. Returns dict of device tensors (spikes int8, y, power, argmax)."""
+    def snn_pipeline(self, x, want_spikes=False, want_y=False, want_power=True, stages=7, out=None):
+        """x: device tensor [B, T, M]. Returns dict of device tensors (spikes int8, y, power, argmax).
+        `stages` (MICLOC_STAGE_* bits: 1 STHT, 2 band-pass + RZCC, 4 LIF + beamforming + power) launches a part of the
+        pipeline; the parts of one batch share this plan's workspace and, via `out`, the output tensors."""
         torch = _torch()
         B, T, M = x.shape
         if M != self.num_mic:
             raise ValueError(f"number of channels in the input siganl {M} should be the same as the number of microphones {self.num_mic}!")
         G = self.G
-        out = {}
-        spikes = torch.empty((B, T, self.C), dtype=torch.int8, device=self.device) if want_spikes else None
-        y = torch.empty((B, T, G), dtype=torch.float64, device=self.device) if want_y else None
-        power = torch.empty((B, G), dtype=torch.float64, device=self.device) if want_power else None
-        argmax = torch.empty((B,), dtype=torch.int32, device=self.device) if want_power else None
+        if out is None:
+            out = dict(spikes=torch.empty((B, T, self.C), dtype=torch.int8, device=self.device) if want_spikes else None,
+                       y=torch.empty((B, T, G), dtype=torch.float64, device=self.device) if want_y else None,
+                       power=torch.empty((B, G), dtype=torch.float64, device=self.device) if want_power else None,
+                       argmax=torch.empty((B,), dtype=torch.int32, device=self.device) if want_power else None)
         ws, nbytes = self.workspace(B, T)
         _lib.check(
-            self.lib.micloc_snn_pipeline_f64(self.handle, _ptr(x), B, T, _ptr(spikes), _ptr(y), _ptr(power), _ptr(argmax),
-                                              _ptr(ws), nbytes, _stream(self.device)),
+            self.lib.micloc_snn_pipeline_stages_f64(self.handle, _ptr(x), B, T, _ptr(out["spikes"]), _ptr(out["y"]), _ptr(out["power"]),
+                                                     _ptr(out["argmax"]), _ptr(ws), nbytes, _stream(self.device), int(stages)),
             "snn_pipeline",
         )
-        out.update(spikes=spikes, y=y, power=power, argmax=argmax)
         return out
 
     def snn_pipeline_f32bf(self, x, want_spikes=False):

@@ -108,6 +108,16 @@ int micloc_beamform_c128_f64(const micloc_plan *plan, const double *pre, int B, 
  * spikes / y / power / argmax may each be NULL (at least one must be given). */
 int micloc_snn_pipeline_f64(const micloc_plan *plan, const double *x, int B, int T, int8_t *spikes, double *y,
                             double *power, int32_t *argmax, void *ws, size_t ws_bytes, void *stream);
+/* The same pipeline, launched in parts: `stages` selects which of its three kernel groups this call enqueues.  The
+ * intermediate results live in the workspace (and in `spikes` when given), so the parts of one batch must use the same
+ * workspace, in order; a caller may enqueue them on different streams with its own event dependencies -- e.g. the STHT
+ * of batch i+1 next to the latency-bound band-pass/RZCC of batch i. */
+#define MICLOC_STAGE_STHT 1     /* snn_beamformer.py:325-327 (quadrature FIR)                    */
+#define MICLOC_STAGE_ENCODE 2   /* snn_beamformer.py:330-338 (band-pass, re/im stack, RZCC)      */
+#define MICLOC_STAGE_BEAMFORM 4 /* snn_beamformer.py:342-368 (LIF, beamforming) + power/arg-max  */
+#define MICLOC_STAGE_ALL 7
+int micloc_snn_pipeline_stages_f64(const micloc_plan *plan, const double *x, int B, int T, int8_t *spikes, double *y,
+                                   double *power, int32_t *argmax, void *ws, size_t ws_bytes, void *stream, int stages);
 /* Beamformer.apply_to_signal (beamformer.py:260-292) + power/argmax for B trials. */
 int micloc_beamformer_pipeline_f64(const micloc_plan *plan, const double *x, int B, int T, double *y,
                                    double *power, int32_t *argmax, void *ws, size_t ws_bytes, void *stream);

@@ -272,3 +272,32 @@ def test_live_demo_frame_processing(cfg2):
     seen = []
     demo.run([pack, np.ones((4800, 8), dtype=np.int32)], sink=seen.append)
     assert seen[0] == got and np.isnan(seen[1])
+
+
+def test_pipeline_in_stages_equals_fused_call(cfg2):
+    """micloc_snn_pipeline_stages_f64: the three kernel groups enqueued one call at a time (same plan, same outputs)
+    give exactly what the fused call gives; invalid stage masks are refused."""
+    import torch
+
+    from conftest import golden
+    from haghighatshoarmuir2024_amd import _lib
+    from haghighatshoarmuir2024_amd.runtime import Plan
+
+    z = golden("trials_cfg2.npz")
+    p = Plan(7, cfg2["kernel"], cfg2["b"], cfg2["a"], cfg2["robust_width"], True)
+    p.set_neuron_kernel(cfg2["nir"])
+    p.set_bf_mat(cfg2["bf_mat"])
+    x = p.to_device(z["sig_in"])
+    fused = p.snn_pipeline(x, want_spikes=True, want_power=True)
+    fused = {k: (v.clone() if v is not None else None) for k, v in fused.items()}
+    out = p.snn_pipeline(x, want_spikes=True, want_power=True, stages=1)
+    out["spikes"].fill_(9)
+    p.snn_pipeline(x, stages=2, out=out)
+    assert torch.equal(out["spikes"], fused["spikes"])
+    out["power"].fill_(-1.0)
+    p.snn_pipeline(x, stages=4, out=out)
+    assert torch.equal(out["power"], fused["power"]) and torch.equal(out["argmax"], fused["argmax"])
+    np.testing.assert_array_equal(out["argmax"].cpu().numpy(), z["argmax"])
+    for bad in (0, 8, -1):
+        with pytest.raises(_lib.MiclocError):
+            p.snn_pipeline(x, stages=bad, out=out)
