@@ -460,3 +460,51 @@ def test_lif_beamform_stage_shapes_vs_oracle(torch, C, G, T, n_nir):
     top2 = np.sort(pw, axis=1)[:, -2:]
     clear = (top2[:, 1] - top2[:, 0]) > 1e-9 * top2[:, 1]
     np.testing.assert_array_equal(out_p["argmax"].cpu().numpy()[clear], out_y["argmax"].cpu().numpy()[clear])
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fused_pipeline_random_configurations_vs_oracle(torch, seed):
+    """Randomised configurations (microphones, STHT length and tap pattern, filter order, robust width, polarity,
+    neuron-kernel length, DoA count, trial length, signal character) through the fused pipeline against the oracle:
+    spikes bit-exact, power 1e-12, same arg-max.  Small sizes, fixed seeds."""
+    from haghighatshoarmuir2024_amd.runtime import Plan
+    from scipy.signal import butter
+
+    rng = np.random.default_rng(1000 + seed)
+    M = int(rng.choice([1, 2, 3, 5, 7, 8, 12]))
+    L = int(rng.choice([8, 30, 64, 96, 200]))
+    kernel = rng.standard_normal(L)
+    if rng.random() < 0.6:
+        kernel[::2] = 0.0  # Hilbert-like stride-2 pattern (compact tap table)
+    order = int(rng.choice([1, 2, 3]))
+    b, a = butter(order, [0.05, 0.2 + 0.1 * rng.random()], btype="bandpass")
+    w = int(rng.choice([1, 2, 5, 12, 24]))
+    bipolar = bool(rng.random() < 0.7)
+    n_nir = int(rng.choice([1, 7, 35, 60]))
+    nir = np.abs(rng.standard_normal(n_nir)) + 0.01
+    G = int(rng.choice([3, 16, 17, 100, 200, 361]))
+    T = int(rng.choice([1, 2, 17, 255, 256, 257, 700, 1500]))
+    B = int(rng.choice([1, 2, 5]))
+    W = rng.standard_normal((2 * M, G))
+    kind = seed % 4
+    t = np.arange(T)[None, :, None]
+    if kind == 0:
+        x = rng.standard_normal((B, T, M))
+    elif kind == 1:  # tone + weak noise: long monotone stretches of the cumulative sum
+        x = np.sin(0.3 * t + rng.random((B, 1, M)) * 6.28) + 0.01 * rng.standard_normal((B, T, M))
+    elif kind == 2:  # quantised: exact ties and plateaus
+        x = np.round(3 * rng.standard_normal((B, T, M)))
+    else:  # silent start, then signal: streams without a direction for a while
+        x = rng.standard_normal((B, T, M)) * (t >= T // 2)
+    p = Plan(M, kernel, b, a, w, bipolar)
+    p.set_neuron_kernel(nir)
+    p.set_bf_mat(W)
+    out = p.snn_pipeline(p.to_device(x), want_spikes=True, want_power=True)
+    for i in range(B):
+        ref = O.snn_chain(x[i], kernel, b, a, w, bipolar, nir, W, want=("spikes", "power"))
+        np.testing.assert_array_equal(out["spikes"][i].cpu().numpy(), ref["spikes"], err_msg=f"M={M} L={L} w={w} bip={bipolar} T={T}")
+        np.testing.assert_allclose(out["power"][i].cpu().numpy(), ref["power"], rtol=1e-12, atol=1e-300)
+        pw = out["power"][i].cpu().numpy()
+        top = np.sort(pw)[-2:] if G > 1 else np.array([0.0, pw[0]])
+        if top[1] - top[0] > 1e-9 * abs(top[1]):
+            assert int(out["argmax"][i]) == ref["argmax"]
