@@ -28,35 +28,68 @@ __global__ __launch_bounds__(64 * STHT_MAX_MB) void stht_kernel(const double *__
     extern __shared__ __attribute__((aligned(16))) double Xs[];
     constexpr int U = 8 / S;
     const int tid = threadIdx.x;
-    const int t0 = blockIdx.x * STHT_TILE;
-    const int m0 = blockIdx.y * MB;
-    const int b = blockIdx.z;
+    // XCD-aware placement (speed only, never correctness): workgroups are dealt round-robin over the 8 XCDs, each with
+    // its own 4 MB L2, and consecutive time tiles of a (trial, mic group) row share `halo` input samples -- half of
+    // what a tile reads.  Linear id L goes to XCD L % 8; give that XCD a whole row at a time, so the halo is an L2 hit
+    // instead of a second trip to HBM (measured: 2 x the unique input bytes fetched without this).
+    int tile_x = blockIdx.x, row_yz = blockIdx.y + gridDim.y * blockIdx.z;
+    {
+        const int ntile = gridDim.x, nrow = gridDim.y * gridDim.z;
+        const int L = tile_x + ntile * row_yz;
+        const int full = (nrow >> 3) << 3;  // rows in complete groups of 8
+        if (L < full * ntile) {
+            const int j = L >> 3;
+            const int rq = j / ntile;
+            tile_x = j - rq * ntile;
+            row_yz = 8 * rq + (L & 7);
+        }
+    }
+    const int t0 = tile_x * STHT_TILE;
+    const int m0 = (row_yz % gridDim.y) * MB;
+    const int b = row_yz / gridDim.y;
     const int N = 8 + halo + STHT_TILE;
     const int tq0 = t0 - halo - 8;  // global time of logical LDS index 0
     const double *xb = x + (size_t)b * T * M;
 
     // ---- stage (tile + halo) x MB mics, transposed to per-mic rows, zero outside [0, T) ----------
-    // Loads are issued in batches of 8 (clamped addresses, so unconditional) before any LDS write: the
-    // block pays the HBM latency twice per tile instead of once per row.
+    // Loads are issued in one batch of 16 per thread (clamped addresses, so unconditional) before any LDS write: the
+    // block pays the HBM latency once per tile instead of once per row.
     {
         const int mm = tid % MB;
         const int m = m0 + mm;
         const int mc = m < M ? m : M - 1;
         double *row = Xs + (size_t)mm * rowstride;
         const int q0 = tid / MB;
-        for (int qb = q0; qb < N; qb += 64 * 8) {
-            double v[8];
+        constexpr int NB = 16;  // loads in flight per thread: the whole tile + halo of the default shape in one batch
+        if (m < M && tq0 >= 0 && tq0 + N <= T && N <= 64 * NB) {
+            // interior tile (workgroup-uniform apart from m < M): no clamping, constant strides on both sides.
+            // skew(q0 + 64 i) = skew(q0) + 80 i because 64 is a multiple of 8.
+            const double *src = xb + (size_t)(tq0 + q0) * M + m;
+            double *dst = row + skew(q0);
+            double v[NB];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                int t = tq0 + qb + 64 * i;
-                t = t < 0 ? 0 : (t >= T ? T - 1 : t);
-                v[i] = xb[(size_t)t * M + mc];
+            for (int i = 0; i < NB; ++i) {
+                const int q = q0 + 64 * i;
+                v[i] = src[(size_t)(q < N ? 64 * i : 0) * M];
             }
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int q = qb + 64 * i;
-                const int t = tq0 + q;
-                if (q < N) row[skew(q)] = (t >= 0 && t < T && m < M) ? v[i] : 0.0;
+            for (int i = 0; i < NB; ++i)
+                if (q0 + 64 * i < N) dst[80 * i] = v[i];
+        } else {
+            for (int qb = q0; qb < N; qb += 64 * NB) {
+                double v[NB];
+#pragma unroll
+                for (int i = 0; i < NB; ++i) {
+                    int t = tq0 + qb + 64 * i;
+                    t = t < 0 ? 0 : (t >= T ? T - 1 : t);
+                    v[i] = xb[(size_t)t * M + mc];
+                }
+#pragma unroll
+                for (int i = 0; i < NB; ++i) {
+                    const int q = qb + 64 * i;
+                    const int t = tq0 + q;
+                    if (q < N) row[skew(q)] = (t >= 0 && t < T && m < M) ? v[i] : 0.0;
+                }
             }
         }
     }
