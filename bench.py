@@ -38,8 +38,8 @@ HBM_PEAK_GBS = 8000.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--grid", type=int, default=360)
     ap.add_argument("--trials", type=int, default=1100, help="trials per rank per step (11 SNRs x 100)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
