@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--grid", type=int, default=360)
     ap.add_argument("--trials", type=int, default=1100, help="trials per rank per step (11 SNRs x 100)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=300, help="trials timed on the CPU oracle")
+    ap.add_argument("--cpu-sample", type=int, default=1100, help="trials timed on the CPU oracle (the whole batch: about 15 s of CPU work)")
     ap.add_argument("--streams", type=int, default=3, help="HIP streams consecutive steps are pipelined over (1 = serial)")
     ap.add_argument("--traffic-bytes", type=float, default=None, help="HBM bytes per dominant-kernel launch from a separate rocprofv3 --pmc pass")
     return ap.parse_args()
