@@ -311,6 +311,11 @@ def main():
                        "parallelism": f"trial-sharded x{world}", "hip_streams": max(1, args.streams), "hip_graphs": True},
             "mae_deg_per_snr": [float(v) for v in (mae * 180 / np.pi).cpu().numpy()],
             "roofline": roof,
+            # the north star also asks for the fraction of the HBM roofline: algorithmic bytes of the fused sweep
+            # (one fp64 frame in, int8 spikes out and back in = 8M + 2M bytes per frame) over the whole job
+            "hbm_fraction": {"bytes_per_frame": 10 * M, "achieved_GBs": value / world * 10 * M / 1e9, "peak_GBs": HBM_PEAK_GBS,
+                             "frac_per_gpu": value / world * 10 * M / 1e9 / HBM_PEAK_GBS,
+                             "note": "compute-bound path (about 300 flop/B): small by construction, the binding roof is in `roofline`"},
             "variants": {"covariance_power": cov_variant, "f32_mfma_beamform": f32_variant},
         }
         if not args.no_cpu_baseline and world == 1:
