@@ -27,8 +27,8 @@ if ROOT not in sys.path:
 
 # HBM bytes per launch of the dominant kernel for the DEFAULT workload (1100 trials, T=4799, G=360), from separate
 # rocprofv3 --pmc passes (profiles/r1/pmc_summary.csv): 2 x FETCH_SIZE (gfx950 counts wide reads at half,
-# MI355X_MICROARCH.md "HBM") + WRITE_SIZE, both reported in KiB: 2 * 43166 + 60088 KiB.
-BEAMFORM_TRAFFIC_BYTES_DEFAULT = (2 * 43166 + 60088) * 1024
+# MI355X_MICROARCH.md "HBM") + WRITE_SIZE, both reported in KiB: 2 * 36409 + 60088 KiB.
+BEAMFORM_TRAFFIC_BYTES_DEFAULT = (2 * 36409 + 60088) * 1024
 # stage key in `stages_ms` -> device symbol that dominates it (what rocprofv3 lists)
 KERNEL_SYMBOL = {"beamform_kernel": "beamform_ws_kernel", "stht_kernel": "stht_kernel", "bandpass_rzcc_kernel": "bandpass_rzcc_fast_kernel"}
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X datasheet fp64 matrix = fp64 vector = 1/2 of the 157.3 TF fp32 rate in MI355X_MICROARCH.md

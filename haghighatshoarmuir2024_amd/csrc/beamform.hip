@@ -50,6 +50,22 @@ __device__ __forceinline__ double row_sum4(double x)
     return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
 }
 
+// XCD-aware placement (speed only, never correctness): workgroups are dealt round-robin over the 8 XCDs (4 MB of L2
+// each); consecutive chunks of a trial share the LIF halo rows, so an XCD is given a whole trial at a time and the halo
+// becomes an L2 hit instead of a second HBM fetch.  Grid (nchunks, B), linear id L = chunk + nchunks * b -> XCD L % 8.
+__device__ __forceinline__ void xcd_chunk_order(int &chunk, int &b)
+{
+    const int nchunks = gridDim.x, nb = gridDim.y;
+    const int L = chunk + nchunks * b;
+    const int full = (nb >> 3) << 3;  // trials in complete groups of 8
+    if (L < full * nchunks) {
+        const int j = L >> 3;
+        const int bq = j / nchunks;
+        chunk = j - bq * nchunks;
+        b = 8 * bq + (L & 7);
+    }
+}
+
 int beamform_nchunks(int T) { return (T + BF_CHUNK - 1) / BF_CHUNK; }
 
 // more than 64 channels: the slab kernel below works on 256-frame chunks
@@ -439,9 +455,9 @@ __global__ __launch_bounds__(BF_THREADS, NT == 2 ? 6 : 4) void beamform_ws_kerne
     const int l = tid & 63;
     const int lc = l & 15;
     const int q = l >> 4;
-    const int chunk = blockIdx.x;
+    int chunk = blockIdx.x, b = blockIdx.y;
+    xcd_chunk_order(chunk, b);
     const int nchunks = gridDim.x;
-    const int b = blockIdx.y;
     constexpr int CH = BF_WAVES * NT * 16;  // frames per workgroup
     constexpr int TILES = CH / 16;
     const int cs = chunk * CH;
