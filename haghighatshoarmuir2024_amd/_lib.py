@@ -44,6 +44,7 @@ SYMBOLS = {
     "micloc_plan_set_neuron_kernel": (c_int, [c_void_p, c_double_p, c_int]),
     "micloc_plan_set_bf_mat": (c_int, [c_void_p, c_double_p, c_int, c_int]),
     "micloc_plan_set_bf_mat_c128": (c_int, [c_void_p, c_double_p, c_double_p, c_int, c_int]),
+    "micloc_plan_generation": (c_int, [c_void_p]),
     "micloc_padded_T": (c_int, [c_int]),
     "micloc_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),
     "micloc_stht_f64": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
@@ -61,6 +62,7 @@ SYMBOLS = {
     "micloc_lif_covariance_f64": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "micloc_snn_pipeline_cov_f64": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "micloc_synth_delay_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, ctypes.c_double, c_void_p, c_void_p]),
+    "micloc_doa_error_f64": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "micloc_xylo_workspace_bytes": (c_size_t, [c_int, c_int]),
     "micloc_xylo_lif_i16": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                     c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -38,6 +38,9 @@ struct micloc_plan {
     BeamformW W{};
     int W_is_complex = 0;
     int G_out = 0;  // DoA grid size seen by the caller
+    // bumped whenever a device table is re-allocated (captured hipGraphs holding the old pointers become stale)
+    int generation = 0;
+    size_t taps_cap = 0, ntab_cap = 0, W_cap = 0;  // allocated doubles
 };
 
 namespace {
@@ -57,14 +60,21 @@ struct DeviceGuard {
     }
 };
 
-int upload(double **dptr, const std::vector<double> &host)
+// Uploads a host table.  A table that fits the existing allocation is overwritten in place (device pointer unchanged:
+// hipGraphs captured against this plan stay valid); otherwise the buffer is re-allocated and *generation is bumped.
+int upload(double **dptr, size_t *cap, int *generation, const std::vector<double> &host)
 {
-    if (*dptr) {
-        HIP_TRY(hipFree(*dptr));
-        *dptr = nullptr;
+    const size_t n = host.empty() ? 1 : host.size();
+    if (!*dptr || *cap < n) {
+        if (*dptr) {
+            HIP_TRY(hipFree(*dptr));
+            *dptr = nullptr;
+            *cap = 0;
+        }
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(dptr), n * sizeof(double)));
+        *cap = n;
+        ++*generation;
     }
-    const size_t bytes = (host.empty() ? 1 : host.size()) * sizeof(double);
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(dptr), bytes));
     if (!host.empty()) HIP_TRY(hipMemcpy(*dptr, host.data(), host.size() * sizeof(double), hipMemcpyHostToDevice));
     return MICLOC_OK;
 }
@@ -148,6 +158,12 @@ int micloc_plan_create(const micloc_config *cfg, micloc_plan **out)
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev)
         return MICLOC_ERR_NO_DEVICE;
+    {
+        // the code objects in this library are gfx950 only
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess || strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+            return MICLOC_ERR_NO_DEVICE;
+    }
 
     micloc_plan *p = new (std::nothrow) micloc_plan();
     if (!p) return MICLOC_ERR_INVALID;
@@ -202,7 +218,7 @@ int micloc_plan_create(const micloc_config *cfg, micloc_plan **out)
     }
 
     DeviceGuard guard(p->device);
-    int rc = upload(&p->d_taps, compact);
+    int rc = upload(&p->d_taps, &p->taps_cap, &p->generation, compact);
     if (rc != MICLOC_OK) {
         delete p;
         return rc;
@@ -233,7 +249,7 @@ int micloc_plan_set_neuron_kernel(micloc_plan *p, const double *nir, int n)
     DeviceGuard guard(p->device);
     // the table may be in use by queued kernels: replace it only after the device went idle
     HIP_TRY(hipDeviceSynchronize());
-    int rc = upload(&p->d_ntab, tab);
+    int rc = upload(&p->d_ntab, &p->ntab_cap, &p->generation, tab);
     if (rc != MICLOC_OK) return rc;
     p->ntab.tab = p->d_ntab;
     p->ntab.n = n;
@@ -246,7 +262,7 @@ static int set_W(micloc_plan *p, const std::vector<double> &Wp, int CT, int GT, 
 {
     DeviceGuard guard(p->device);
     HIP_TRY(hipDeviceSynchronize());
-    int rc = upload(&p->d_W, Wp);
+    int rc = upload(&p->d_W, &p->W_cap, &p->generation, Wp);
     if (rc != MICLOC_OK) return rc;
     p->W.Wp = p->d_W;
     p->W.CT = CT;
@@ -296,6 +312,8 @@ int micloc_plan_set_bf_mat_c128(micloc_plan *p, const double *Wre, const double 
     return set_W(p, Wp, CT, Gp / 16, C, 2 * G, 1, G);
 }
 
+int micloc_plan_generation(const micloc_plan *p) { return p ? p->generation : -1; }
+
 size_t micloc_workspace_bytes(const micloc_plan *p, int B, int T)
 {
     if (!p || bad_batch(B) || T < 1) return 0;
@@ -306,6 +324,7 @@ size_t micloc_workspace_bytes(const micloc_plan *p, int B, int T)
 int micloc_stht_f64(const micloc_plan *p, const double *x, int B, int T, double *h, int Ts, void *stream)
 {
     if (!p || !x || !h || bad_batch(B) || T < 1) return MICLOC_ERR_INVALID;
+    DeviceGuard guard(p->device);  // launches and stream belong to the plan's device, whatever the caller's current one
     if (Ts != micloc_padded_T(T)) return MICLOC_ERR_SHAPE;
     HIP_TRY(launch_stht(p->taps, x, h, B, T, p->M, Ts, (hipStream_t)stream));
     return MICLOC_OK;
@@ -315,6 +334,7 @@ int micloc_bandpass_rzcc_f64(const micloc_plan *p, const double *h, int B, int T
                              int8_t *spikes, void *ws, size_t ws_bytes, void *stream)
 {
     if (!p || !h || bad_batch(B) || T < 1 || (!pre && !spikes)) return MICLOC_ERR_INVALID;
+    DeviceGuard guard(p->device);  // launches and stream belong to the plan's device, whatever the caller's current one
     if (Ts != micloc_padded_T(T)) return MICLOC_ERR_SHAPE;
     const int nl = B * p->C;
     if (spikes && bad_ws(ws, ws_bytes, rzcc_scratch_bytes(nl, T))) return MICLOC_ERR_WORKSPACE;
@@ -327,6 +347,7 @@ int micloc_lif_beamform_f64(const micloc_plan *p, const int8_t *spikes, int B, i
                             int32_t *argmax, void *ws, size_t ws_bytes, void *stream)
 {
     if (!p || !spikes || bad_batch(B) || T < 1 || (!y && !power && !argmax)) return MICLOC_ERR_INVALID;
+    DeviceGuard guard(p->device);  // launches and stream belong to the plan's device, whatever the caller's current one
     if (!p->d_ntab || !p->d_W) return MICLOC_ERR_NOT_SET;
     if (p->W_is_complex) return MICLOC_ERR_SHAPE;
     const int Gp = 16 * p->W.GT;
@@ -344,6 +365,7 @@ int micloc_beamform_c128_f64(const micloc_plan *p, const double *pre, int B, int
                              int32_t *argmax, void *ws, size_t ws_bytes, void *stream)
 {
     if (!p || !pre || bad_batch(B) || T < 1 || (!y && !power && !argmax)) return MICLOC_ERR_INVALID;
+    DeviceGuard guard(p->device);  // launches and stream belong to the plan's device, whatever the caller's current one
     if (Ts != micloc_padded_T(T)) return MICLOC_ERR_SHAPE;
     if (!p->d_W) return MICLOC_ERR_NOT_SET;
     if (!p->W_is_complex) return MICLOC_ERR_SHAPE;
@@ -369,6 +391,7 @@ int micloc_snn_pipeline_stages_f64(const micloc_plan *p, const double *x, int B,
                                    double *power, int32_t *argmax, void *ws, size_t ws_bytes, void *stream, int stages)
 {
     if (!p || !x || bad_batch(B) || T < 1 || (!spikes && !y && !power && !argmax)) return MICLOC_ERR_INVALID;
+    DeviceGuard guard(p->device);  // launches and stream belong to the plan's device, whatever the caller's current one
     if (stages <= 0 || (stages & ~MICLOC_STAGE_ALL)) return MICLOC_ERR_INVALID;
     const bool want_bf = y || power || argmax;
     if (want_bf && (!p->d_ntab || !p->d_W)) return MICLOC_ERR_NOT_SET;
@@ -400,6 +423,7 @@ int micloc_beamformer_pipeline_f64(const micloc_plan *p, const double *x, int B,
                                    int32_t *argmax, void *ws, size_t ws_bytes, void *stream)
 {
     if (!p || !x || bad_batch(B) || T < 1 || (!y && !power && !argmax)) return MICLOC_ERR_INVALID;
+    DeviceGuard guard(p->device);  // launches and stream belong to the plan's device, whatever the caller's current one
     if (!p->d_W) return MICLOC_ERR_NOT_SET;
     if (!p->W_is_complex) return MICLOC_ERR_SHAPE;
     const WsLayout w = ws_layout(p, B, T);
@@ -484,6 +508,7 @@ int micloc_lif_beamform_f32(const micloc_plan *p, const int8_t *spikes, int B, i
                             void *ws, size_t ws_bytes, void *stream)
 {
     if (!p || !spikes || bad_batch(B) || T < 1 || (!power && !argmax)) return MICLOC_ERR_INVALID;
+    DeviceGuard guard(p->device);  // launches and stream belong to the plan's device, whatever the caller's current one
     if (!p->d_ntab || !p->d_W) return MICLOC_ERR_NOT_SET;
     if (p->W_is_complex || p->W.CT > 4) return MICLOC_ERR_SHAPE;
     const int Gp = 16 * p->W.GT;
@@ -501,6 +526,7 @@ int micloc_lif_covariance_f64(const micloc_plan *p, const int8_t *spikes, int B,
 {
     if (!p || !spikes || bad_batch(B) || T < 1 || t_start < 0 || t_start >= T || (!cov && !power && !argmax))
         return MICLOC_ERR_INVALID;
+    DeviceGuard guard(p->device);  // launches and stream belong to the plan's device, whatever the caller's current one
     if (!p->d_ntab) return MICLOC_ERR_NOT_SET;
     const bool want_power = power || argmax;
     if (want_power && (!p->d_W || p->W_is_complex)) return p->d_W ? MICLOC_ERR_SHAPE : MICLOC_ERR_NOT_SET;
@@ -520,6 +546,7 @@ int micloc_snn_pipeline_cov_f64(const micloc_plan *p, const double *x, int B, in
 {
     if (!p || !x || bad_batch(B) || T < 1 || t_start < 0 || t_start >= T || (!cov && !power && !argmax))
         return MICLOC_ERR_INVALID;
+    DeviceGuard guard(p->device);  // launches and stream belong to the plan's device, whatever the caller's current one
     if (!p->d_ntab) return MICLOC_ERR_NOT_SET;
     const bool want_power = power || argmax;
     if (want_power && (!p->d_W || p->W_is_complex)) return p->d_W ? MICLOC_ERR_SHAPE : MICLOC_ERR_NOT_SET;
@@ -549,6 +576,16 @@ int micloc_synth_delay_f64(const double *time, const double *sig, const double *
 {
     if (!time || !sig || !slopes || !delays || !x || T < 2 || bad_batch(B) || M < 1 || !(fs > 0.0)) return MICLOC_ERR_INVALID;
     HIP_TRY(launch_synth(time, sig, slopes, T, delays, B, M, fs, x, (hipStream_t)stream));
+    return MICLOC_OK;
+}
+
+// ---- per-trial DoA error and per-SNR mean absolute error ------------------------------------------------------
+int micloc_doa_error_f64(const int32_t *argmax, const double *doa_list, int G, const double *doa_true, int B, int groups,
+                         double *err, double *mae, void *stream)
+{
+    if (!argmax || !doa_list || !doa_true || G < 1 || bad_batch(B) || groups < 1 || B % groups != 0 || (!err && !mae))
+        return MICLOC_ERR_INVALID;
+    HIP_TRY(launch_doa_error(argmax, doa_list, G, doa_true, B, groups, err, mae, (hipStream_t)stream));
     return MICLOC_OK;
 }
 

@@ -93,4 +93,8 @@ hipError_t launch_xylo(const uint8_t *spikes_in, int B, int T, int Cin, const in
 hipError_t launch_synth(const double *xp, const double *fp, const double *slopes, int T, const double *delays, int B,
                         int M, double inv_step, double *out, hipStream_t stream);
 
+// ---- sweep results ---------------------------------------------------------------------------------------------
+hipError_t launch_doa_error(const int32_t *argmax, const double *doa_list, int G, const double *doa_true, int B, int groups,
+                            double *err, double *mae, hipStream_t stream);
+
 }  // namespace micloc

@@ -61,12 +61,14 @@ class Workspace:
     def __init__(self, device):
         self.device = device
         self.buf = None
+        self.generation = 0  # bumped on every (re)allocation: graphs captured against the old buffer are stale
 
     def get(self, nbytes):
         torch = _torch()
         if self.buf is None or self.buf.numel() < nbytes:
             self.buf = None
             self.buf = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+            self.generation += 1
         return self.buf
 
 
@@ -138,6 +140,12 @@ class Plan:
     def workspace(self, B, T):
         n = self.lib.micloc_workspace_bytes(self.handle, B, T)
         return self.ws.get(n), n
+
+    @property
+    def generation(self):
+        """Changes whenever a device pointer a captured hipGraph may hold was re-allocated: the plan's tables
+        (micloc_plan_generation) or this plan's workspace.  StreamPipeline.capture records it, replay() checks it."""
+        return (self.lib.micloc_plan_generation(self.handle), self.ws.generation)
 
     def padded_T(self, T):
         return self.lib.micloc_padded_T(T)
@@ -344,6 +352,20 @@ def synth_delay(time_in, sig_in, delays, fs, device=None):
     return x
 
 
+def doa_error(argmax, doa_list, doa_true, groups=1, want_err=True):
+    """Device tensors argmax [B] int32, doa_list [G] f64, doa_true [B] f64 -> (err [B] or None, mae [groups]):
+    arcsin|sin(doa_list[argmax] - doa_true)| and its mean per SNR group (target_snn_localization.py:464-467, :520)."""
+    torch = _torch()
+    lib = _lib.load()
+    B = argmax.shape[0]
+    dev = argmax.device
+    err = torch.empty((B,), dtype=torch.float64, device=dev) if want_err else None
+    mae = torch.empty((groups,), dtype=torch.float64, device=dev)
+    _lib.check(lib.micloc_doa_error_f64(_ptr(argmax), _ptr(doa_list), doa_list.shape[0], _ptr(doa_true), B, int(groups), _ptr(err), _ptr(mae),
+                                        _stream(dev)), "doa_error")
+    return err, mae
+
+
 class StreamPipeline:
     """Round-robin dispatch of consecutive batches over several HIP streams, one Plan (= workspace) per stream.
 
@@ -385,12 +407,17 @@ class StreamPipeline:
             # thread_local: other threads (e.g. the RCCL watchdog) may touch the runtime while this thread captures
             with torch.cuda.graph(g, stream=s, capture_error_mode="thread_local"):
                 out = fn(plan)
-            graphs.append((g, out))
+            graphs.append((g, out, plan.generation))
         state = {"next": 0}
+        plans = self.plans
 
         def replay():
             i = state["next"] % len(graphs)
             state["next"] += 1
+            if plans[i].generation != graphs[i][2]:
+                # the graph holds raw device pointers of tables / workspace that have been re-allocated since
+                raise _lib.MiclocError("stale HIP graph: the plan's tables or workspace were re-allocated after capture "
+                                       "(set_bf_mat / set_neuron_kernel with a larger table, or a larger batch); capture again")
             with torch.cuda.stream(self.streams[i]):
                 graphs[i][0].replay()
             return graphs[i][1]

@@ -47,7 +47,7 @@ typedef enum {
     MICLOC_ERR_WORKSPACE = -3,   /* ws too small or misaligned */
     MICLOC_ERR_NOT_SET = -4,     /* neuron kernel / bf_mat not set on the plan */
     MICLOC_ERR_HIP = -5,         /* a HIP runtime call failed; see micloc_last_hip_error */
-    MICLOC_ERR_NO_DEVICE = -6    /* no gfx950 device / device ordinal out of range */
+    MICLOC_ERR_NO_DEVICE = -6    /* device ordinal out of range, or the device is not a gfx950 (checked in plan_create) */
 } micloc_status;
 
 typedef struct micloc_plan micloc_plan;
@@ -76,6 +76,12 @@ int micloc_plan_set_bf_mat(micloc_plan *plan, const double *W, int C, int G);
 /* complex beamforming matrix (host, row-major [M][G] re and im); Beamformer bf_mat, applied as
  * sig @ bf_mat.conj() (beamformer.py:290) */
 int micloc_plan_set_bf_mat_c128(micloc_plan *plan, const double *Wre, const double *Wim, int M, int G);
+
+/* Counter that changes whenever a device table of the plan was RE-ALLOCATED (set_neuron_kernel / set_bf_mat with a
+ * table larger than any before).  A hipGraph captured from stage calls holds the raw table pointers: re-capture (or
+ * refuse to replay) when the value differs from the one read at capture time.  Tables that fit the existing allocation
+ * are overwritten in place after a device synchronisation and leave the counter -- and captured graphs -- valid. */
+int micloc_plan_generation(const micloc_plan *plan);
 
 /* padded time stride of planar buffers (multiple of 8 samples) */
 int micloc_padded_T(int T);
@@ -160,6 +166,13 @@ int micloc_snn_pipeline_cov_f64(const micloc_plan *plan, const double *x, int B,
  * diff(sig)/diff(time), delays [B][M] (already shifted so that their minimum is 0), x [B][T][M]. */
 int micloc_synth_delay_f64(const double *time, const double *sig, const double *slopes, int T, const double *delays,
                            int B, int M, double fs, double *x, void *stream);
+
+/* ---- Monte-Carlo results ---------------------------------------------------------------------- */
+/* err[b] = arcsin|sin(doa_list[argmax[b]] - doa_true[b])| (target_snn_localization.py:464-466; pi-periodic) and
+ * mae[s] = mean of err over the `B / groups` consecutive trials of SNR group s (:520).  All pointers are DEVICE buffers
+ * (doa_list [G], doa_true [B], err [B], mae [groups]); err or mae may be NULL; B must be a multiple of groups. */
+int micloc_doa_error_f64(const int32_t *argmax, const double *doa_list, int G, const double *doa_true, int B, int groups,
+                         double *err, double *mae, void *stream);
 
 /* ---- Xylo-A2 hidden-layer integer LIF (BASELINE config 4) -------------------------------------- */
 /* Replaces XyloSim.evolve as called by Demo.xylo_process (xylo_snn_localization.py:358-377) with the network built at
