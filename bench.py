@@ -1,21 +1,28 @@
 #!/usr/bin/env python3
 """Headline benchmark: audio frames/s through the full STHT -> RZCC -> SNN-beamform pipeline.
 
-Workload (BASELINE.json configs[1], target_snn_localization.py): 7-mic centre-circular array, 48 kHz,
+Default workload (BASELINE.json configs[1], target_snn_localization.py): 7-mic centre-circular array, 48 kHz,
 0.1 s noisy 2 kHz test tone (T = 4799 frames), 11 SNRs x 100 Monte-Carlo trials = 1100 trials per step,
 DoA grid 360 (BASELINE's nominal grid; `--grid 449` selects the script-exact one), bf_mat designed from the
 1 s 1->2 kHz chirp with design_from_template on the device before timing.  One "step" = one pass of the
 hot path over the 1100-trial batch (inputs resident in HBM): STHT, band-pass, RZCC, LIF, beamforming,
 power, arg-max, DoA error / MAE.  Weak scaling: every rank processes its own 1100-trial batch.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--grid G] [--no-cpu-baseline]
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--grid G] [--no-cpu-baseline] [--config noisy|speech|stress]
 
-Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for the field definitions).
+`--gpus N` (N > 1) without a launcher: this process stays GPU-free and starts N ranks of itself (one per GPU,
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, RCCL process group); under `python -m torch.distributed.run`
+(WORLD_SIZE already set) it is one of the ranks.  Rank 0 prints ONE JSON line (DESIGN.md "Measurement").
+
+Other workloads (same JSON contract, their own `config.workload`, not the headline):
+  --config speech   BASELINE configs[2], per-GPU share: 125 trials of the LibriSpeech utterance (T = 332 157)
+  --config stress   BASELINE configs[4], 64 mics / 96 kHz / 1440 DoAs, `--trials` trials per GPU (default 256)
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,79 +32,169 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-# HBM bytes per launch of the dominant kernel for the DEFAULT workload (1100 trials, T=4799, G=360), from separate
-# rocprofv3 --pmc passes (profiles/r1/pmc_summary.csv): 2 x FETCH_SIZE (gfx950 counts wide reads at half,
-# MI355X_MICROARCH.md "HBM") + WRITE_SIZE, both reported in KiB: 2 * 36409 + 60088 KiB.
-BEAMFORM_TRAFFIC_BYTES_DEFAULT = (2 * 36409 + 60088) * 1024
 # stage key in `stages_ms` -> device symbol that dominates it (what rocprofv3 lists)
-KERNEL_SYMBOL = {"beamform_kernel": "beamform_ws_kernel", "stht_kernel": "stht_kernel", "bandpass_rzcc_kernel": "bandpass_rzcc_fast_kernel"}
+KERNEL_SYMBOL = {"beamform_kernel": "beamform_ws_kernel", "stht_kernel": "stht_kernel", "bandpass_rzcc_kernel": "bandpass_rzcc"}
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X datasheet fp64 matrix = fp64 vector = 1/2 of the 157.3 TF fp32 rate in MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--grid", type=int, default=360)
-    ap.add_argument("--trials", type=int, default=1100, help="trials per rank per step (11 SNRs x 100)")
+    ap.add_argument("--config", choices=["noisy", "speech", "stress"], default="noisy")
+    ap.add_argument("--grid", type=int, default=None, help="DoA grid size (default: 360; stress: 1440)")
+    ap.add_argument("--trials", type=int, default=None, help="trials per rank per step (default: 1100 = 11 SNRs x 100; speech 125; stress 256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=1100, help="trials timed on the CPU oracle (the whole batch: about 15 s of CPU work)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of each cpu_baseline leg")
     ap.add_argument("--streams", type=int, default=3, help="HIP streams consecutive steps are pipelined over (1 = serial)")
-    ap.add_argument("--traffic-bytes", type=float, default=None, help="HBM bytes per dominant-kernel launch from a separate rocprofv3 --pmc pass")
-    return ap.parse_args()
+    ap.add_argument("--traffic-bytes", type=float, default=None, help="override roofline.traffic (HBM bytes per dominant-kernel launch)")
+    ap.add_argument("--pmc-summary", default=None, help="committed rocprofv3 PMC summary to read roofline.traffic from (default: newest profiles/r*/pmc_summary.csv)")
+    # test hook (tests/test_bench_launch_cpu.py): exercise the rank launcher and the collective code on CPU with gloo
+    ap.add_argument("--cpu-stub", action="store_true", help=argparse.SUPPRESS)
+    args = ap.parse_args(argv)
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    return args
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# rank launcher (runs in a process that has not touched the GPU)
+# ----------------------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def visible_gpus():
+    import torch
+
+    return int(torch.cuda.device_count())  # counts devices without initialising the HIP runtime state of this process
+
+
+def launch_ranks(args, argv):
+    """Start `args.gpus` copies of this script, one per GPU, as CHILD processes (never exec from a GPU-initialised
+    process) and return the exit code of the job.  Rank 0's stdout (the JSON line) passes straight through."""
+    n = args.gpus
+    if not args.cpu_stub:
+        have = visible_gpus()
+        if have < n:
+            print(f"bench.py: --gpus {n} requested but only {have} HIP device(s) visible", file=sys.stderr)
+            return 2
+    env0 = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n))
+    procs = []
+    for r in range(n):
+        env = dict(env0, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    rc = 0
+    alive = set(range(n))
+    while alive:
+        for r in list(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                for o in alive:  # one rank failed: the others would wait in a collective for ever
+                    procs[o].terminate()
+        time.sleep(0.05)
+    return rc
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# workloads
+# ----------------------------------------------------------------------------------------------------------------
+def chirp_template(fs, freq_range):
+    # target_snn_localization.py:345-356
+    time_temp = np.arange(0, 1.0, step=1 / fs)
+    period = time_temp[-1]
+    freq_inst = freq_range[0] + (freq_range[1] - freq_range[0]) * (time_temp % period) / period
+    return time_temp, np.sin(2 * np.pi * np.cumsum(freq_inst) / fs)
+
+
+def speech_source(fs):
+    """The LibriSpeech utterance of BASELINE config 3 (84-121123-0020.flac, decoded by haghighatshoarmuir2024_amd.flac and
+    kept as PCM in tests/golden/speech_trial.npz), resampled like target_snn_localization.py:149-154."""
+    z = np.load(os.path.join(ROOT, "tests", "golden", "speech_trial.npz"))
+    rate = int(z["rate"])
+    sig = z["pcm16"].astype(np.float64) / 32768.0
+    t = np.arange(len(sig)) / rate
+    t_fs = np.linspace(t[0], t[-1], int(len(sig) / rate * fs))
+    return t_fs, np.interp(t_fs, t, sig)
 
 
 def build_workload(args, rank, device):
     import torch
 
-    from haghighatshoarmuir2024_amd.array_geometry import CenterCircularArray
+    from haghighatshoarmuir2024_amd.array_geometry import CenterCircularArray, Random2DArray
     from haghighatshoarmuir2024_amd.snn_beamformer import SNNBeamformer, neuron_impulse_response
 
-    fs, num_mic, freq_design = 48_000, 7, 2000.0
+    cfg = args.config
+    freq_design = 2000.0
     freq_range = [0.5 * freq_design, freq_design]
     tau = 1.0 / (2 * np.pi * freq_design)
-    geometry = CenterCircularArray(radius=4.5e-2, num_mic=num_mic)
+    if cfg == "stress":
+        fs, num_mic = 96_000, 64
+        np.random.seed(1)  # Random2DArray draws from the global NumPy stream (array_geometry.py:126-127)
+        geometry = Random2DArray(radius=0.2, num_mic=num_mic)
+        G = args.grid or 1440
+        B = args.trials or 256
+    else:
+        fs, num_mic = 48_000, 7
+        geometry = CenterCircularArray(radius=4.5e-2, num_mic=num_mic)
+        G = args.grid or 360
+        B = args.trials or (125 if cfg == "speech" else 1100)
     beamf = SNNBeamformer(geometry=geometry, kernel_duration=10.0e-3, tau_vec=np.asarray([tau, tau]), freq_range=freq_range, fs=fs,
                           bipolar_spikes=True, device=device)
-    # chirp template and DoA grid (target_snn_localization.py:345-371)
-    time_temp = np.arange(0, 1.0, step=1 / fs)
-    period = time_temp[-1]
-    freq_inst = freq_range[0] + (freq_range[1] - freq_range[0]) * (time_temp % period) / period
-    sig_temp = np.sin(2 * np.pi * np.cumsum(freq_inst) / fs)
-    doa_list = np.linspace(-np.pi, np.pi, args.grid)
-    bf_mat = beamf.design_from_template((time_temp, sig_temp), doa_list)
+    doa_list = np.linspace(-np.pi, np.pi, G)
+    if cfg == "stress":
+        # designing 1440 DoAs x 1 s x 64 mics is a one-off cost outside the hot path: random unit-norm columns
+        rng_w = np.random.RandomState(5)
+        bf_mat = rng_w.randn(2 * num_mic, G)
+        bf_mat /= np.linalg.norm(bf_mat, axis=0, keepdims=True)
+    else:
+        bf_mat = beamf.design_from_template(chirp_template(fs, freq_range), doa_list)
 
-    # test signals (target_snn_localization.py:435-455): synthetic, generated here, noise drawn on the device
-    time_test = np.arange(0, 100e-3, step=1 / fs)
-    sig_test = np.sin(2 * np.pi * freq_design * time_test)
-    B = args.trials
+    # test signals (target_snn_localization.py:435-455 / :148-154,213-245): synthetic, generated here, noise drawn on the device
+    if cfg == "speech":
+        time_test, sig_test = speech_source(fs)
+        snr_gain = 1.0  # the speech sweep applies no bandwidth correction (target_snn_localization.py:227)
+    else:
+        time_test = np.arange(0, 100e-3, step=1 / fs)
+        sig_test = np.sin(2 * np.pi * freq_design * time_test)
+        snr_gain = (fs / 2) / (freq_range[1] - freq_range[0])
     rng = np.random.RandomState(1000 + rank)
     doa = rng.rand(B) * 2 * np.pi
     snr_db_vec = np.linspace(-10, 20, 11)
-    snr_db = snr_db_vec[(np.arange(B) * len(snr_db_vec)) // B] - 10 * np.log10((fs / 2) / (freq_range[1] - freq_range[0]))
+    groups = len(snr_db_vec) if B % len(snr_db_vec) == 0 else 1
+    snr_db = snr_db_vec[(np.arange(B) * len(snr_db_vec)) // B] - 10 * np.log10(snr_gain)
     time_in, clean = beamf.synthesize_batch((time_test, sig_test), doa)  # device synthesis, bit-exact with np.interp
     gen = torch.Generator(device=device)
     gen.manual_seed(1234 + rank)
     sigma = torch.sqrt(torch.mean(clean**2, dim=(1, 2))) / torch.sqrt(10 ** (torch.from_numpy(snr_db).to(device) / 10))
-    x = (clean + sigma[:, None, None] * torch.randn(clean.shape, generator=gen, device=device, dtype=torch.float64)).contiguous()
+    x = clean
+    for lo in range(0, B, 64):  # in place, in slices: config 3's batch is 2.3 GB
+        x[lo : lo + 64] += sigma[lo : lo + 64, None, None] * torch.randn(x[lo : lo + 64].shape, generator=gen, device=device, dtype=torch.float64)
     del clean
 
     plan = beamf.plan()
-    nir = neuron_impulse_response(time_in, beamf.tau_vec)
+    nir = neuron_impulse_response(time_in[: min(len(time_in), 48_000)], beamf.tau_vec)
     plan.set_neuron_kernel(nir)
     plan.set_bf_mat(bf_mat)
     return dict(beamf=beamf, plan=plan, x=x, doa=torch.from_numpy(doa).to(device), doa_list=torch.from_numpy(doa_list).to(device),
-                bf_mat=bf_mat, nir=nir, snr_groups=len(snr_db_vec), fs=fs)
+                bf_mat=bf_mat, nir=nir, snr_groups=groups, fs=fs)
 
 
-def make_step(wl, nstreams):
+def make_step(wl, nstreams, variants=True):
     """One step = one pass of the hot path over the batch.  Consecutive steps are independent batches, so they are
     dispatched round-robin over `nstreams` HIP streams (one plan/workspace each): the latency-bound RZCC kernel of
     one step overlaps the throughput-bound STHT / beamforming kernels of its neighbours."""
-    import torch
-
+    from haghighatshoarmuir2024_amd import runtime
     from haghighatshoarmuir2024_amd.runtime import StreamPipeline
 
     x, doa, doa_list, S = wl["x"], wl["doa"], wl["doa_list"], wl["snr_groups"]
@@ -114,16 +211,15 @@ def make_step(wl, nstreams):
             out = plan.snn_pipeline_f32bf(x)
         else:
             out = plan.snn_pipeline_cov(x, want_power=True) if cov else plan.snn_pipeline(x, want_power=True)
-        est = doa_list[out["argmax"].long()]
-        err = torch.arcsin(torch.abs(torch.sin(est - doa)))
-        mae = err.reshape(S, -1).mean(dim=1)
+        # DoA error per trial + MAE per SNR on the device (micloc_doa_error_f64): the graph holds micloc kernels only
+        _, mae = runtime.doa_error(out["argmax"], doa_list, doa, groups=S, want_err=False)
         return out, mae
 
-    # one HIP graph per stream (pipeline kernels + the DoA-error / MAE ops), replayed round-robin
+    # one HIP graph per stream (pipeline kernels + the DoA-error / MAE kernel), replayed round-robin
     replay_direct = pipe.capture(lambda plan: body(plan, False))
-    replay_cov = pipe.capture(lambda plan: body(plan, True)) if x.shape[2] * 2 <= 64 else None
-
-    replay_f32 = pipe.capture(lambda plan: body(plan, "f32")) if x.shape[2] * 2 <= 64 else None
+    small = variants and x.shape[2] * 2 <= 64
+    replay_cov = pipe.capture(lambda plan: body(plan, True)) if small else None
+    replay_f32 = pipe.capture(lambda plan: body(plan, "f32")) if small else None
 
     def step(cov=False):
         if cov == "f32":
@@ -134,13 +230,12 @@ def make_step(wl, nstreams):
 
 
 def stage_times(wl, iters):
-    """Average duration of each stage of the pipeline (HIP events on the launch stream), in ms."""
+    """Average duration of each kernel group of the FUSED pipeline (HIP events on the launch stream), in ms: exactly the
+    launches one step makes (micloc_snn_pipeline_stages_f64 with one stage bit at a time, sharing one workspace)."""
     import torch
 
     plan, x = wl["plan"], wl["x"]
-    B, T, M = x.shape
-    h = plan.stht(x)
-    _, spikes = plan.bandpass_rzcc(h, T, want_pre=False, want_spikes=True)
+    out = plan.snn_pipeline(x, want_power=True)  # allocates the outputs, fills the workspace intermediates
     res = {}
 
     def timed(fn):
@@ -155,49 +250,167 @@ def stage_times(wl, iters):
         torch.cuda.synchronize()
         return float(np.mean([a.elapsed_time(b) for a, b in zip(e0, e1)]))
 
-    res["stht_kernel"] = timed(lambda: plan.stht(x))
-    res["bandpass_rzcc_kernel"] = timed(lambda: plan.bandpass_rzcc(h, T, want_pre=False, want_spikes=True))
-    res["beamform_kernel"] = timed(lambda: plan.lif_beamform(spikes, want_power=True))
+    res["stht_kernel"] = timed(lambda: plan.snn_pipeline(x, stages=1, out=out))
+    res["bandpass_rzcc_kernel"] = timed(lambda: plan.snn_pipeline(x, stages=2, out=out))
+    res["beamform_kernel"] = timed(lambda: plan.snn_pipeline(x, stages=4, out=out))
     return res
 
 
-def cpu_baseline(wl, n):
-    """The oracle (CPU restatement, scalar C, one thread) on the first n trials of the same batch."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(wl, budget_s):
+    """The CPU restatement of the same hot path on the first trials of the SAME batch, three ways:
+      value            the C oracle, trial-parallel over all host cores (one thread per core)
+      single_thread    the C oracle on one core
+      numpy_ops        the reference's own op sequence (NumPy / SciPy calls, BLAS threads at their default), one process
+    Each leg is sized for about `budget_s` seconds from a short calibration run."""
     from oracle import oracle as O
 
     beamf = wl["beamf"]
-    x = wl["x"][:n].cpu().numpy()
     b, a = beamf.bandpass_filter
+    w = beamf.spk_encoder.robust_width
+    B, T, M = wl["x"].shape
+    G = wl["bf_mat"].shape[1]
+    cores = os.cpu_count() or 1
     O.lib()
+    args = (beamf.kernel, b, a, w, True, wl["nir"], wl["bf_mat"])
+
+    def sized(rate, cap):
+        return int(max(1, min(cap, rate * budget_s)))
+
+    x_cal = wl["x"][: min(B, 4)].cpu().numpy()
     t0 = time.perf_counter()
-    pw, am = O.snn_chain_batch(x, beamf.kernel, b, a, beamf.spk_encoder.robust_width, True, wl["nir"], wl["bf_mat"])
-    dt = time.perf_counter() - t0
-    return dict(value=n * x.shape[1] / dt, unit="frames/s", cores=1, kind="port",
-                sample=f"{n} of the {wl['x'].shape[0]} trials of the same batch (T={x.shape[1]}, M={x.shape[2]}, G={wl['bf_mat'].shape[1]}), "
-                       f"{dt:.1f} s, oracle/micloc_oracle.c single thread"), am
+    O.snn_chain_batch(x_cal, *args)
+    per_trial = (time.perf_counter() - t0) / len(x_cal)
+
+    n1 = sized(1.0 / per_trial, B)
+    x1 = wl["x"][:n1].cpu().numpy()
+    t0 = time.perf_counter()
+    _, am1 = O.snn_chain_batch(x1, *args)
+    dt1 = time.perf_counter() - t0
+
+    reps = max(1, int(np.ceil(sized(cores / per_trial, 64 * B) / B)))  # the whole batch, repeated if the box has many cores
+    xa = wl["x"].cpu().numpy()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        _, am_all = O.snn_chain_batch_parallel(xa, *args, threads=cores)
+    dta = time.perf_counter() - t0
+
+    t0 = time.perf_counter()
+    r0 = O.snn_chain_numpy(xa[0], *args)
+    per_np = time.perf_counter() - t0
+    nn = sized(1.0 / per_np, min(B, 400))
+    t0 = time.perf_counter()
+    am_np = [O.snn_chain_numpy(xa[i], *args)["argmax"] for i in range(nn)]
+    dtn = time.perf_counter() - t0
+    del r0
+
+    shape = f"T={T}, M={M}, G={G}"
+    return dict(value=reps * B * T / dta, unit="frames/s", cores=cores, kind="port", cpu_model=cpu_model(), host_cpus=cores,
+                sample=f"{reps} x all {B} trials of the same batch ({shape}), {dta:.1f} s, oracle/micloc_oracle.c, trials split over {cores} threads",
+                single_thread=dict(value=n1 * T / dt1, unit="frames/s", cores=1,
+                                   sample=f"first {n1} trials, {dt1:.1f} s, oracle/micloc_oracle.c, one thread"),
+                numpy_ops=dict(value=nn * T / dtn, unit="frames/s", cores="BLAS default",
+                               sample=f"first {nn} trials, {dtn:.1f} s, oracle.snn_chain_numpy: the reference's NumPy/SciPy op sequence, one process"),
+                ), dict(all=am_all, one=am1, numpy=np.asarray(am_np))
 
 
-def main():
-    args = parse()
+def traffic_from_profiles(symbol, grid_size, path=None):
+    """HBM bytes per launch of `symbol` at launch size `grid_size` (work-items) from a COMMITTED rocprofv3 PMC summary
+    (tools/summarize_profiles.py pmc): 2 x FETCH_SIZE + WRITE_SIZE, both KiB, FETCH_SIZE doubled as MI355X_MICROARCH.md
+    "HBM" prescribes for gfx950.  Returns (bytes or None, source)."""
+    import csv
+    import glob
+
+    if path is None:
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_summary.csv")),
+                       key=lambda p: int("".join(c for c in os.path.basename(os.path.dirname(p)) if c.isdigit()) or 0))
+        if not cands:
+            return None, None
+        path = cands[-1]
+    fetch = write = None
+    try:
+        for r in csv.DictReader(open(path)):
+            if symbol in r["kernel"] and int(float(r["grid_size"])) == grid_size:
+                if r["counter"] == "FETCH_SIZE":
+                    fetch = float(r["mean_value"])
+                elif r["counter"] == "WRITE_SIZE":
+                    write = float(r["mean_value"])
+    except (OSError, KeyError, ValueError):
+        return None, None
+    if fetch is None or write is None:
+        return None, os.path.relpath(path, ROOT)
+    return (2.0 * fetch + write) * 1024.0, os.path.relpath(path, ROOT)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+def run_stub(args, rank, world):
+    """Launcher / collective plumbing on CPU (gloo): a few arithmetic 'steps', the same barrier + max-over-ranks timing and
+    the same JSON contract.  Not a measurement; used by tests/test_bench_launch_cpu.py only."""
     import torch
     import torch.distributed as dist
 
+    use_dist = world > 1
+    if args.steps < 0 and rank == world - 1:
+        return 3  # test hook: a rank that dies before the rendezvous
+    if use_dist:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    v = torch.arange(1000, dtype=torch.float64)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        v = v * 1.0000001
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    group = 1
+    if use_dist:
+        dist.barrier()
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        group = dist.get_world_size()
+    if rank == 0:
+        print(json.dumps({"metric": "stub", "value": world * 1000 * args.steps / float(dt.item()), "unit": "elements/s", "n_gpus": group,
+                          "rccl_ranks": group, "backend": "gloo (cpu stub)", "steps": args.steps, "warmup": args.warmup, "scaling": "weak"}), flush=True)
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+def run(args):
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
+    if args.cpu_stub:
+        return run_stub(args, rank, world)
+    import torch
+    import torch.distributed as dist
+
     if world != args.gpus and world > 1:
         args.gpus = world
+    if local_rank >= torch.cuda.device_count():
+        print(f"bench.py: rank {rank} has no device (LOCAL_RANK {local_rank}, {torch.cuda.device_count()} visible)", file=sys.stderr)
+        return 2
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     # MICLOC_FORCE_DIST=1 runs the collective code path with a 1-rank RCCL group (to exercise it on a 1-GPU box)
     use_dist = world > 1 or os.environ.get("MICLOC_FORCE_DIST") == "1"
+    group_size = 1
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        group_size = dist.get_world_size()
 
     wl = build_workload(args, rank, device)
-    step, pipe = make_step(wl, max(1, args.streams))
+    noisy = args.config == "noisy"
+    nstreams = max(1, args.streams) if noisy else 1  # the long / wide workloads fill the chip with one batch
+    step, pipe = make_step(wl, nstreams, variants=noisy)
     B, T, M = wl["x"].shape
     G = wl["bf_mat"].shape[1]
 
@@ -207,59 +420,40 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out, mae = step()
-    barrier()
-    dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    def timed_steps(fn):
+        for _ in range(args.warmup):
+            fn()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            res = fn()
+        barrier()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+        if use_dist:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item()), res
+
+    dt, (out, mae) = timed_steps(step)
     if use_dist:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         # the sweep's one exchange step: gather the per-rank MAE curves (RCCL)
         gathered = [torch.empty_like(mae) for _ in range(world)]
         dist.all_gather(gathered, mae)
         mae = torch.stack(gathered).mean(dim=0)
-    dt = float(tmax.item())
-    frames = world * B * T * args.steps
+    frames = group_size * B * T * args.steps
     value = frames / dt
     argmax_direct = out["argmax"].clone()  # graph outputs are static buffers: keep a copy for the comparisons below
+    power_direct = out["power"].clone()
 
-    # separately reported algorithmic variant: covariance-form power, same K steps, same inputs
-    cov_variant = None
-    if M * 2 <= 64:
-        for _ in range(args.warmup):
-            step(cov=True)
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            out_c, mae_c = step(cov=True)
-        barrier()
-        dtc = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
-        if use_dist:
-            dist.all_reduce(dtc, op=dist.ReduceOp.MAX)
-        dtc = float(dtc.item())
+    cov_variant = f32_variant = None
+    if noisy and M * 2 <= 64:
+        # separately reported algorithmic variant: covariance-form power, same K steps, same inputs
+        dtc, (out_c, _) = timed_steps(lambda: step(cov=True))
         cov_variant = {"value": frames / dtc, "unit": "frames/s", "ms_per_step": dtc / args.steps * 1e3,
                        "argmax_equal_to_direct": bool(torch.equal(out_c["argmax"], argmax_direct)),
                        "note": "power = w^T (V^T V / T) w instead of mean_t (V w)^2: algebraically identical, 2C^2 instead of 2CG flops per frame; not the headline"}
-
-    # second separately reported variant: fp32-MFMA beamforming tail (fp64 up to the spikes)
-    f32_variant = None
-    if M * 2 <= 64:
-        for _ in range(args.warmup):
-            step(cov="f32")
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            out_f, mae_f = step(cov="f32")
-        barrier()
-        dtf = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
-        if use_dist:
-            dist.all_reduce(dtf, op=dist.ReduceOp.MAX)
-        dtf = float(dtf.item())
-        relerr = float((out_f["power"] / out["power"] - 1).abs().max().item())
+        # second separately reported variant: fp32-MFMA beamforming tail (fp64 up to the spikes)
+        dtf, (out_f, _) = timed_steps(lambda: step(cov="f32"))
+        relerr = float((out_f["power"] / power_direct - 1).abs().max().item())
         f32_variant = {"value": frames / dtf, "unit": "frames/s", "ms_per_step": dtf / args.steps * 1e3,
                        "argmax_equal_to_f64": int((out_f["argmax"] == argmax_direct).sum().item()), "trials": int(B),
                        "max_rel_power_err_vs_f64": relerr,
@@ -278,25 +472,34 @@ def main():
         }
         dom = max(st, key=st.get)
         frames_launch = B * T
+        traffic_src = None
         if dom == "bandpass_rzcc_kernel":
             # latency-bound sequential stage: price it against HBM with its algorithmic bytes (8 B in per channel sample + 1 B spike out)
             achieved = frames_launch * (8 * C + C) / (st[dom] * 1e-3) / 1e9
-            roof = dict(kernel=dom, bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
+            roof = dict(kernel=KERNEL_SYMBOL[dom], bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
                         traffic=args.traffic_bytes)
         else:
             achieved = frames_launch * flops[dom] / (st[dom] * 1e-3) / 1e12
             traffic = args.traffic_bytes
-            if traffic is None and dom == "beamform_kernel" and (B, T, M, G) == (1100, 4799, 7, 360):
-                traffic = float(BEAMFORM_TRAFFIC_BYTES_DEFAULT)
-            roof = dict(kernel=KERNEL_SYMBOL.get(dom, dom), bound="mfma", achieved=achieved, peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+            if traffic is None and dom == "beamform_kernel" and C <= 16:
+                # launch size of beamform_ws_kernel: 256-frame chunks x 512 work-items per trial
+                traffic, traffic_src = traffic_from_profiles(KERNEL_SYMBOL[dom], -(-T // 256) * 512 * B, args.pmc_summary)
+            sym = KERNEL_SYMBOL.get(dom, dom)
+            if dom == "beamform_kernel" and C > 64:
+                sym = "beamform_slab_kernel"
+            roof = dict(kernel=sym, bound="mfma", achieved=achieved, peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                         frac=achieved / FP64_MFMA_PEAK_TFLOPS, traffic=traffic)
+        roof["traffic_source"] = traffic_src
         roof["avg_launch_ms"] = st[dom]
         roof["stages_ms"] = st
+        names = {"noisy": "target_snn_localization noisy sweep", "speech": "target_snn_localization speech sweep (LibriSpeech 84-121123-0020, per-GPU share of 1000 trials)",
+                 "stress": "stress shape (64-mic Random2DArray r=0.2 m after np.random.seed(1), 96 kHz, random unit-norm bf_mat)"}
         result = {
             "metric": "audio samples/sec through STHT+RZCC+SNN beamform, 7-mic 48kHz 360-DoA; DoA MAE vs ref",
             "value": value,
-            "unit": "frames/s (one frame = one 7-mic audio sample instant)",
-            "n_gpus": world,
+            "unit": "frames/s (one frame = one audio sample instant across all mics)",
+            "n_gpus": group_size,
+            "rccl_ranks": group_size if use_dist else 0,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
@@ -305,23 +508,24 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"target_snn_localization noisy sweep: 7-mic centre-circular, 48 kHz, T={T}, {B} trials/GPU/step (11 SNR x {B // 11}), "
-                                   f"{G}-DoA grid, bipolar RZCC, bf_mat designed on device from the 1 s chirp",
+            "config": {"workload": f"{names[args.config]}: {M}-mic, {wl['fs'] // 1000} kHz, T={T}, {B} trials/GPU/step, "
+                                   f"{G}-DoA grid, bipolar RZCC" + (", bf_mat designed on device from the 1 s chirp" if args.config != "stress" else ""),
                        "trials_per_gpu": B, "frames_per_trial": T, "num_mic": M, "num_doa": G, "mic_samples_per_s": value * M,
-                       "parallelism": f"trial-sharded x{world}", "hip_streams": max(1, args.streams), "hip_graphs": True},
+                       "parallelism": f"trial-sharded x{group_size}", "hip_streams": nstreams, "hip_graphs": True},
             "mae_deg_per_snr": [float(v) for v in (mae * 180 / np.pi).cpu().numpy()],
             "roofline": roof,
             # the north star also asks for the fraction of the HBM roofline: algorithmic bytes of the fused sweep
             # (one fp64 frame in, int8 spikes out and back in = 8M + 2M bytes per frame) over the whole job
-            "hbm_fraction": {"bytes_per_frame": 10 * M, "achieved_GBs": value / world * 10 * M / 1e9, "peak_GBs": HBM_PEAK_GBS,
-                             "frac_per_gpu": value / world * 10 * M / 1e9 / HBM_PEAK_GBS,
+            "hbm_fraction": {"bytes_per_frame": 10 * M, "achieved_GBs": value / group_size * 10 * M / 1e9, "peak_GBs": HBM_PEAK_GBS,
+                             "frac_per_gpu": value / group_size * 10 * M / 1e9 / HBM_PEAK_GBS,
                              "note": "compute-bound path (about 300 flop/B): small by construction, the binding roof is in `roofline`"},
             "variants": {"covariance_power": cov_variant, "f32_mfma_beamform": f32_variant},
         }
-        if not args.no_cpu_baseline and world == 1:
-            cb, am_cpu = cpu_baseline(wl, min(args.cpu_sample, B))
-            am_gpu = argmax_direct[: len(am_cpu)].cpu().numpy()
-            cb["argmax_equal_to_gpu"] = bool(np.array_equal(am_cpu, am_gpu))
+        if not args.no_cpu_baseline and group_size == 1 and noisy:
+            cb, am = cpu_baseline(wl, args.cpu_seconds)
+            am_gpu = argmax_direct.cpu().numpy()
+            cb["argmax_equal_to_gpu"] = bool(np.array_equal(am["all"], am_gpu) and np.array_equal(am["one"], am_gpu[: len(am["one"])])
+                                             and np.array_equal(am["numpy"], am_gpu[: len(am["numpy"])]))
             result["cpu_baseline"] = cb
     if use_dist:
         dist.barrier()
@@ -336,7 +540,17 @@ def main():
             pass
         sys.stdout.flush()
         print(json.dumps(result), flush=True)
+    return 0
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
+    args = parse(argv)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # still GPU-free here: nothing above imported torch.cuda state or loaded libmicloc_hip.so
+        return launch_ranks(args, argv)
+    return run(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

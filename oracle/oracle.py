@@ -187,6 +187,45 @@ def snn_chain_batch(x, kernel, b, a, robust_width, bipolar, nir, W):
     return pw, am
 
 
+def snn_chain_numpy(x, kernel, b, a, robust_width, bipolar, nir, W):
+    """The same chain as snn_chain, op for op as the reference runs it on the CPU (NumPy / SciPy calls, BLAS threads at
+    their default): snn_beamformer.py:325-368 + spike_encoder.py:115-137 + target_snn_localization.py:462-464.
+    bench.py times this as the `numpy_ops` leg of cpu_baseline; tests check it against snn_chain."""
+    from scipy.signal import find_peaks, lfilter
+
+    x = np.asarray(x, dtype=np.float64)
+    L = len(kernel)
+    sig_h = np.roll(x, L // 2, axis=0) + 1j * lfilter(kernel, [1], x, axis=0)
+    sig_h = lfilter(b, a, sig_h, axis=0)
+    r = np.hstack([np.real(sig_h), np.imag(sig_h)])
+    spikes = np.zeros_like(r)
+    for ch in range(r.shape[1]):
+        peaks, _ = find_peaks(np.cumsum(r[:, ch]), distance=robust_width)
+        spikes[peaks, ch] = 1
+        if bipolar:
+            valleys, _ = find_peaks(-np.cumsum(r[:, ch]), distance=robust_width)
+            spikes[valleys, ch] = -1
+    vmem = lfilter(nir, [1], spikes, axis=0)
+    y = vmem @ W
+    power = np.mean(np.abs(y) ** 2, axis=0)
+    return dict(spikes=spikes.astype(np.int8), power=power, argmax=int(np.argmax(power)))
+
+
+def snn_chain_batch_parallel(x, kernel, b, a, robust_width, bipolar, nir, W, threads):
+    """snn_chain_batch with the trials split over `threads` host threads (the C call releases the GIL): the
+    trial-parallel leg of bench.py's cpu_baseline (target_snn_localization.py:447-467 has no cross-trial state)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    B = x.shape[0]
+    threads = max(1, min(int(threads), B))
+    bounds = [(i * B // threads, (i + 1) * B // threads) for i in range(threads)]
+    lib()
+    with ThreadPoolExecutor(threads) as ex:
+        parts = list(ex.map(lambda lh: snn_chain_batch(x[lh[0] : lh[1]], kernel, b, a, robust_width, bipolar, nir, W), bounds))
+    return np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])
+
+
 def beamformer_chain(x, kernel, b, a, W, want_y=True):
     """Beamformer.apply_to_signal (complex W of shape M x G) + power/argmax."""
     x, xp = _d(x)
