@@ -45,6 +45,8 @@ SYMBOLS = {
     "micloc_plan_set_bf_mat": (c_int, [c_void_p, c_double_p, c_int, c_int]),
     "micloc_plan_set_bf_mat_c128": (c_int, [c_void_p, c_double_p, c_double_p, c_int, c_int]),
     "micloc_plan_generation": (c_int, [c_void_p]),
+    "micloc_plan_set_encoder_chunk": (c_int, [c_void_p, c_int]),
+    "micloc_plan_encoder_chunks": (c_int, [c_void_p, c_int, c_int]),
     "micloc_padded_T": (c_int, [c_int]),
     "micloc_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),
     "micloc_stht_f64": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
@@ -56,6 +58,8 @@ SYMBOLS = {
     "micloc_beamformer_pipeline_f64": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "micloc_rzcc_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "micloc_rzcc_encode_f64": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "micloc_rzcc_workspace_bytes_ex": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "micloc_rzcc_encode_ex_f64": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "micloc_lfilter_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "micloc_lfilter_f64": (c_int, [c_double_p, c_double_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "micloc_lif_beamform_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

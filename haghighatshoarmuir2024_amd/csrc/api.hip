@@ -40,6 +40,7 @@ struct micloc_plan {
     int G_out = 0;  // DoA grid size seen by the caller
     // bumped whenever a device table is re-allocated (captured hipGraphs holding the old pointers become stale)
     int generation = 0;
+    int chunk_frames = 0;  // encoder time chunking: 0 automatic, < 0 off, > 0 owned frames per chunk
     size_t taps_cap = 0, ntab_cap = 0, W_cap = 0;  // allocated doubles
 };
 
@@ -102,7 +103,7 @@ WsLayout ws_layout(const micloc_plan *p, int B, int T)
     w.pre = off;
     off += planar;
     w.scratch = off;
-    off += rzcc_scratch_bytes(B * p->C, T);
+    off += rzcc_scratch_bytes(B * p->C, T, p->robust_width, p->chunk_frames);
     w.spikes = off;
     off += align256((size_t)B * T * p->C);
     w.partial = off;
@@ -314,6 +315,19 @@ int micloc_plan_set_bf_mat_c128(micloc_plan *p, const double *Wre, const double 
 
 int micloc_plan_generation(const micloc_plan *p) { return p ? p->generation : -1; }
 
+int micloc_plan_set_encoder_chunk(micloc_plan *p, int chunk_frames)
+{
+    if (!p) return MICLOC_ERR_INVALID;
+    p->chunk_frames = chunk_frames;
+    return MICLOC_OK;
+}
+
+int micloc_plan_encoder_chunks(const micloc_plan *p, int B, int T)
+{
+    if (!p || bad_batch(B) || T < 1) return MICLOC_ERR_INVALID;
+    return rzcc_chunks(B * p->C, T, p->robust_width, p->chunk_frames);
+}
+
 size_t micloc_workspace_bytes(const micloc_plan *p, int B, int T)
 {
     if (!p || bad_batch(B) || T < 1) return 0;
@@ -337,9 +351,9 @@ int micloc_bandpass_rzcc_f64(const micloc_plan *p, const double *h, int B, int T
     DeviceGuard guard(p->device);  // launches and stream belong to the plan's device, whatever the caller's current one
     if (Ts != micloc_padded_T(T)) return MICLOC_ERR_SHAPE;
     const int nl = B * p->C;
-    if (spikes && bad_ws(ws, ws_bytes, rzcc_scratch_bytes(nl, T))) return MICLOC_ERR_WORKSPACE;
+    if (spikes && bad_ws(ws, ws_bytes, rzcc_scratch_bytes(nl, T, p->robust_width, p->chunk_frames))) return MICLOC_ERR_WORKSPACE;
     HIP_TRY(launch_bandpass_rzcc(p->iir, h, nl, p->C, T, Ts, p->robust_width, p->bipolar, pre, spikes, ws,
-                                 (hipStream_t)stream));
+                                 (hipStream_t)stream, nullptr, 0, 0, p->chunk_frames));
     return MICLOC_OK;
 }
 
@@ -407,7 +421,7 @@ int micloc_snn_pipeline_stages_f64(const micloc_plan *p, const double *x, int B,
     if (stages & MICLOC_STAGE_STHT) HIP_TRY(launch_stht(p->taps, x, h, B, T, p->M, Ts, st, false));
     if (stages & MICLOC_STAGE_ENCODE)
         HIP_TRY(launch_bandpass_rzcc(p->iir, h, B * p->C, p->C, T, Ts, p->robust_width, p->bipolar, nullptr, spk,
-                                     base + w.scratch, st, x, p->M, p->taps.shift));
+                                     base + w.scratch, st, x, p->M, p->taps.shift, p->chunk_frames));
     if (want_bf && (stages & MICLOC_STAGE_BEAMFORM)) {
         const int Gp = 16 * p->W.GT;
         const bool want_power = power || argmax;
@@ -446,18 +460,27 @@ int micloc_beamformer_pipeline_f64(const micloc_plan *p, const double *x, int B,
 }
 
 // ---- stand-alone operators -------------------------------------------------------------------------------
-size_t micloc_rzcc_workspace_bytes(int B, int T, int C)
+size_t micloc_rzcc_workspace_bytes(int B, int T, int C) { return micloc_rzcc_workspace_bytes_ex(B, T, C, 1, 0); }
+
+size_t micloc_rzcc_workspace_bytes_ex(int B, int T, int C, int robust_width, int chunk_frames)
 {
-    if (B < 1 || T < 1 || C < 1) return 0;
+    if (B < 1 || T < 1 || C < 1 || robust_width < 1) return 0;
     const size_t planar = align256((size_t)B * C * micloc_padded_T(T) * sizeof(double));
-    return planar + rzcc_scratch_bytes(B * C, T);
+    return planar + rzcc_scratch_bytes(B * C, T, robust_width, chunk_frames);
 }
 
 int micloc_rzcc_encode_f64(const double *sig, int B, int T, int C, int robust_width, int bipolar, int8_t *spikes,
                            void *ws, size_t ws_bytes, void *stream)
 {
+    return micloc_rzcc_encode_ex_f64(sig, B, T, C, robust_width, bipolar, 0, spikes, ws, ws_bytes, stream);
+}
+
+int micloc_rzcc_encode_ex_f64(const double *sig, int B, int T, int C, int robust_width, int bipolar, int chunk_frames,
+                              int8_t *spikes, void *ws, size_t ws_bytes, void *stream)
+{
     if (!sig || !spikes || bad_batch(B) || T < 1 || C < 1 || robust_width < 1) return MICLOC_ERR_INVALID;
-    if (bad_ws(ws, ws_bytes, micloc_rzcc_workspace_bytes(B, T, C))) return MICLOC_ERR_WORKSPACE;
+    // (the automatic choice does not depend on robust_width: micloc_rzcc_workspace_bytes(B, T, C) covers chunk_frames 0)
+    if (bad_ws(ws, ws_bytes, micloc_rzcc_workspace_bytes_ex(B, T, C, robust_width, chunk_frames))) return MICLOC_ERR_WORKSPACE;
     const int Ts = micloc_padded_T(T);
     unsigned char *base = reinterpret_cast<unsigned char *>(ws);
     double *planar = reinterpret_cast<double *>(base);
@@ -469,7 +492,7 @@ int micloc_rzcc_encode_f64(const double *sig, int B, int T, int C, int robust_wi
     id.b[0] = 1.0;  // fma(1, x, +0) == x: the identity filter keeps the stream bit-exact
     id.a[0] = 1.0;
     HIP_TRY(launch_bandpass_rzcc(id, planar, B * C, C, T, Ts, robust_width, bipolar ? 1 : 0, nullptr, spikes, scratch,
-                                 st));
+                                 st, nullptr, 0, 0, chunk_frames));
     return MICLOC_OK;
 }
 
@@ -562,7 +585,7 @@ int micloc_snn_pipeline_cov_f64(const micloc_plan *p, const double *x, int B, in
     // the in-phase channels are the rolled input frames: the band-pass kernel reads them from x directly
     HIP_TRY(launch_stht(p->taps, x, h, B, T, p->M, Ts, st, false));
     HIP_TRY(launch_bandpass_rzcc(p->iir, h, B * p->C, p->C, T, Ts, p->robust_width, p->bipolar, nullptr, spk,
-                                 base + w.scratch, st, x, p->M, p->taps.shift));
+                                 base + w.scratch, st, x, p->M, p->taps.shift, p->chunk_frames));
     double *partial = reinterpret_cast<double *>(base + w.partial);
     HIP_TRY(launch_lif_cov(p->ntab, spk, B, T, p->C, CT, t_start, partial, st));
     HIP_TRY(launch_cov_power(partial, B, T, CT, p->C, T - t_start, want_power ? p->W.Wp : nullptr,

@@ -33,11 +33,14 @@ struct IirCoef {
     int n;
 };
 
-// per-lane candidate lists (slot-major): pos [2][cap][nlanes] int32, val [2][cap][nlanes] double
-size_t rzcc_scratch_bytes(int nlanes, int T);
+// Scratch of the encoder: flagged-unit list, chunk checkpoints, fallback candidate lists (rzcc.hip "Time chunking").
+// chunk_frames: 0 = automatic, < 0 = never chunk, > 0 = owned frames per chunk.
+size_t rzcc_scratch_bytes(int nlanes, int T, int robust_width, int chunk_frames);
+int rzcc_chunks(int nlanes, int T, int robust_width, int chunk_frames);  // chunks per stream the launcher will use
 hipError_t launch_bandpass_rzcc(const IirCoef &coef, const double *h, int nlanes, int C, int T, int Ts,
                                 int robust_width, int bipolar, double *pre, int8_t *spikes, void *scratch,
-                                hipStream_t stream, const double *xin = nullptr, int M = 0, int shift = 0);
+                                hipStream_t stream, const double *xin = nullptr, int M = 0, int shift = 0,
+                                int chunk_frames = 0);
 // row-major [B][T][C] <-> planar [B][C][Ts]
 hipError_t launch_pack_planar(const double *src, double *dst, int B, int T, int C, int Ts, hipStream_t stream);
 hipError_t launch_unpack_planar(const double *src, double *dst, int B, int T, int C, int Ts, hipStream_t stream);

@@ -26,9 +26,11 @@
 //     independent clusters at every same-polarity gap >= distance.  After each tile the wave walks the NEW
 //     events (not the time steps), closes finished clusters, resolves them in LDS and scatters the kept
 //     peaks as +1 / -1 bytes into the zero-initialised [B][T][C] spike tensor.
-//   * a cluster that outgrows the LDS ring (pathological inputs: long runs of close peaks) flags its
-//     stream; flagged streams are redone by a slow list-based kernel with unbounded capacity, so the
-//     result is exact for every input.
+//   * a cluster that outgrows the LDS ring (long runs of close peaks) flags its (stream, chunk) unit; flagged
+//     units are redone by a slow list-based kernel with unbounded capacity, so the result is exact for
+//     every input.
+//   * long streams are cut into time chunks that run side by side, each restarted from the EXACT state a
+//     cheap serial scan stored at its boundary (see "Time chunking" below): bit-exact by construction.
 #include "micloc_internal.h"
 
 #include <type_traits>
@@ -110,17 +112,7 @@ __device__ __forceinline__ void resolve_cluster(int s, int e, int stride, int w,
     }
 }
 
-// ---------------------------------------------------------------------------------------------------
-// Fast path: a wave pipeline over 16-step tiles (one barrier per tile).
-//   wave L (loader)  tile k+1 -> LDS (loads issued two tiles earlier, into registers), stores filtered tiles
-//   wave F (filter)  tile k  : x -> band-pass -> cumulative sum, in place in LDS
-//   wave D (detect)  tile k-1: local maxima / minima of the cumulative sum -> candidate ring
-//   waves S0, S1 (select) tile k-2: walk the new candidates of one polarity each, close clusters, min-distance
-//                    greedy, scatter spikes
-// Each stage is a different wave of the workgroup, i.e. a different SIMD of the CU, so the serial chain of
-// one stream costs max(stage) instructions per time step instead of their sum.
-// ---------------------------------------------------------------------------------------------------
-constexpr int RZ_MT = 16;
+constexpr int RZ_MT = 16;  // time steps per tile of the wave pipeline (one barrier per tile)
 
 // ---- detect-stage helpers: per-lane updates driven by wave-level lane masks (SGPR pairs) ------------------------
 // v += 1 in the lanes of m (one VALU instruction: add with carry-in)
@@ -151,12 +143,12 @@ struct DetectState {
 // 8 VALU instructions: two fp64 compares, the append counter, the plateau edge, the candidate word and three for the
 // ring address; everything that concerns the direction of the last change is SALU work on lane masks.
 template <int J, typename RingP, typename RingV>
-__device__ __forceinline__ void detect_step(DetectState &d, double c, int word_base, uint64_t bip, int lane, RingP &ringP,
-                                            RingV &ringV)
+__device__ __forceinline__ void detect_step(DetectState &d, double c, int word_base, uint64_t bip, uint64_t live, int lane,
+                                            RingP &ringP, RingV &ringV)
 {
     const uint64_t rise = __builtin_amdgcn_fcmp(c, d.prev, 2);  // ordered >
     const uint64_t fall = __builtin_amdgcn_fcmp(c, d.prev, 4);  // ordered <
-    const uint64_t ev = (fall & d.dpos) | (bip & rise & d.dneg);
+    const uint64_t ev = ((fall & d.dpos) | (bip & rise & d.dneg)) & live;
     const int slot = d.n & (RZ_RING - 1);  // unconditional store; consumed only if n advances
     ringP[slot][lane] = d.lrel + word_base + J;  // left + t - 1; position = word >> 1 (plateau midpoint)
     ringV[slot][lane] = d.prev;                  // plateau value; minima negate it when they compare
@@ -193,8 +185,8 @@ __device__ __forceinline__ void detect_append(DetectState &d, const double (&c)[
 //             compile time.  6 instead of 12 SALU instructions per step -- they count: a single wave issues at most one
 //             instruction of ANY kind every ~4 cycles, and this wave is one stage of a latency-bound pipeline.
 template <int J0, int MODE, typename RingP, typename RingV>
-__device__ __forceinline__ void detect_half(DetectState &d, const double (&c)[RZ_MT], int word_base, uint64_t bip, int lane,
-                                            RingP &ringP, RingV &ringV)
+__device__ __forceinline__ void detect_half(DetectState &d, const double (&c)[RZ_MT], int word_base, uint64_t bip,
+                                            uint64_t live, int lane, RingP &ringP, RingV &ringV)
 {
     uint64_t rise[8], fall[8], ev[8];
 #pragma unroll
@@ -207,12 +199,12 @@ __device__ __forceinline__ void detect_half(DetectState &d, const double (&c)[RZ
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
         if (MODE == 0) {
-            ev[u] = (fall[u] & d.dpos) | (bip & rise[u] & d.dneg);
+            ev[u] = ((fall[u] & d.dpos) | (bip & rise[u] & d.dneg)) & live;
             d.ffall |= fall[u] & ~(d.dpos | d.dneg);
             d.dpos = rise[u] | (d.dpos & ~fall[u]);
             d.dneg = fall[u] | (d.dneg & ~rise[u]);
         } else {
-            ev[u] = MODE == 1 ? ((fall[u] & d.dpos) | (rise[u] & ~d.dpos)) : (fall[u] & d.dpos);
+            ev[u] = (MODE == 1 ? ((fall[u] & d.dpos) | (rise[u] & ~d.dpos)) : (fall[u] & d.dpos)) & live;
             d.dpos = rise[u] | (d.dpos & ~fall[u]);
         }
         rise[u] |= fall[u];  // strict change
@@ -222,11 +214,11 @@ __device__ __forceinline__ void detect_half(DetectState &d, const double (&c)[RZ
 }
 
 template <int MODE, typename RingP, typename RingV>
-__device__ __forceinline__ void detect_full(DetectState &d, const double (&c)[RZ_MT], int word_base, uint64_t bip, int lane,
-                                            RingP &ringP, RingV &ringV)
+__device__ __forceinline__ void detect_full(DetectState &d, const double (&c)[RZ_MT], int word_base, uint64_t bip,
+                                            uint64_t live, int lane, RingP &ringP, RingV &ringV)
 {
-    detect_half<0, MODE>(d, c, word_base, bip, lane, ringP, ringV);
-    detect_half<8, MODE>(d, c, word_base, bip, lane, ringP, ringV);
+    detect_half<0, MODE>(d, c, word_base, bip, live, lane, ringP, ringV);
+    detect_half<8, MODE>(d, c, word_base, bip, live, lane, ringP, ringV);
     if (MODE != 0) d.dneg = ~d.dpos;
     d.prev = c[RZ_MT - 1];
 }
@@ -234,16 +226,231 @@ __device__ __forceinline__ void detect_full(DetectState &d, const double (&c)[RZ
 // last, partial tile of a stream
 template <int J, typename Tile, typename RingP, typename RingV>
 __device__ __forceinline__ void detect_partial(DetectState &d, const Tile &tile, int steps, int word_base, uint64_t bip,
-                                               int lane, RingP &ringP, RingV &ringV)
+                                               uint64_t live, int lane, RingP &ringP, RingV &ringV)
 {
     if constexpr (J < RZ_MT) {
         if (J < steps) {  // uniform
-            detect_step<J>(d, tile[J][lane], word_base, bip, lane, ringP, ringV);
-            detect_partial<J + 1>(d, tile, steps, word_base, bip, lane, ringP, ringV);
+            detect_step<J>(d, tile[J][lane], word_base, bip, live, lane, ringP, ringV);
+            detect_partial<J + 1>(d, tile, steps, word_base, bip, live, lane, ringP, ringV);
         }
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Time chunking with exact state hand-off.
+//
+// The serial chain of a stream (DF2T state, running sum, detector state) cannot be re-associated without changing
+// bits, but it can be CHECKPOINTED: rzcc_scan_kernel walks every stream once with nothing but the band-pass and the
+// running sum (the cheapest possible serial pass: two waves per 64 streams) and stores the exact state at every
+// chunk boundary.  bandpass_rzcc_fast_kernel then runs one workgroup per (64 streams, chunk): it restarts the
+// recurrences from the stored state -- the same operations on the same operands, hence the same bits -- and does
+// the expensive part (detect + select + scatter) for its chunk, P chunks side by side.  With few, long streams
+// (speech: 1750 streams x 332 157 steps) this turns a 28-workgroup latency chain into a launch that fills the chip.
+//
+// Chunk p owns the clusters whose FIRST candidate lies in [own_lo, own_hi).  Clusters are separated by
+// same-polarity gaps >= w, so a chunk starts Vt tiles (>= w steps) early: every candidate that can chain into an
+// owned cluster is seen, and a cluster whose first seen member lies before own_lo belongs to the predecessor.
+// After own_hi it runs V2t more tiles to see its last cluster close; a cluster still open then, a ring overflow, or a
+// detector state the scan could not pin down (a plateau longer than a tile right at the boundary) flags the
+// (stream, chunk) unit, which rzcc_unit_fallback_kernel redoes serially from the same checkpoint with unbounded lists.
+// ---------------------------------------------------------------------------------------------------
+struct RzGeom {
+    int P;    // chunks per stream (1: one pass over the whole stream, no scan kernel)
+    int Lt;   // RZ_MT-step tiles owned by a chunk: chunk p owns the times [RZ_MT p Lt, RZ_MT (p+1) Lt)
+    int Vt;   // look-back tiles (RZ_MT Vt >= w)
+    int V2t;  // tail tiles
+};
+
+struct RzSpan {
+    int m_lo, m_hi;      // tiles processed: [m_lo, m_hi)
+    int own_lo, own_hi;  // owned cluster starts: [own_lo, own_hi)
+    bool at_end;         // m_hi is the end of the stream
+};
+
+__host__ __device__ inline RzSpan rz_span(const RzGeom &g, int p, int NM)
+{
+    RzSpan s;
+    s.m_lo = p == 0 ? 0 : p * g.Lt - g.Vt;
+    const int hi = (p + 1) * g.Lt + g.V2t;
+    s.m_hi = (p == g.P - 1 || hi > NM) ? NM : hi;
+    s.own_lo = p == 0 ? 0 : p * g.Lt * RZ_MT;
+    s.own_hi = p == g.P - 1 ? 0x7fffffff : (p + 1) * g.Lt * RZ_MT;
+    s.at_end = s.m_hi == NM;
+    return s;
+}
+
+// checkpoint q = p - 1 (state entering tile m_lo(p)):  doubles [q][N][nlanes]: DF2T state z_0..z_{N-2}, running sum;
+// ints [q][3][nlanes]: direction of the last strict change (RZ_DIR_*), its time, last tile that contained one
+constexpr int RZ_DIR_NONE = 0, RZ_DIR_RISE = 1, RZ_DIR_FALL = 2, RZ_DIR_UNKNOWN = 3;
+
+// ---- loader wave (shared by the scan and the encoder kernel) ----------------------------------------------------
+// 16-step x 64-stream input tiles from the planar [stream][Ts] layout (in-phase channels straight from the rolled
+// input frames) into a transposed LDS tile; two register sets keep the loads of two tiles in flight.
+template <bool WANT_PRE, typename XT, typename YT>
+__device__ __forceinline__ void rz_loader(XT &X, YT &Y, const double *__restrict__ h, double *__restrict__ pre,
+                                          const double *__restrict__ xin, int base, int nlanes, int C, int T, int Ts, int M,
+                                          int shift, int m_lo, int m_hi, int nstep, int lane)
+{
+    const int tl = lane & 15;  // time offset inside the tile
+    const int sq = lane >> 4;  // stream slot 0..3 of each group of four
+    const bool full_block = base + 64 <= nlanes;
+    double v[2][16];  // two register sets: the loads of tile m are issued two tiles before they are written to LDS
+    // Per-stream source.  Quadrature channels (and everything when xin == nullptr) come from the planar STHT
+    // buffer h; with xin != nullptr the in-phase channels c < M are read straight from the input frames,
+    // x[b][(t - L/2) mod T][c]  (np.roll, snn_beamformer.py:325), so the STHT kernel need not write them.
+    const double *pb[16];
+    bool rolled[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        int g = base + 4 * j + sq;
+        g = g < nlanes ? g : nlanes - 1;
+        const int bb = g / C, cc = g - bb * C;
+        rolled[j] = xin != nullptr && cc < M;
+        pb[j] = rolled[j] ? xin + (size_t)bb * T * M + cc : h + (size_t)g * Ts;
+    }
+    const int sh = shift % T;
+    auto issue_loads = [&](int m, auto set) {
+        constexpr int S = decltype(set)::value;
+        const int t = m * RZ_MT + tl;
+        const int tc = t < Ts ? t : Ts - 1;  // clamp: samples past T are never used
+        int tr = (t < T ? t : T - 1) - sh;
+        tr = tr < 0 ? tr + T : tr;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[S][j] = rolled[j] ? pb[j][(size_t)tr * M] : pb[j][tc];
+    };
+    auto write_tile = [&](int buf, auto set) {
+        constexpr int S = decltype(set)::value;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) X[buf][tl][4 * j + sq] = v[S][j];
+    };
+    auto store_tile = [&](int m) {  // (WANT_PRE launches are never chunked: m is also the buffer parity)
+        const int t = m * RZ_MT + tl;
+        const int yb = m & 1;
+        if (full_block && (m + 1) * RZ_MT <= Ts) {
+            double *p = pre + (size_t)(base + sq) * Ts + t;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) p[(size_t)(4 * j) * Ts] = Y[WANT_PRE ? yb : 0][WANT_PRE ? tl : 0][WANT_PRE ? 4 * j + sq : 0];
+        } else {
+#pragma unroll 4
+            for (int j = 0; j < 16; ++j) {
+                const int g = base + 4 * j + sq;
+                if (g < nlanes && t < Ts) pre[(size_t)g * Ts + t] = Y[WANT_PRE ? yb : 0][WANT_PRE ? tl : 0][WANT_PRE ? 4 * j + sq : 0];
+            }
+        }
+    };
+    using set0 = std::integral_constant<int, 0>;
+    using set1 = std::integral_constant<int, 1>;
+    // Loads and LDS writes are unconditional (tile index clamped; a tile past the end lands in a buffer nobody
+    // reads): with straight-line code the compiler's s_waitcnt vmcnt(N) leaves the younger register set in flight.
+    const int NMc = m_hi - m_lo;
+    auto clampm = [&](int kk) { return m_lo + (kk < NMc ? kk : NMc - 1); };
+    issue_loads(clampm(0), set0{});
+    write_tile(0, set0{});
+    issue_loads(clampm(1), set1{});
+    issue_loads(clampm(2), set0{});
+    __syncthreads();
+    // iteration k writes tile k+1 (register set (k+1) & 1) and refills that set with tile k+3
+    auto iter = [&](int k, auto set) {
+        write_tile((k + 1) % 3, set);
+        issue_loads(clampm(k + 3), set);
+        if (WANT_PRE && k >= 1 && k <= NMc) store_tile(k - 1);
+        __syncthreads();
+    };
+    int k = 0;
+    for (; k + 1 < nstep; k += 2) {
+        iter(k, set1{});
+        iter(k + 1, set0{});
+    }
+    if (k < nstep) iter(k, set1{});
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Scan: band-pass + running sum only, exact state at every chunk boundary.  Two waves per 64 streams (loader, filter).
+// ---------------------------------------------------------------------------------------------------
+template <int N>
+__global__ __launch_bounds__(128) void rzcc_scan_kernel(const double *__restrict__ h, IirCoef coef, int nlanes, int C, int T,
+                                                         int Ts, const double *__restrict__ xin, int M, int shift, RzGeom g,
+                                                         double *__restrict__ ckd, int *__restrict__ cki)
+{
+    __shared__ __attribute__((aligned(16))) double X[3][RZ_MT][RZ_ROW];
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int base = blockIdx.x * 64;
+    const int m_end = (g.P - 1) * g.Lt - g.Vt;  // tile of the last checkpoint: nothing to do beyond it
+    const int nstep = m_end + 1;
+    if (wave == 0) {
+        rz_loader<false>(X, X, h, nullptr, xin, base, nlanes, C, T, Ts, M, shift, 0, m_end, nstep, lane);
+        return;
+    }
+    // ------------------------------------ filter + checkpoints ----------------------------------------
+    const int lane_g = base + lane;
+    const bool active = lane_g < nlanes;
+    Iir<N> iir;
+    iir.init();
+    double cs = 0.0;
+    int chg_tile = -1;        // last tile with a strict change of the running sum
+    int dir = RZ_DIR_NONE;    // direction / time of the last strict change, valid when chg_tile is the previous tile
+    int left = 0;
+    int next_ck = g.Lt - g.Vt;
+    int q = 0;
+    __syncthreads();
+    for (int k = 0; k < nstep; ++k) {
+        if (k == next_ck) {
+            if (active) {
+                const size_t nl = (size_t)nlanes;
+#pragma unroll
+                for (int i = 0; i < N - 1; ++i) ckd[((size_t)q * N + i) * nl + lane_g] = iir.z[i];
+                ckd[((size_t)q * N + (N - 1)) * nl + lane_g] = cs;
+                // the detector state is exact if the last strict change happened in the tile just walked with full
+                // tracking (or never); otherwise only the tile of the last change is known
+                const int d = chg_tile < 0 ? RZ_DIR_NONE : (chg_tile == k - 1 ? dir : RZ_DIR_UNKNOWN);
+                cki[((size_t)q * 3 + 0) * nl + lane_g] = d;
+                cki[((size_t)q * 3 + 1) * nl + lane_g] = chg_tile < 0 ? 0 : left;
+                cki[((size_t)q * 3 + 2) * nl + lane_g] = chg_tile;
+            }
+            next_ck += g.Lt;
+            ++q;
+        }
+        if (k < m_end) {
+            const int buf = k % 3;
+            uint64_t chg = 0;
+            if (k + 1 == next_ck) {
+                // tile in front of a checkpoint: track direction and time of the last strict change
+#pragma unroll
+                for (int j = 0; j < RZ_MT; ++j) {
+                    const double y = iir.step(coef, X[buf][j][lane]);
+                    const double c1 = cs + y;
+                    const bool rise = c1 > cs, fall = c1 < cs;
+                    dir = rise ? RZ_DIR_RISE : (fall ? RZ_DIR_FALL : dir);
+                    left = (rise || fall) ? k * RZ_MT + j : left;
+                    chg |= __builtin_amdgcn_fcmp(c1, cs, 6);  // ordered != : exactly the detector's rise | fall
+                    cs = c1;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < RZ_MT; ++j) {
+                    const double y = iir.step(coef, X[buf][j][lane]);
+                    const double c1 = cs + y;
+                    chg |= __builtin_amdgcn_fcmp(c1, cs, 6);
+                    cs = c1;
+                }
+            }
+            chg_tile = ((chg >> lane) & 1) ? k : chg_tile;
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Encoder: a wave pipeline over 16-step tiles (one barrier per tile), one workgroup per (64 streams, chunk).
+//   wave L (loader)  tile k+1 -> LDS (loads issued two tiles earlier, into registers), stores filtered tiles
+//   wave F (filter)  tile k  : x -> band-pass -> cumulative sum, in place in LDS
+//   wave D (detect)  tile k-1: local maxima / minima of the cumulative sum -> candidate ring
+//   waves S0, S1 (select) tile k-2: walk the new candidates of one polarity each, close clusters, min-distance
+//                    greedy, scatter spikes
+// Each stage is a different wave of the workgroup, i.e. a different SIMD of the CU, so the serial chain of
+// one stream costs max(stage) instructions per time step instead of their sum.
+// ---------------------------------------------------------------------------------------------------
 template <int N, bool WANT_PRE, bool WANT_SPIKES>
 __global__ __launch_bounds__(320) void bandpass_rzcc_fast_kernel(const double *__restrict__ h,
                                                                   double *__restrict__ pre,
@@ -251,97 +458,38 @@ __global__ __launch_bounds__(320) void bandpass_rzcc_fast_kernel(const double *_
                                                                   int *__restrict__ flag_count,
                                                                   int *__restrict__ flag_list, IirCoef coef,
                                                                   int nlanes, int C, int T, int Ts, int w, int bipolar,
-                                                                  const double *__restrict__ xin, int M, int shift)
+                                                                  const double *__restrict__ xin, int M, int shift,
+                                                                  RzGeom g, int nblk, const double *__restrict__ ckd,
+                                                                  const int *__restrict__ cki)
 {
     __shared__ __attribute__((aligned(16))) double X[3][RZ_MT][RZ_ROW];
     __shared__ double Y[WANT_PRE ? 2 : 1][WANT_PRE ? RZ_MT : 1][WANT_PRE ? RZ_ROW : 1];
     __shared__ double ringV[WANT_SPIKES ? RZ_RING : 1][64];
     __shared__ int ringP[WANT_SPIKES ? RZ_RING : 1][64];
     __shared__ int nPub[64];
-    __shared__ int polPub[64];  // 1: the stream's first candidate is a minimum (candidates alternate from there)
+    __shared__ int polPub[64];     // 1: the stream's first candidate is a minimum (candidates alternate from there)
     __shared__ int deadPub[64];
+    __shared__ int ovPub[64];      // the detect wave found the ring full (or the checkpoint unusable): unit flagged
+    __shared__ int leftPub[64];    // time of the last strict change when the detect wave stopped
+    __shared__ int oldPub[2][64];  // per polarity: oldest ring entry the select wave still needs
 
     // 0: loader, 1: filter, 2: detect, 3: select maxima, 4: select minima (wave 4 shares its SIMD with the loader)
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
-    const int base = blockIdx.x * 64;
-    const int NM = (T + RZ_MT - 1) / RZ_MT;
+    const int blk = blockIdx.x % nblk;
+    const int p = blockIdx.x / nblk;
+    const int base = blk * 64;
+    const RzSpan sp_ = rz_span(g, p, (T + RZ_MT - 1) / RZ_MT);
+    const int m_lo = sp_.m_lo;
+    const int NM = sp_.m_hi - sp_.m_lo;  // tiles of this chunk
     const int NSTEP = WANT_SPIKES ? NM + 2 : NM + 1;
     const int lane_g = base + lane;
     const bool active = lane_g < nlanes;
+    const int lane_c = active ? lane_g : nlanes - 1;  // clamped: inactive lanes shadow the last stream, results unused
+    const size_t nl = (size_t)nlanes;
 
     if (wave == 0) {
-        // ------------------------------------ loader ---------------------------------------------------
-        const int tl = lane & 15;  // time offset inside the tile
-        const int sq = lane >> 4;  // stream slot 0..3 of each group of four
-        const bool full_block = base + 64 <= nlanes;
-        double v[2][16];  // two register sets: the loads of tile m are issued two tiles before they are written to LDS
-        // Per-stream source.  Quadrature channels (and everything when xin == nullptr) come from the planar STHT
-        // buffer h; with xin != nullptr the in-phase channels c < M are read straight from the input frames,
-        // x[b][(t - L/2) mod T][c]  (np.roll, snn_beamformer.py:325), so the STHT kernel need not write them.
-        const double *pb[16];
-        bool rolled[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            int g = base + 4 * j + sq;
-            g = g < nlanes ? g : nlanes - 1;
-            const int bb = g / C, cc = g - bb * C;
-            rolled[j] = xin != nullptr && cc < M;
-            pb[j] = rolled[j] ? xin + (size_t)bb * T * M + cc : h + (size_t)g * Ts;
-        }
-        const int sh = shift % T;
-        auto issue_loads = [&](int m, auto set) {
-            constexpr int S = decltype(set)::value;
-            const int t = m * RZ_MT + tl;
-            const int tc = t < Ts ? t : Ts - 1;  // clamp: samples past T are never used
-            int tr = (t < T ? t : T - 1) - sh;
-            tr = tr < 0 ? tr + T : tr;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) v[S][j] = rolled[j] ? pb[j][(size_t)tr * M] : pb[j][tc];
-        };
-        auto write_tile = [&](int buf, auto set) {
-            constexpr int S = decltype(set)::value;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) X[buf][tl][4 * j + sq] = v[S][j];
-        };
-        auto store_tile = [&](int m) {
-            const int t = m * RZ_MT + tl;
-            const int yb = m & 1;
-            if (full_block && (m + 1) * RZ_MT <= Ts) {
-                double *p = pre + (size_t)(base + sq) * Ts + t;
-#pragma unroll
-                for (int j = 0; j < 16; ++j) p[(size_t)(4 * j) * Ts] = Y[WANT_PRE ? yb : 0][WANT_PRE ? tl : 0][WANT_PRE ? 4 * j + sq : 0];
-            } else {
-#pragma unroll 4
-                for (int j = 0; j < 16; ++j) {
-                    const int g = base + 4 * j + sq;
-                    if (g < nlanes && t < Ts) pre[(size_t)g * Ts + t] = Y[WANT_PRE ? yb : 0][WANT_PRE ? tl : 0][WANT_PRE ? 4 * j + sq : 0];
-                }
-            }
-        };
-        using set0 = std::integral_constant<int, 0>;
-        using set1 = std::integral_constant<int, 1>;
-        // Loads and LDS writes are unconditional (tile index clamped; a tile past the end lands in a buffer nobody
-        // reads): with straight-line code the compiler's s_waitcnt vmcnt(N) leaves the younger register set in flight.
-        auto clampm = [&](int m) { return m < NM ? m : NM - 1; };
-        issue_loads(0, set0{});
-        write_tile(0, set0{});
-        issue_loads(clampm(1), set1{});
-        issue_loads(clampm(2), set0{});
-        __syncthreads();
-        // iteration k writes tile k+1 (register set (k+1) & 1) and refills that set with tile k+3
-        auto iter = [&](int k, auto set) {
-            write_tile((k + 1) % 3, set);
-            issue_loads(clampm(k + 3), set);
-            if (WANT_PRE && k >= 1 && k <= NM) store_tile(k - 1);
-            __syncthreads();
-        };
-        int k = 0;
-        for (; k + 1 < NSTEP; k += 2) {
-            iter(k, set1{});
-            iter(k + 1, set0{});
-        }
-        if (k < NSTEP) iter(k, set1{});
+        rz_loader<WANT_PRE>(X, Y, h, pre, xin, base, nlanes, C, T, Ts, M, shift, m_lo, sp_.m_hi, NSTEP, lane);
         return;
     }
 
@@ -350,11 +498,17 @@ __global__ __launch_bounds__(320) void bandpass_rzcc_fast_kernel(const double *_
         Iir<N> iir;
         iir.init();
         double cs = 0.0;
+        if (p > 0) {
+#pragma unroll
+            for (int i = 0; i < N - 1; ++i) iir.z[i] = ckd[((size_t)(p - 1) * N + i) * nl + lane_c];
+            cs = ckd[((size_t)(p - 1) * N + (N - 1)) * nl + lane_c];
+        }
         __syncthreads();
         for (int k = 0; k < NSTEP; ++k) {
             if (k < NM) {
                 const int buf = k % 3;
-                const int steps = (T - k * RZ_MT) < RZ_MT ? (T - k * RZ_MT) : RZ_MT;
+                const int tb = (m_lo + k) * RZ_MT;
+                const int steps = (T - tb) < RZ_MT ? (T - tb) : RZ_MT;
                 auto one = [&](int j) {
                     const double y = iir.step(coef, X[buf][j][lane]);
                     if (WANT_PRE) Y[WANT_PRE ? (k & 1) : 0][WANT_PRE ? j : 0][WANT_PRE ? lane : 0] = y;
@@ -387,29 +541,57 @@ __global__ __launch_bounds__(320) void bandpass_rzcc_fast_kernel(const double *_
         d.lrel = 0;
         d.n = 0;
         d.dpos = d.dneg = d.ffall = 0;
+        uint64_t live = ~0ull;  // lanes that may still append (ring space checked before every tile)
+        if (p > 0) {
+            // detector state at the chunk start, from the scan's checkpoint
+            const int dir = cki[((size_t)(p - 1) * 3 + 0) * nl + lane_c];
+            const int left = cki[((size_t)(p - 1) * 3 + 1) * nl + lane_c];
+            d.prev = ckd[((size_t)(p - 1) * N + (N - 1)) * nl + lane_c];
+            d.lrel = left - m_lo * RZ_MT;
+            d.dpos = __ballot(dir == RZ_DIR_RISE);
+            d.dneg = __ballot(dir == RZ_DIR_FALL);
+            d.ffall = d.dneg;
+            live = ~__ballot(dir == RZ_DIR_UNKNOWN);
+        }
         const uint64_t bip = bipolar ? ~0ull : 0ull;
         nPub[lane] = 0;
         polPub[lane] = 0;
+        ovPub[lane] = (int)((~live >> lane) & 1);
         __syncthreads();
         for (int k = 0; k < NSTEP; ++k) {
             if (k >= 1 && k <= NM) {
                 const int m = k - 1;
-                const int tbase = m * RZ_MT;
+                const int tbase = (m_lo + m) * RZ_MT;
                 const int steps = (T - tbase) < RZ_MT ? (T - tbase) : RZ_MT;
+                // Ring space for a whole tile of appends?  oldPub lags by one barrier and only grows: conservative.
+                {
+                    const int o0 = oldPub[0][lane], o1 = oldPub[1][lane];
+                    const int oldest = bipolar ? (o0 < o1 ? o0 : o1) : o0;
+                    // After this tile at most RZ_RING - 1 entries may be pending, so that one slot -- the one in front
+                    // of the oldest pending entry -- is always free: a lane that has to stop appending parks its
+                    // (unconditional) ring writes there, where the select waves never look.
+                    const uint64_t full = __ballot(d.n + RZ_MT - oldest > RZ_RING - 1);
+                    if (full & live) {  // uniform
+                        d.n = ((full >> lane) & 1) ? oldest + RZ_RING - 1 : d.n;
+                        live &= ~full;
+                        ovPub[lane] = (int)((~live >> lane) & 1);
+                    }
+                }
                 // left + t - 1 = (tbase + lrel) + (tbase + j) - 1
                 if (steps == RZ_MT) {
                     double c[RZ_MT];
 #pragma unroll
                     for (int j = 0; j < RZ_MT; ++j) c[j] = X[m % 3][j][lane];
                     if ((d.dpos | d.dneg) != ~0ull)  // uniform
-                        detect_full<0>(d, c, 2 * tbase - 1, bip, lane, ringP, ringV);
+                        detect_full<0>(d, c, 2 * tbase - 1, bip, live, lane, ringP, ringV);
                     else if (bipolar)
-                        detect_full<1>(d, c, 2 * tbase - 1, bip, lane, ringP, ringV);
+                        detect_full<1>(d, c, 2 * tbase - 1, bip, live, lane, ringP, ringV);
                     else
-                        detect_full<2>(d, c, 2 * tbase - 1, bip, lane, ringP, ringV);
+                        detect_full<2>(d, c, 2 * tbase - 1, bip, live, lane, ringP, ringV);
                 } else {
-                    detect_partial<0>(d, X[m % 3], steps, 2 * tbase - 1, bip, lane, ringP, ringV);
+                    detect_partial<0>(d, X[m % 3], steps, 2 * tbase - 1, bip, live, lane, ringP, ringV);
                 }
+                if (k == NM) leftPub[lane] = d.lrel + tbase;
                 d.lrel -= RZ_MT;
                 nPub[lane] = d.n;
                 polPub[lane] = (int)((d.ffall >> lane) & 1);
@@ -429,24 +611,30 @@ __global__ __launch_bounds__(320) void bandpass_rzcc_fast_kernel(const double *_
     int s_open = -1;      // first list index of the open cluster (-1: none)
     int l_last = 0;       // position of the last own candidate
     bool dead = !active;  // ring overflow (or lane out of range): stop selecting; redone by the fallback kernel
-    const int b = active ? lane_g / C : 0;
-    const int ch = active ? lane_g - b * C : 0;
+    const int b = lane_c / C;
+    const int ch = lane_c - b * C;
     int8_t *sp = spikes + (size_t)b * T * C + ch;
     const int8_t mark = mypol ? -1 : 1;
     const double sgn = mypol ? -1.0 : 1.0;
+    const int own_lo = sp_.own_lo, own_hi = sp_.own_hi;
     auto word_at = [&](int i) { return &ringP[i & (RZ_RING - 1)][lane]; };
     auto val_at = [&](int i) { return &ringV[i & (RZ_RING - 1)][lane]; };
     auto close_cluster = [&](int s, int e, int lastpos) {
+        const int first = *word_at(s) >> 1;
+        if (first < own_lo || first >= own_hi) return;  // the cluster belongs to a neighbouring chunk
         if (e - s <= stride)
             sp[(size_t)lastpos * C] = mark;
         else
             resolve_cluster(s, e, stride, w, mark, sp, C, word_at, val_at, sgn);
     };
     if (mypol == 0) deadPub[lane] = 0;
+    oldPub[mypol][lane] = 0;
+    if (!mine) oldPub[mypol][lane] = 0x7fffffff;
     __syncthreads();
     for (int k = 0; k < NSTEP; ++k) {
         if (k >= 2 && mine) {
             const int n = nPub[lane];  // candidates published by the detect wave before the last barrier
+            if (ovPub[lane]) dead = true;
             if (i_next < 0 && n > 0) i_next = bipolar ? (polPub[lane] ^ mypol) : 0;
             while (__any(!dead && i_next >= 0 && i_next < n)) {
                 if (!dead && i_next >= 0 && i_next < n) {
@@ -461,97 +649,177 @@ __global__ __launch_bounds__(320) void bandpass_rzcc_fast_kernel(const double *_
                     i_next = i + stride;
                 }
             }
-            // the detect wave runs up to two tiles ahead of what has been selected: everything still open must
-            // survive 2 * RZ_MT more appends
-            const int oldest = s_open >= 0 ? s_open : n;
-            if (!dead && n - oldest >= RZ_RING - 2 * RZ_MT) dead = true;
+            // everything from the open cluster on must survive in the ring; without one, everything not yet examined
+            oldPub[mypol][lane] = dead ? 0x7fffffff : (s_open >= 0 ? s_open : (i_next >= 0 ? i_next : 0));
         }
         __syncthreads();
     }
     if (active && mine) {
-        if (!dead) {
-            if (s_open >= 0) close_cluster(s_open, nPub[lane], l_last);
-        } else if (atomicExch(&deadPub[lane], 1) == 0) {  // flag the stream once, whichever polarity overflowed
+        if (ovPub[lane]) dead = true;
+        if (!dead && s_open >= 0) {
+            const int first = *word_at(s_open) >> 1;
+            if (first >= own_lo && first < own_hi) {
+                // the next candidate the stream can still produce completes after the last step of this chunk:
+                // position >= (left + t_end) >> 1.  Closed iff that is >= w away (or the stream ends here).
+                const int t_end = (m_lo + NM) * RZ_MT;
+                if (sp_.at_end || ((leftPub[lane] + t_end) >> 1) - l_last >= w)
+                    close_cluster(s_open, nPub[lane], l_last);
+                else
+                    dead = true;
+            }
+        }
+        if (dead && atomicExch(&deadPub[lane], 1) == 0) {  // flag the unit once, whichever polarity gave up
             const int kk = atomicAdd(flag_count, 1);
-            flag_list[kk] = lane_g;
+            flag_list[kk] = p * nlanes + lane_g;
         }
     }
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Fallback for flagged streams: unbounded candidate lists in global scratch (slot-major), selection
-// after the stream.  Slow (conditional global stores in the serial loop) but exact for any input.
+// Fallback for flagged (stream, chunk) units: serial walk from the chunk's checkpoint, unbounded candidate lists in
+// global scratch (slot-major), selection afterwards.  Slow (conditional global stores in the serial loop) but exact
+// for any input.  Slot s handles the flagged units s, s + nslots, ... one after the other.
 // ---------------------------------------------------------------------------------------------------
 template <int N>
-__global__ __launch_bounds__(64) void rzcc_fallback_kernel(const double *__restrict__ h, int8_t *__restrict__ spikes,
-                                                            const int *__restrict__ flag_count,
-                                                            const int *__restrict__ flag_list, int *__restrict__ plist,
-                                                            double *__restrict__ vlist, IirCoef coef, int nlanes,
-                                                            int C, int T, int Ts, int w, int bipolar,
-                                                            const double *__restrict__ xin, int M, int shift)
+__global__ __launch_bounds__(64) void rzcc_unit_fallback_kernel(const double *__restrict__ h, int8_t *__restrict__ spikes,
+                                                                 const int *__restrict__ flag_count,
+                                                                 const int *__restrict__ flag_list, int *__restrict__ plist,
+                                                                 double *__restrict__ vlist, int nslots, IirCoef coef,
+                                                                 int nlanes, int C, int T, int Ts, int w, int bipolar,
+                                                                 const double *__restrict__ xin, int M, int shift, RzGeom g,
+                                                                 const double *__restrict__ ckd, const int *__restrict__ cki)
 {
-    const int idx = blockIdx.x * 64 + threadIdx.x;
-    if (idx >= *flag_count) return;
-    const int lane_g = flag_list[idx];
-    const int b = lane_g / C;
-    const int ch = lane_g - b * C;
-    const bool rolled = xin != nullptr && ch < M;
-    const double *src = rolled ? xin + (size_t)b * T * M + ch : h + (size_t)lane_g * Ts;
+    const int slot = blockIdx.x * 64 + threadIdx.x;
+    if (slot >= nslots) return;
+    const int count = *flag_count;
+    const int NMall = (T + RZ_MT - 1) / RZ_MT;
+    const size_t NS = (size_t)nslots;
+    const size_t nl = (size_t)nlanes;
+    int *P = plist + slot;
+    double *V = vlist + slot;
     const int sh = shift % T;
-    const size_t NL = (size_t)nlanes;
-    int *P = plist + idx;
-    double *V = vlist + idx;
+    auto word_at = [&](int i) { return P + (size_t)i * NS; };
+    auto val_at = [&](int i) { return V + (size_t)i * NS; };
 
-    Iir<N> iir;
-    iir.init();
-    double c = 0.0, prev = __builtin_nan("");
-    int left = 0, dir = 0, n = 0;
-    for (int t = 0; t < T; ++t) {
-        int tr = t - sh;
-        tr = tr < 0 ? tr + T : tr;
-        const double y = iir.step(coef, rolled ? src[(size_t)tr * M] : src[t]);
-        c = c + y;
-        const bool rise = c > prev;
-        const bool fall = c < prev;
-        if ((fall && dir > 0) || (bipolar && rise && dir < 0)) {
-            P[(size_t)n * NL] = ((left + t - 1) & ~1) | (rise ? 1 : 0);
-            V[(size_t)n * NL] = rise ? -prev : prev;
-            ++n;  // n <= T - 1 < capacity T
+    for (int idx = slot; idx < count; idx += nslots) {
+        const int unit = flag_list[idx];
+        const int p = unit / nlanes;
+        const int lane_g = unit - p * nlanes;
+        const RzSpan span = rz_span(g, p, NMall);
+        const int b = lane_g / C;
+        const int ch = lane_g - b * C;
+        const bool rolled = xin != nullptr && ch < M;
+        const double *src = rolled ? xin + (size_t)b * T * M + ch : h + (size_t)lane_g * Ts;
+        auto sample = [&](int t) {
+            int tr = t - sh;
+            tr = tr < 0 ? tr + T : tr;
+            return rolled ? src[(size_t)tr * M] : src[t];
+        };
+        Iir<N> iir;
+        auto load_ck = [&](int q, double &cs) {  // q < 0: the stream start
+            iir.init();
+            cs = 0.0;
+            if (q >= 0) {
+#pragma unroll
+                for (int i = 0; i < N - 1; ++i) iir.z[i] = ckd[((size_t)q * N + i) * nl + lane_g];
+                cs = ckd[((size_t)q * N + (N - 1)) * nl + lane_g];
+            }
+        };
+        double c = 0.0;
+        int left = 0, dir = 0;  // dir: +1 rise, -1 fall, 0 none yet
+        if (p > 0) {
+            const int dcode = cki[((size_t)(p - 1) * 3 + 0) * nl + lane_g];
+            left = cki[((size_t)(p - 1) * 3 + 1) * nl + lane_g];
+            dir = dcode == RZ_DIR_RISE ? 1 : (dcode == RZ_DIR_FALL ? -1 : 0);
+            if (dcode == RZ_DIR_UNKNOWN) {
+                // the last strict change lies in tile Lc, more than a tile before this chunk: walk that tile again from
+                // the nearest checkpoint at or before it
+                const int Lc = cki[((size_t)(p - 1) * 3 + 2) * nl + lane_g];
+                int pq = (Lc + g.Vt) / g.Lt;  // largest chunk whose first tile is <= Lc
+                pq = pq > p - 1 ? p - 1 : pq;
+                load_ck(pq - 1, c);
+                const int t0 = pq == 0 ? 0 : (pq * g.Lt - g.Vt) * RZ_MT;
+                for (int t = t0; t < (Lc + 1) * RZ_MT; ++t) {
+                    const double c1 = c + iir.step(coef, sample(t));
+                    if (c1 > c) {
+                        dir = 1;
+                        left = t;
+                    } else if (c1 < c) {
+                        dir = -1;
+                        left = t;
+                    }
+                    c = c1;
+                }
+            }
         }
-        left = (rise || fall) ? t : left;
-        dir = rise ? 1 : (fall ? -1 : dir);
-        prev = c;
-    }
+        load_ck(p - 1, c);
+        double prev = p > 0 ? c : __builtin_nan("");
 
-    int8_t *sp = spikes + (size_t)b * T * C + ch;
-    const int stride = bipolar ? 2 : 1;
-    auto word_at = [&](int i) { return P + (size_t)i * NL; };
-    auto val_at = [&](int i) { return V + (size_t)i * NL; };
-    const int first_pol = n > 0 ? (P[0] & 1) : 0;
-    for (int pol = 0; pol < (bipolar ? 2 : 1); ++pol) {
-        const int8_t mark = pol ? -1 : 1;
-        const int i0 = bipolar ? (first_pol == pol ? 0 : 1) : 0;
-        if (i0 >= n) continue;
-        int s = i0;
-        int plast = *word_at(i0) >> 1;
-        for (int i = i0 + stride;; i += stride) {
-            const bool has = i < n;
-            int pi = 0;
-            bool closes = true;
-            if (has) {
-                pi = *word_at(i) >> 1;
-                closes = (pi - plast) >= w;
+        // ---- candidates from the chunk start until every owned cluster has provably closed -------------------
+        int n = 0;
+        int lastpos[2] = {0, 0};
+        bool seen[2] = {false, false};
+        bool done[2] = {false, !bipolar};
+        const int t_lo = span.m_lo * RZ_MT;
+        for (int t = t_lo; t < T && !(done[0] && done[1]); ++t) {
+            const double y = iir.step(coef, sample(t));
+            c = c + y;
+            const bool rise = c > prev;
+            const bool fall = c < prev;
+            if ((fall && dir > 0) || (bipolar && rise && dir < 0)) {
+                const int pol = rise ? 1 : 0;
+                const int pos = (left + t - 1) >> 1;
+                P[(size_t)n * NS] = ((left + t - 1) & ~1) | pol;
+                V[(size_t)n * NS] = rise ? -prev : prev;
+                ++n;  // n <= T - 1 < capacity T
+                // a cluster that starts at or after own_hi: every owned cluster of this polarity is closed
+                if ((!seen[pol] || pos - lastpos[pol] >= w) && pos >= span.own_hi) done[pol] = true;
+                seen[pol] = true;
+                lastpos[pol] = pos;
             }
-            if (closes) {
-                const int e = has ? i : n;
-                if (e - s <= stride)
-                    sp[(size_t)plast * C] = mark;
-                else
-                    resolve_cluster(s, e, stride, w, mark, sp, C, word_at, val_at, 1.0);
-                s = i;
+            left = (rise || fall) ? t : left;
+            dir = rise ? 1 : (fall ? -1 : dir);
+            prev = c;
+            // no candidate of either polarity can still appear before (left + t + 1) >> 1
+            const int nextpos = (left + t + 1) >> 1;
+            if (nextpos >= span.own_hi) {
+                if (!seen[0] || nextpos - lastpos[0] >= w) done[0] = true;
+                if (!seen[1] || nextpos - lastpos[1] >= w) done[1] = true;
             }
-            if (!has) break;
-            plast = pi;
+        }
+
+        // ---- clusters of each polarity; the owned ones are resolved and scattered -----------------------------
+        int8_t *sp = spikes + (size_t)b * T * C + ch;
+        const int stride = bipolar ? 2 : 1;
+        const int first_pol = n > 0 ? (P[0] & 1) : 0;
+        for (int pol = 0; pol < (bipolar ? 2 : 1); ++pol) {
+            const int8_t mark = pol ? -1 : 1;
+            const int i0 = bipolar ? (first_pol == pol ? 0 : 1) : 0;
+            if (i0 >= n) continue;
+            int s = i0;
+            int plast = *word_at(i0) >> 1;
+            for (int i = i0 + stride;; i += stride) {
+                const bool has = i < n;
+                int pi = 0;
+                bool closes = true;
+                if (has) {
+                    pi = *word_at(i) >> 1;
+                    closes = (pi - plast) >= w;
+                }
+                if (closes) {
+                    const int e = has ? i : n;
+                    const int first = *word_at(s) >> 1;
+                    if (first >= span.own_lo && first < span.own_hi) {
+                        if (e - s <= stride)
+                            sp[(size_t)plast * C] = mark;
+                        else
+                            resolve_cluster(s, e, stride, w, mark, sp, C, word_at, val_at, 1.0);
+                    }
+                    s = i;
+                }
+                if (!has) break;
+                plast = pi;
+            }
         }
     }
 }
@@ -580,57 +848,130 @@ static hipError_t zero_fill(void *ptr, size_t bytes, hipStream_t stream)
     return hipGetLastError();
 }
 
-size_t rzcc_scratch_bytes(int nlanes, int T)
+// ---- launch geometry and scratch layout -------------------------------------------------------------------------
+// chunk_frames: 0 = automatic, < 0 = never chunk, > 0 = owned frames per chunk (rounded up to whole tiles)
+static RzGeom rz_geom(int nlanes, int T, int w, int chunk_frames)
 {
-    size_t bytes = 256;                                         // flagged-stream counter
-    bytes += ((size_t)nlanes * sizeof(int) + 255) & ~(size_t)255;  // flagged-stream list
-    bytes += (size_t)T * nlanes * sizeof(double);               // fallback priority lists
-    bytes += (size_t)T * nlanes * sizeof(int);                  // fallback position lists
-    return (bytes + 255) & ~(size_t)255;
+    RzGeom g;
+    const int NM = (T + RZ_MT - 1) / RZ_MT;
+    const int nblk = (nlanes + 63) / 64;
+    g.Vt = (w + RZ_MT - 1) / RZ_MT;
+    if (g.Vt < 1) g.Vt = 1;
+    g.V2t = 4;
+    int Lt = NM;
+    if (chunk_frames > 0) {
+        Lt = (chunk_frames + RZ_MT - 1) / RZ_MT;
+    } else if (chunk_frames == 0) {
+        // Few workgroups and long streams: split so that about 2048 workgroups exist (8 per CU), chunks of at least 2048
+        // frames (look-back + tail tiles cost 4 %).  Launches that already fill the chip stay one exact pass: the
+        // scan's serial walk would be pure overhead there.
+        if (nblk < 160 && NM >= 2 * 128) {
+            const int want = (2048 + nblk - 1) / nblk;
+            Lt = (NM + want - 1) / want;
+            if (Lt < 128) Lt = 128;
+        }
+    }
+    if (Lt < g.Vt + 1) Lt = g.Vt + 1;
+    int P = (NM + Lt - 1) / Lt;
+    // unit ids p * nlanes + lane must fit an int; keep the checkpoint tables small
+    while (P > 1 && ((long long)P * nlanes >= (1ll << 30) || P > 4096)) {
+        Lt *= 2;
+        P = (NM + Lt - 1) / Lt;
+    }
+    if (P < 1) P = 1;
+    g.P = P;
+    g.Lt = P == 1 ? NM : Lt;
+    return g;
 }
+
+struct RzScratch {
+    size_t count, list, ckd, cki, vlist, plist, total;
+    int nslots;
+};
+
+static RzScratch rz_scratch(int nlanes, int T, int P)
+{
+    RzScratch s;
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    size_t off = 0;
+    s.count = off;
+    off += 256;
+    s.list = off;
+    off += al((size_t)P * nlanes * sizeof(int));
+    s.ckd = off;
+    off += al((size_t)(P > 1 ? P - 1 : 0) * MICLOC_MAX_IIR * nlanes * sizeof(double));
+    s.cki = off;
+    off += al((size_t)(P > 1 ? P - 1 : 0) * 3 * nlanes * sizeof(int));
+    // fallback candidate lists: T entries per slot (a unit may have to walk to the end of its stream), at most 256 MiB
+    long long slots = (256ll << 20) / (12ll * (T > 0 ? T : 1));
+    if (slots < 64) slots = 64;
+    if (slots > (long long)P * nlanes) slots = (long long)P * nlanes;
+    if (slots > 4096) slots = 4096;
+    s.nslots = (int)slots;
+    s.vlist = off;
+    off += al((size_t)T * s.nslots * sizeof(double));
+    s.plist = off;
+    off += al((size_t)T * s.nslots * sizeof(int));
+    s.total = al(off);
+    return s;
+}
+
+size_t rzcc_scratch_bytes(int nlanes, int T, int w, int chunk_frames)
+{
+    return rz_scratch(nlanes, T, rz_geom(nlanes, T, w, chunk_frames).P).total;
+}
+
+int rzcc_chunks(int nlanes, int T, int w, int chunk_frames) { return rz_geom(nlanes, T, w, chunk_frames).P; }
 
 template <int N>
 static void launch_rz(const IirCoef &coef, const double *h, int nlanes, int C, int T, int Ts, int w, int bipolar,
-                      double *pre, int8_t *spikes, int *flag_count, int *flag_list, int *plist, double *vlist,
+                      double *pre, int8_t *spikes, unsigned char *scratch, const RzGeom &g, const RzScratch &sc,
                       const double *xin, int M, int shift, hipStream_t stream)
 {
-    dim3 grid((nlanes + 63) / 64), block(spikes ? 320 : 128);
+    const int nblk = (nlanes + 63) / 64;
+    int *flag_count = scratch ? reinterpret_cast<int *>(scratch + sc.count) : nullptr;
+    int *flag_list = scratch ? reinterpret_cast<int *>(scratch + sc.list) : nullptr;
+    double *ckd = scratch ? reinterpret_cast<double *>(scratch + sc.ckd) : nullptr;
+    int *cki = scratch ? reinterpret_cast<int *>(scratch + sc.cki) : nullptr;
+    if (g.P > 1)
+        hipLaunchKernelGGL((rzcc_scan_kernel<N>), dim3(nblk), dim3(128), 0, stream, h, coef, nlanes, C, T, Ts, xin, M, shift,
+                           g, ckd, cki);
+    dim3 grid(nblk * g.P), block(spikes ? 320 : 128);
     if (pre && spikes)
         hipLaunchKernelGGL((bandpass_rzcc_fast_kernel<N, true, true>), grid, block, 0, stream, h, pre, spikes,
-                           flag_count, flag_list, coef, nlanes, C, T, Ts, w, bipolar, xin, M, shift);
+                           flag_count, flag_list, coef, nlanes, C, T, Ts, w, bipolar, xin, M, shift, g, nblk, ckd, cki);
     else if (spikes)
         hipLaunchKernelGGL((bandpass_rzcc_fast_kernel<N, false, true>), grid, block, 0, stream, h, pre, spikes,
-                           flag_count, flag_list, coef, nlanes, C, T, Ts, w, bipolar, xin, M, shift);
+                           flag_count, flag_list, coef, nlanes, C, T, Ts, w, bipolar, xin, M, shift, g, nblk, ckd, cki);
     else
         hipLaunchKernelGGL((bandpass_rzcc_fast_kernel<N, true, false>), grid, block, 0, stream, h, pre, spikes,
-                           flag_count, flag_list, coef, nlanes, C, T, Ts, w, bipolar, xin, M, shift);
+                           flag_count, flag_list, coef, nlanes, C, T, Ts, w, bipolar, xin, M, shift, g, nblk, ckd, cki);
     if (spikes)
-        hipLaunchKernelGGL((rzcc_fallback_kernel<N>), grid, dim3(64), 0, stream, h, spikes, flag_count, flag_list,
-                           plist, vlist, coef, nlanes, C, T, Ts, w, bipolar, xin, M, shift);
+        hipLaunchKernelGGL((rzcc_unit_fallback_kernel<N>), dim3((sc.nslots + 63) / 64), dim3(64), 0, stream, h, spikes,
+                           flag_count, flag_list, reinterpret_cast<int *>(scratch + sc.plist),
+                           reinterpret_cast<double *>(scratch + sc.vlist), sc.nslots, coef, nlanes, C, T, Ts, w, bipolar, xin,
+                           M, shift, g, ckd, cki);
 }
 
 hipError_t launch_bandpass_rzcc(const IirCoef &coef, const double *h, int nlanes, int C, int T, int Ts,
                                 int robust_width, int bipolar, double *pre, int8_t *spikes, void *scratch,
-                                hipStream_t stream, const double *xin, int M, int shift)
+                                hipStream_t stream, const double *xin, int M, int shift, int chunk_frames)
 {
     if (!pre && !spikes) return hipErrorInvalidValue;
-    int *flag_count = nullptr, *flag_list = nullptr, *plist = nullptr;
-    double *vlist = nullptr;
+    // launches that also store the filtered signal walk each stream once (the loader stores tile by tile)
+    const RzGeom g = rz_geom(nlanes, T, robust_width, (pre || !spikes) ? -1 : chunk_frames);
+    const RzScratch sc = rz_scratch(nlanes, T, g.P);
+    unsigned char *base = reinterpret_cast<unsigned char *>(scratch);
     if (spikes) {
-        unsigned char *base = reinterpret_cast<unsigned char *>(scratch);
-        flag_count = reinterpret_cast<int *>(base);
-        flag_list = reinterpret_cast<int *>(base + 256);
-        vlist = reinterpret_cast<double *>(base + 256 + (((size_t)nlanes * sizeof(int) + 255) & ~(size_t)255));
-        plist = reinterpret_cast<int *>(vlist + (size_t)T * nlanes);
-        hipError_t e = zero_fill(flag_count, 256, stream);
+        hipError_t e = zero_fill(base + sc.count, 256, stream);
         if (e != hipSuccess) return e;
         e = zero_fill(spikes, (size_t)nlanes * T, stream);
         if (e != hipSuccess) return e;
     }
-#define RZ_CASE(NN)                                                                                       \
-    case NN:                                                                                              \
-        launch_rz<NN>(coef, h, nlanes, C, T, Ts, robust_width, bipolar, pre, spikes, flag_count, flag_list, \
-                      plist, vlist, xin, M, shift, stream);                                               \
+#define RZ_CASE(NN)                                                                                                 \
+    case NN:                                                                                                        \
+        launch_rz<NN>(coef, h, nlanes, C, T, Ts, robust_width, bipolar, pre, spikes, spikes ? base : nullptr, g, sc, \
+                      xin, M, shift, stream);                                                                       \
         break;
     switch (coef.n) {
         RZ_CASE(1)

@@ -137,6 +137,14 @@ class Plan:
             self.w_complex = False
         self.G = W.shape[1]
 
+    def set_encoder_chunk(self, chunk_frames):
+        """Time chunking of the band-pass / RZCC stage (micloc_plan_set_encoder_chunk): 0 automatic, < 0 off,
+        > 0 owned frames per chunk.  Bit-identical results for every setting."""
+        _lib.check(self.lib.micloc_plan_set_encoder_chunk(self.handle, int(chunk_frames)), "set_encoder_chunk")
+
+    def encoder_chunks(self, B, T):
+        return self.lib.micloc_plan_encoder_chunks(self.handle, int(B), int(T))
+
     def workspace(self, B, T):
         n = self.lib.micloc_workspace_bytes(self.handle, B, T)
         return self.ws.get(n), n
@@ -288,8 +296,9 @@ def _op_workspace(device, nbytes):
     return ws.get(nbytes)
 
 
-def rzcc_encode(sig, robust_width, bipolar, device=None):
-    """ZeroCrossingSpikeEncoder.evolve on the device. sig: numpy/torch [T, C] or [B, T, C] -> int8 device tensor."""
+def rzcc_encode(sig, robust_width, bipolar, device=None, chunk_frames=0):
+    """ZeroCrossingSpikeEncoder.evolve on the device. sig: numpy/torch [T, C] or [B, T, C] -> int8 device tensor.
+    chunk_frames: time chunking (0 automatic, < 0 off, > 0 frames per chunk); the result does not depend on it."""
     torch = _torch()
     lib = _lib.load()
     device = require_gpu(device)
@@ -302,10 +311,10 @@ def rzcc_encode(sig, robust_width, bipolar, device=None):
     B, T, C = sig.shape
     spikes = torch.zeros((B, T, C), dtype=torch.int8, device=device)
     if B * T * C > 0:
-        nbytes = lib.micloc_rzcc_workspace_bytes(B, T, C)
+        nbytes = lib.micloc_rzcc_workspace_bytes_ex(B, T, C, int(robust_width), int(chunk_frames))
         ws = _op_workspace(device, nbytes)
-        _lib.check(lib.micloc_rzcc_encode_f64(_ptr(sig), B, T, C, int(robust_width), int(bool(bipolar)), _ptr(spikes), _ptr(ws), nbytes,
-                                              _stream(device)), "rzcc_encode")
+        _lib.check(lib.micloc_rzcc_encode_ex_f64(_ptr(sig), B, T, C, int(robust_width), int(bool(bipolar)), int(chunk_frames), _ptr(spikes),
+                                                 _ptr(ws), nbytes, _stream(device)), "rzcc_encode")
     return spikes[0] if squeeze else spikes
 
 

@@ -83,6 +83,15 @@ int micloc_plan_set_bf_mat_c128(micloc_plan *plan, const double *Wre, const doub
  * are overwritten in place after a device synchronisation and leave the counter -- and captured graphs -- valid. */
 int micloc_plan_generation(const micloc_plan *plan);
 
+/* Time chunking of the band-pass / RZCC stage.  The stage is serial in time per (trial, channel) stream; with few, long
+ * streams it is cut into chunks of `chunk_frames` owned frames that run side by side, each restarted from the exact
+ * state a serial scan stored at its boundary -- results are bit-identical for every setting.  0 (default): automatic
+ * (chunks only when the launch would not fill the chip); < 0: never; > 0: this many frames per chunk.  Changes the
+ * workspace size: query micloc_workspace_bytes again.  micloc_plan_encoder_chunks reports the chunks per stream a
+ * (B, T) launch will use. */
+int micloc_plan_set_encoder_chunk(micloc_plan *plan, int chunk_frames);
+int micloc_plan_encoder_chunks(const micloc_plan *plan, int B, int T);
+
 /* padded time stride of planar buffers (multiple of 8 samples) */
 int micloc_padded_T(int T);
 /* bytes of scratch needed by any stage / pipeline call with this (B, T) */
@@ -133,6 +142,10 @@ int micloc_beamformer_pipeline_f64(const micloc_plan *plan, const double *x, int
 size_t micloc_rzcc_workspace_bytes(int B, int T, int C);
 int micloc_rzcc_encode_f64(const double *sig, int B, int T, int C, int robust_width, int bipolar, int8_t *spikes,
                            void *ws, size_t ws_bytes, void *stream);
+/* the same with an explicit time-chunking choice (see micloc_plan_set_encoder_chunk) */
+size_t micloc_rzcc_workspace_bytes_ex(int B, int T, int C, int robust_width, int chunk_frames);
+int micloc_rzcc_encode_ex_f64(const double *sig, int B, int T, int C, int robust_width, int bipolar, int chunk_frames,
+                              int8_t *spikes, void *ws, size_t ws_bytes, void *stream);
 /* scipy.signal.lfilter(b, a, x, axis=0) on row-major x [B][T][C] (Filterbank.evolve,
  * filterbank.py:25-46); b, a are host [n], zero-padded to the same length n <= MICLOC_MAX_IIR. */
 size_t micloc_lfilter_workspace_bytes(int B, int T, int C);

@@ -1,0 +1,138 @@
+"""Time-chunked band-pass / RZCC stage (rzcc.hip "Time chunking"): every chunk restarts from the exact state the
+serial scan stored at its boundary, so the spikes must be IDENTICAL -- to the un-chunked launch, to the oracle and
+to the reference's golden spikes -- for every chunk length, including chunk boundaries inside plateaus, inside
+long clusters (ring overflow -> unit fallback), and at ragged stream ends."""
+import numpy as np
+import pytest
+
+from conftest import golden
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch
+
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch
+
+
+def _plan(cfg2, bipolar=True):
+    from haghighatshoarmuir2024_amd.runtime import Plan
+
+    p = Plan(7, cfg2["kernel"], cfg2["b"], cfg2["a"], cfg2["robust_width"], bipolar)
+    p.set_neuron_kernel(cfg2["nir"])
+    p.set_bf_mat(cfg2["bf_mat"])
+    return p
+
+
+@pytest.mark.parametrize("bipolar", [True, False])
+def test_fused_pipeline_is_chunk_invariant(cfg2, torch, bipolar):
+    z = golden("trials_cfg2.npz")
+    rng = np.random.RandomState(5)
+    x = np.concatenate([z["sig_in"], z["sig_in"][:1] * 1e-3 + 0.05 * rng.randn(1, 4799, 7), rng.randn(6, 4799, 7)])
+    p = _plan(cfg2, bipolar)
+    xd = p.to_device(x)
+    p.set_encoder_chunk(-1)
+    assert p.encoder_chunks(*x.shape[:2]) == 1
+    ref = p.snn_pipeline(xd, want_spikes=True, want_power=True)
+    ref_spikes = ref["spikes"].cpu().numpy()
+    for b in range(3):
+        want = O.snn_chain(x[b], cfg2["kernel"], cfg2["b"], cfg2["a"], cfg2["robust_width"], bipolar, cfg2["nir"], cfg2["bf_mat"], want=("spikes",))
+        np.testing.assert_array_equal(ref_spikes[b], want["spikes"])
+    if bipolar:
+        np.testing.assert_array_equal(ref_spikes[:3], z["spikes"])  # the reference's own spikes
+    for chunk in (32, 48, 100, 256, 1000, 2400, 4784, 4799, 10000):
+        p.set_encoder_chunk(chunk)
+        P = p.encoder_chunks(*x.shape[:2])
+        assert P == -(-300 // (-(-chunk // 16))), (chunk, P)
+        out = p.snn_pipeline(xd, want_spikes=True, want_power=True)
+        np.testing.assert_array_equal(out["spikes"].cpu().numpy(), ref_spikes, err_msg=f"chunk={chunk}")
+        np.testing.assert_array_equal(out["argmax"].cpu().numpy(), ref["argmax"].cpu().numpy())
+
+
+@pytest.mark.parametrize("T", [33, 95, 96, 97, 500, 1601])
+def test_ragged_lengths(cfg2, torch, T):
+    rng = np.random.RandomState(T)
+    x = rng.randn(5, T, 7)
+    p = _plan(cfg2)
+    xd = p.to_device(x)
+    for chunk in (32, 64, 160):
+        p.set_encoder_chunk(chunk)
+        got = p.snn_pipeline(xd, want_spikes=True, want_power=False)["spikes"].cpu().numpy()
+        for b in range(5):
+            want = O.snn_chain(x[b], cfg2["kernel"], cfg2["b"], cfg2["a"], cfg2["robust_width"], True, cfg2["nir"], cfg2["bf_mat"], want=("spikes",))
+            np.testing.assert_array_equal(got[b], want["spikes"], err_msg=f"T={T} chunk={chunk} b={b}")
+
+
+def test_edge_cases_chunked(torch):
+    """The encoder's golden edge cases (plateaus at the start, exact ties, peaks exactly w apart, alternating inputs that
+    overflow the candidate ring) with chunk boundaries every 32 / 48 / 80 frames."""
+    from haghighatshoarmuir2024_amd import runtime
+
+    z = golden("rzcc_edge.npz")
+    for n in sorted({k.split("__")[0] for k in z.files}):
+        x, w, bip = z[f"{n}__in"], int(z[f"{n}__w"]), int(z[f"{n}__bip"])
+        want = O.rzcc(x, w, bip)
+        for chunk in (16 * (-(-w // 16) + 1), 48, 80, 400):
+            if chunk < 16 * (-(-w // 16) + 1):
+                continue
+            got = runtime.rzcc_encode(x, w, bip, chunk_frames=chunk).cpu().numpy()
+            np.testing.assert_array_equal(got, want, err_msg=f"{n} chunk={chunk}")
+
+
+def test_plateaus_across_chunk_boundaries(torch):
+    """Digital silence: the running sum stays constant over many chunks, so the detector state at a chunk start
+    (direction and time of the last strict change) comes from far back -- scan checkpoints marked 'unknown' and the unit
+    fallback's walk to the tile of the last change."""
+    from haghighatshoarmuir2024_amd import runtime
+
+    rng = np.random.RandomState(11)
+    T, C = 3000, 6
+    x = rng.randn(T, C)
+    x[200:1400, 0] = 0.0           # long plateau after a rise or fall
+    x[0:700, 1] = 0.0              # nothing before the first sample that moves
+    x[:, 2] = 0.0                  # a dead channel
+    x[900:2950, 3] = 0.0           # plateau that ends near the end
+    x[100:120, 4] = 0.0            # short plateau inside a tile
+    x[1000:1064, 5] = 0.0          # exactly four tiles
+    # the plateau value must be reached from both directions somewhere
+    x[199, 0], x[899, 3] = 1.0, -1.0
+    for w, bip in ((12, 1), (3, 0), (24, 1)):
+        want = O.rzcc(x, w, bip)
+        for chunk in (64, 160, 1008):
+            if chunk < 16 * (-(-w // 16) + 1):
+                continue
+            got = runtime.rzcc_encode(x, w, bip, chunk_frames=chunk).cpu().numpy()
+            np.testing.assert_array_equal(got, want, err_msg=f"w={w} bip={bip} chunk={chunk}")
+
+
+def test_long_clusters_across_chunks(torch):
+    """Out-of-band content: extrema every 4 samples with w = 12 chain into clusters that span many chunks (far beyond the
+    LDS ring): units are flagged and redone by the list-based fallback, which walks past its chunk until the cluster closes."""
+    from haghighatshoarmuir2024_amd import runtime
+
+    rng = np.random.RandomState(2)
+    T = 2500
+    t = np.arange(T)
+    x = np.stack([np.cos(2 * np.pi * t / 8) + 1e-3 * rng.randn(T),                       # one giant cluster per polarity
+                  np.cos(2 * np.pi * t / 8) * (t % 600 < 300) + 0.3 * np.cos(2 * np.pi * t / 40),  # bursts of chains
+                  rng.randn(T),
+                  np.where(t % 2 == 0, 1.0, -1.0) * (1 + 0.01 * rng.rand(T))], axis=1)    # alternating every step
+    for w, bip in ((12, 1), (12, 0), (40, 1)):
+        want = O.rzcc(x, w, bip)
+        for chunk in (64, 208, 1200):
+            if chunk < 16 * (-(-w // 16) + 1):
+                continue
+            got = runtime.rzcc_encode(x, w, bip, chunk_frames=chunk).cpu().numpy()
+            np.testing.assert_array_equal(got, want, err_msg=f"w={w} bip={bip} chunk={chunk}")
+
+
+def test_automatic_choice(cfg2, torch):
+    """Launches that fill the chip stay one exact pass; few long streams are chunked (BASELINE config 3 shape)."""
+    p = _plan(cfg2)
+    assert p.encoder_chunks(1100, 4799) == 1
+    assert p.encoder_chunks(125, 332157) > 32
+    assert p.encoder_chunks(2, 100) == 1
