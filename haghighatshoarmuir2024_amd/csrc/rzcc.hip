@@ -414,16 +414,18 @@ __global__ __launch_bounds__(128) void rzcc_scan_kernel(const double *__restrict
         if (k < m_end) {
             const int buf = k % 3;
             uint64_t chg = 0;
+            const bool t0 = k == 0;  // the very first sample has no predecessor: never a strict change (detector: prev = NaN)
             if (k + 1 == next_ck) {
                 // tile in front of a checkpoint: track direction and time of the last strict change
 #pragma unroll
                 for (int j = 0; j < RZ_MT; ++j) {
                     const double y = iir.step(coef, X[buf][j][lane]);
                     const double c1 = cs + y;
-                    const bool rise = c1 > cs, fall = c1 < cs;
+                    const bool first = j == 0 && t0;
+                    const bool rise = c1 > cs && !first, fall = c1 < cs && !first;
                     dir = rise ? RZ_DIR_RISE : (fall ? RZ_DIR_FALL : dir);
                     left = (rise || fall) ? k * RZ_MT + j : left;
-                    chg |= __builtin_amdgcn_fcmp(c1, cs, 6);  // ordered != : exactly the detector's rise | fall
+                    chg |= __ballot(rise || fall);  // exactly the detector's rise | fall
                     cs = c1;
                 }
             } else {
@@ -431,7 +433,8 @@ __global__ __launch_bounds__(128) void rzcc_scan_kernel(const double *__restrict
                 for (int j = 0; j < RZ_MT; ++j) {
                     const double y = iir.step(coef, X[buf][j][lane]);
                     const double c1 = cs + y;
-                    chg |= __builtin_amdgcn_fcmp(c1, cs, 6);
+                    const uint64_t ne = __builtin_amdgcn_fcmp(c1, cs, 6);  // ordered != : the detector's rise | fall
+                    chg |= (j == 0 && t0) ? 0ull : ne;
                     cs = c1;
                 }
             }
@@ -591,7 +594,12 @@ __global__ __launch_bounds__(320) void bandpass_rzcc_fast_kernel(const double *_
                 } else {
                     detect_partial<0>(d, X[m % 3], steps, 2 * tbase - 1, bip, live, lane, ringP, ringV);
                 }
-                if (k == NM) leftPub[lane] = d.lrel + tbase;
+                if (k == NM) {
+                    // time of the last strict change; a lane that has not moved at all yet cannot complete a candidate
+                    // whose plateau starts before the first step after this chunk
+                    const bool hasdir = ((d.dpos | d.dneg) >> lane) & 1;
+                    leftPub[lane] = hasdir ? d.lrel + tbase : tbase + RZ_MT + 1;
+                }
                 d.lrel -= RZ_MT;
                 nPub[lane] = d.n;
                 polPub[lane] = (int)((d.ffall >> lane) & 1);
@@ -656,13 +664,18 @@ __global__ __launch_bounds__(320) void bandpass_rzcc_fast_kernel(const double *_
     }
     if (active && mine) {
         if (ovPub[lane]) dead = true;
+        // the next candidate the stream can still produce completes at t' >= t_end (the first step after this
+        // chunk) with its plateau starting at left' >= left: position (left' + t' - 1) >> 1 >= (left + t_end - 1) >> 1.
+        const int t_end = (m_lo + NM) * RZ_MT;
+        const int nextpos = (leftPub[lane] + t_end - 1) >> 1;
+        // A plateau longer than the tail tiles: a candidate that completes after this chunk can still lie in the owned
+        // range (its position is the plateau midpoint) -- nobody else would claim it.
+        if (!sp_.at_end && nextpos < own_hi) dead = true;
         if (!dead && s_open >= 0) {
             const int first = *word_at(s_open) >> 1;
             if (first >= own_lo && first < own_hi) {
-                // the next candidate the stream can still produce completes after the last step of this chunk:
-                // position >= (left + t_end) >> 1.  Closed iff that is >= w away (or the stream ends here).
-                const int t_end = (m_lo + NM) * RZ_MT;
-                if (sp_.at_end || ((leftPub[lane] + t_end) >> 1) - l_last >= w)
+                // the open cluster is closed iff the next candidate is >= w away (or the stream ends here)
+                if (sp_.at_end || nextpos - l_last >= w)
                     close_cluster(s_open, nPub[lane], l_last);
                 else
                     dead = true;
@@ -741,7 +754,9 @@ __global__ __launch_bounds__(64) void rzcc_unit_fallback_kernel(const double *__
                 const int t0 = pq == 0 ? 0 : (pq * g.Lt - g.Vt) * RZ_MT;
                 for (int t = t0; t < (Lc + 1) * RZ_MT; ++t) {
                     const double c1 = c + iir.step(coef, sample(t));
-                    if (c1 > c) {
+                    if (t == 0) {
+                        // the first sample has no predecessor: never a strict change
+                    } else if (c1 > c) {
                         dir = 1;
                         left = t;
                     } else if (c1 < c) {
@@ -780,8 +795,9 @@ __global__ __launch_bounds__(64) void rzcc_unit_fallback_kernel(const double *__
             left = (rise || fall) ? t : left;
             dir = rise ? 1 : (fall ? -1 : dir);
             prev = c;
-            // no candidate of either polarity can still appear before (left + t + 1) >> 1
-            const int nextpos = (left + t + 1) >> 1;
+            // the next candidate completes at t' >= t + 1 with left' >= left: position (left' + t' - 1) >> 1 >= (left + t) >> 1
+            // (a stream that has not moved at all yet: its first plateau starts at t + 1 at the earliest)
+            const int nextpos = dir == 0 ? t + 1 : (left + t) >> 1;
             if (nextpos >= span.own_hi) {
                 if (!seen[0] || nextpos - lastpos[0] >= w) done[0] = true;
                 if (!seen[1] || nextpos - lastpos[1] >= w) done[1] = true;

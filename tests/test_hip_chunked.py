@@ -90,8 +90,11 @@ def test_plateaus_across_chunk_boundaries(torch):
     from haghighatshoarmuir2024_amd import runtime
 
     rng = np.random.RandomState(11)
-    T, C = 3000, 6
+    T, C = 3000, 8
     x = rng.randn(T, C)
+    x[1:1500, 6:8] = 0.0           # only the FIRST sample moves the sum: no strict change (it has no predecessor), so the
+    x[0, 6], x[1500, 6] = 1.0, -1.0   # fall / rise at 1500 must not complete a candidate
+    x[0, 7], x[1500, 7] = -1.0, 1.0
     x[200:1400, 0] = 0.0           # long plateau after a rise or fall
     x[0:700, 1] = 0.0              # nothing before the first sample that moves
     x[:, 2] = 0.0                  # a dead channel
