@@ -49,6 +49,7 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of each cpu_baseline leg")
     ap.add_argument("--streams", type=int, default=3, help="HIP streams consecutive steps are pipelined over (1 = serial)")
+    ap.add_argument("--encoder-chunk", type=int, default=None, help="frames per time chunk of the band-pass / RZCC stage (default: the library's automatic choice; < 0: never chunk)")
     ap.add_argument("--traffic-bytes", type=float, default=None, help="override roofline.traffic (HBM bytes per dominant-kernel launch)")
     ap.add_argument("--pmc-summary", default=None, help="committed rocprofv3 PMC summary to read roofline.traffic from (default: newest profiles/r*/pmc_summary.csv)")
     # test hook (tests/test_bench_launch_cpu.py): exercise the rank launcher and the collective code on CPU with gloo
@@ -186,8 +187,10 @@ def build_workload(args, rank, device):
     nir = neuron_impulse_response(time_in[: min(len(time_in), 48_000)], beamf.tau_vec)
     plan.set_neuron_kernel(nir)
     plan.set_bf_mat(bf_mat)
+    if args.encoder_chunk is not None:
+        plan.set_encoder_chunk(args.encoder_chunk)
     return dict(beamf=beamf, plan=plan, x=x, doa=torch.from_numpy(doa).to(device), doa_list=torch.from_numpy(doa_list).to(device),
-                bf_mat=bf_mat, nir=nir, snr_groups=groups, fs=fs)
+                bf_mat=bf_mat, nir=nir, snr_groups=groups, fs=fs, encoder_chunk=args.encoder_chunk)
 
 
 def make_step(wl, nstreams, variants=True):
@@ -203,6 +206,8 @@ def make_step(wl, nstreams, variants=True):
         p = wl["beamf"].new_plan()
         p.set_neuron_kernel(wl["nir"])
         p.set_bf_mat(wl["bf_mat"])
+        if wl.get("encoder_chunk") is not None:
+            p.set_encoder_chunk(wl["encoder_chunk"])
         plans.append(p)
     pipe = StreamPipeline(plans)
 
@@ -266,6 +271,30 @@ def cpu_model():
     return "unknown"
 
 
+def usable_cores():
+    """Host cores this process may actually use: the scheduler affinity, capped by the cgroup CPU quota (a GPU box
+    reports all 256 hardware threads in os.cpu_count() but grants a 16-CPU share per GPU)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(np.ceil(int(txt[0]) / int(txt[1])))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, int(np.ceil(q / per))))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
+
+
 def cpu_baseline(wl, budget_s):
     """The CPU restatement of the same hot path on the first trials of the SAME batch, three ways:
       value            the C oracle, trial-parallel over all host cores (one thread per core)
@@ -279,7 +308,8 @@ def cpu_baseline(wl, budget_s):
     w = beamf.spk_encoder.robust_width
     B, T, M = wl["x"].shape
     G = wl["bf_mat"].shape[1]
-    cores = os.cpu_count() or 1
+    host_cpus = os.cpu_count() or 1
+    cores = usable_cores()
     O.lib()
     args = (beamf.kernel, b, a, w, True, wl["nir"], wl["bf_mat"])
 
@@ -297,8 +327,12 @@ def cpu_baseline(wl, budget_s):
     _, am1 = O.snn_chain_batch(x1, *args)
     dt1 = time.perf_counter() - t0
 
-    reps = max(1, int(np.ceil(sized(cores / per_trial, 64 * B) / B)))  # the whole batch, repeated if the box has many cores
     xa = wl["x"].cpu().numpy()
+    ncal = min(B, 4 * cores)  # calibrate the parallel leg on a short parallel run (threads rarely scale linearly)
+    t0 = time.perf_counter()
+    O.snn_chain_batch_parallel(xa[:ncal], *args, threads=cores)
+    par_rate = ncal / (time.perf_counter() - t0)
+    reps = max(1, int(round(sized(par_rate, 64 * B) / B)))  # the whole batch, repeated if the box has many cores
     t0 = time.perf_counter()
     for _ in range(reps):
         _, am_all = O.snn_chain_batch_parallel(xa, *args, threads=cores)
@@ -314,7 +348,7 @@ def cpu_baseline(wl, budget_s):
     del r0
 
     shape = f"T={T}, M={M}, G={G}"
-    return dict(value=reps * B * T / dta, unit="frames/s", cores=cores, kind="port", cpu_model=cpu_model(), host_cpus=cores,
+    return dict(value=reps * B * T / dta, unit="frames/s", cores=cores, kind="port", cpu_model=cpu_model(), host_cpus=host_cpus,
                 sample=f"{reps} x all {B} trials of the same batch ({shape}), {dta:.1f} s, oracle/micloc_oracle.c, trials split over {cores} threads",
                 single_thread=dict(value=n1 * T / dt1, unit="frames/s", cores=1,
                                    sample=f"first {n1} trials, {dt1:.1f} s, oracle/micloc_oracle.c, one thread"),
@@ -409,7 +443,9 @@ def run(args):
 
     wl = build_workload(args, rank, device)
     noisy = args.config == "noisy"
-    nstreams = max(1, args.streams) if noisy else 1  # the long / wide workloads fill the chip with one batch
+    # consecutive steps are independent batches: on every workload the serial scan / encoder of one step (few, long
+    # latency-bound workgroups) overlaps the throughput-bound STHT and beamforming kernels of its neighbours
+    nstreams = max(1, args.streams)
     step, pipe = make_step(wl, nstreams, variants=noisy)
     B, T, M = wl["x"].shape
     G = wl["bf_mat"].shape[1]

@@ -66,6 +66,17 @@ struct Iir {
     }
 };
 
+// The filter coefficients arrive as kernel arguments (scalar loads).  The compiler waits for a scalar load at its first
+// use; when that use sits inside the serial loop, the wait (s_waitcnt lgkmcnt(0): LDS and scalar loads share the counter)
+// is re-executed every tile and drains the LDS reads issued just before it.  Touching the values once in front of the
+// loop moves the wait there.
+template <int N>
+__device__ __forceinline__ void pin_coef(const IirCoef &coef)
+{
+#pragma unroll
+    for (int i = 0; i < N; ++i) asm volatile("; filter coefficient resident" ::"s"(coef.b[i]), "s"(coef.a[i]));
+}
+
 // Greedy min-distance selection inside one cluster.  Entries live at list indices s, s+stride, ... < e;
 // word >> 1 = position (the low bit is free for the caller), complemented once decided; priority = sgn * value.
 // `at(i)` maps a list index to storage.
@@ -365,10 +376,96 @@ __device__ __forceinline__ void rz_loader(XT &X, YT &Y, const double *__restrict
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Scan: band-pass + running sum only, exact state at every chunk boundary.  Two waves per 64 streams (loader, filter).
+// Scan: band-pass + running sum only, exact state at every chunk boundary.  This serial walk is what bounds long
+// streams (speech: 332 157 dependent steps), so it is written for the issue floor of ONE wave: the DF2T step is
+// 9 fma + 1 mul, the running sum 1 add, the plateau test 1 compare + 1 scalar or = 14 issue slots of ~4 cycles
+// (tools/valu_f64_issue.hip: a lone wave sustains 4.4 cycles per fp64 instruction of this exact chain, and a second
+// wave on the SIMD adds nothing -- fp64 VALU is saturated by one wave).  Everything else is kept off that wave:
+//   * two LOADER waves (even / odd tiles, two register sets each = four tiles of global loads in flight; with one
+//     loader and two tiles the walk was bound by HBM latency, 94 cycles per step);
+//   * the FILTER wave reads tile k+1 from LDS into registers while it computes tile k from registers, so no
+//     s_waitcnt lgkmcnt sits inside the arithmetic.
 // ---------------------------------------------------------------------------------------------------
+// loader wave `phase` of NP: owns the tiles m_lo + phase, m_lo + phase + NP, ...; tile m is written to X[m % 3] during
+// iteration m - 1 (tile 0 before the first barrier); `nstep` barriers after the first one.
+template <int NP, int PHASE, typename XT>
+__device__ __forceinline__ void rz_loader_np(XT &X, const double *__restrict__ h, const double *__restrict__ xin, int base,
+                                             int nlanes, int C, int T, int Ts, int M, int shift, int m_lo, int m_hi, int nstep,
+                                             int lane)
+{
+    constexpr int phase = PHASE;  // compile time: the s_waitcnt vmcnt(N) in front of a tile write must be able to leave
+                                  // the younger register set's loads in flight, which needs straight-line knowledge
+    const int tl = lane & 15;  // time offset inside the tile
+    const int sq = lane >> 4;  // stream slot 0..3 of each group of four
+    double v[2][16];
+    const double *pb[16];
+    bool rolled[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        int g = base + 4 * j + sq;
+        g = g < nlanes ? g : nlanes - 1;
+        const int bb = g / C, cc = g - bb * C;
+        rolled[j] = xin != nullptr && cc < M;
+        pb[j] = rolled[j] ? xin + (size_t)bb * T * M + cc : h + (size_t)g * Ts;
+    }
+    const int sh = shift % T;
+    const int NMc = m_hi - m_lo;
+    auto issue_loads = [&](int q, auto set) {  // own tile q (clamped: a tile past the end lands in a buffer nobody reads)
+        constexpr int S = decltype(set)::value;
+        int mm = phase + NP * q;
+        mm = m_lo + (mm < NMc ? mm : NMc - 1);
+        const int t = mm * RZ_MT + tl;
+        const int tc = t < Ts ? t : Ts - 1;
+        int tr = (t < T ? t : T - 1) - sh;
+        tr = tr < 0 ? tr + T : tr;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[S][j] = rolled[j] ? pb[j][(size_t)tr * M] : pb[j][tc];
+    };
+    auto write_tile = [&](int buf, auto set) {
+        constexpr int S = decltype(set)::value;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) X[buf][tl][4 * j + sq] = v[S][j];
+    };
+    using set0 = std::integral_constant<int, 0>;
+    using set1 = std::integral_constant<int, 1>;
+    issue_loads(0, set0{});
+    issue_loads(1, set1{});
+    if (phase == 0) {
+        write_tile(0, set0{});
+        issue_loads(2, set0{});
+    }
+    __syncthreads();
+    // iteration k writes tile m = k + 1 if it is ours: own index q = (m - phase) / NP, register set q & 1, refilled with q + 2
+    // k = 4a + i writes tile m = k + 1 if it is ours ((i + 1) % NP == phase: known at compile time)
+    auto iter = [&](int k, auto pos, auto set) {
+        constexpr int I = decltype(pos)::value;
+        if constexpr (((I + 1) % NP) == phase) {
+            const int m = k + 1;
+            write_tile(m % 3, set);
+            issue_loads((m - phase) / NP + 2, set);
+        }
+        __syncthreads();
+    };
+    // with NP = 2 the set index of tile m is ((m - phase) / 2) & 1: period 4 in k, fixed per (k & 3, phase)
+    static_assert(NP == 2, "unrolled for two loader waves");
+    using p0 = std::integral_constant<int, 0>;
+    using p1 = std::integral_constant<int, 1>;
+    using p2 = std::integral_constant<int, 2>;
+    using p3 = std::integral_constant<int, 3>;
+    int k = 0;
+    for (; k + 3 < nstep; k += 4) {
+        iter(k, p0{}, set0{});      // m = 4a + 1: phase 1, q = 2a     -> set 0
+        iter(k + 1, p1{}, set1{});  // m = 4a + 2: phase 0, q = 2a + 1 -> set 1
+        iter(k + 2, p2{}, set1{});  // m = 4a + 3: phase 1, q = 2a + 1 -> set 1
+        iter(k + 3, p3{}, set0{});  // m = 4a + 4: phase 0, q = 2a + 2 -> set 0
+    }
+    if (k < nstep) iter(k++, p0{}, set0{});
+    if (k < nstep) iter(k++, p1{}, set1{});
+    if (k < nstep) iter(k++, p2{}, set1{});
+}
+
 template <int N>
-__global__ __launch_bounds__(128) void rzcc_scan_kernel(const double *__restrict__ h, IirCoef coef, int nlanes, int C, int T,
+__global__ __launch_bounds__(192) void rzcc_scan_kernel(const double *__restrict__ h, IirCoef coef, int nlanes, int C, int T,
                                                          int Ts, const double *__restrict__ xin, int M, int shift, RzGeom g,
                                                          double *__restrict__ ckd, int *__restrict__ cki)
 {
@@ -377,9 +474,13 @@ __global__ __launch_bounds__(128) void rzcc_scan_kernel(const double *__restrict
     const int lane = threadIdx.x & 63;
     const int base = blockIdx.x * 64;
     const int m_end = (g.P - 1) * g.Lt - g.Vt;  // tile of the last checkpoint: nothing to do beyond it
-    const int nstep = m_end + 1;
+    const int nstep = m_end + 2;                // the filter wave runs one tile behind the LDS ring
     if (wave == 0) {
-        rz_loader<false>(X, X, h, nullptr, xin, base, nlanes, C, T, Ts, M, shift, 0, m_end, nstep, lane);
+        rz_loader_np<2, 0>(X, h, xin, base, nlanes, C, T, Ts, M, shift, 0, m_end, nstep, lane);
+        return;
+    }
+    if (wave == 1) {
+        rz_loader_np<2, 1>(X, h, xin, base, nlanes, C, T, Ts, M, shift, 0, m_end, nstep, lane);
         return;
     }
     // ------------------------------------ filter + checkpoints ----------------------------------------
@@ -393,9 +494,9 @@ __global__ __launch_bounds__(128) void rzcc_scan_kernel(const double *__restrict
     int left = 0;
     int next_ck = g.Lt - g.Vt;
     int q = 0;
-    __syncthreads();
-    for (int k = 0; k < nstep; ++k) {
-        if (k == next_ck) {
+    // tile kk: checkpoint (if due), then the walk over its 16 steps from registers
+    auto tile = [&](int kk, const double (&x)[RZ_MT]) {
+        if (kk == next_ck) {
             if (active) {
                 const size_t nl = (size_t)nlanes;
 #pragma unroll
@@ -403,7 +504,7 @@ __global__ __launch_bounds__(128) void rzcc_scan_kernel(const double *__restrict
                 ckd[((size_t)q * N + (N - 1)) * nl + lane_g] = cs;
                 // the detector state is exact if the last strict change happened in the tile just walked with full
                 // tracking (or never); otherwise only the tile of the last change is known
-                const int d = chg_tile < 0 ? RZ_DIR_NONE : (chg_tile == k - 1 ? dir : RZ_DIR_UNKNOWN);
+                const int d = chg_tile < 0 ? RZ_DIR_NONE : (chg_tile == kk - 1 ? dir : RZ_DIR_UNKNOWN);
                 cki[((size_t)q * 3 + 0) * nl + lane_g] = d;
                 cki[((size_t)q * 3 + 1) * nl + lane_g] = chg_tile < 0 ? 0 : left;
                 cki[((size_t)q * 3 + 2) * nl + lane_g] = chg_tile;
@@ -411,35 +512,82 @@ __global__ __launch_bounds__(128) void rzcc_scan_kernel(const double *__restrict
             next_ck += g.Lt;
             ++q;
         }
-        if (k < m_end) {
-            const int buf = k % 3;
-            uint64_t chg = 0;
-            const bool t0 = k == 0;  // the very first sample has no predecessor: never a strict change (detector: prev = NaN)
-            if (k + 1 == next_ck) {
-                // tile in front of a checkpoint: track direction and time of the last strict change
+        if (kk >= m_end) return;
+        uint64_t chg = 0;
+        const bool t0 = kk == 0;  // the very first sample has no predecessor: never a strict change (detector: prev = NaN)
+        if (kk + 1 == next_ck) {
+            // tile in front of a checkpoint: track direction and time of the last strict change
+#pragma unroll
+            for (int j = 0; j < RZ_MT; ++j) {
+                const double y = iir.step(coef, x[j]);
+                const double c1 = cs + y;
+                const bool first = j == 0 && t0;
+                const bool rise = c1 > cs && !first, fall = c1 < cs && !first;
+                dir = rise ? RZ_DIR_RISE : (fall ? RZ_DIR_FALL : dir);
+                left = (rise || fall) ? kk * RZ_MT + j : left;
+                chg |= __ballot(rise || fall);  // exactly the detector's rise | fall
+                cs = c1;
+            }
+        } else {
+            // Any other tile only needs "did the running sum move at all in this tile".  sum(end) != sum(start) says yes
+            // for one compare per TILE; equality is ambiguous (no change, or a change that came back), so a tile in which
+            // some lane ends where it started is walked again from the saved state with the per-step compare -- the same
+            // operations on the same operands, hence the same state.  Only plateaus (digital silence) ever take it.
+            const Iir<N> iir0 = iir;
+            const double cs0 = cs;
+#pragma unroll
+            for (int j = 0; j < RZ_MT; ++j) cs = cs + iir.step(coef, x[j]);
+            const uint64_t moved = __builtin_amdgcn_fcmp(cs, cs0, 6);  // ordered !=
+            chg = moved;
+            if (t0 || ~moved != 0ull) {  // uniform, rare (and the first tile: its first sample is never a change)
+                iir = iir0;
+                cs = cs0;
+                chg = 0;
 #pragma unroll
                 for (int j = 0; j < RZ_MT; ++j) {
-                    const double y = iir.step(coef, X[buf][j][lane]);
-                    const double c1 = cs + y;
-                    const bool first = j == 0 && t0;
-                    const bool rise = c1 > cs && !first, fall = c1 < cs && !first;
-                    dir = rise ? RZ_DIR_RISE : (fall ? RZ_DIR_FALL : dir);
-                    left = (rise || fall) ? k * RZ_MT + j : left;
-                    chg |= __ballot(rise || fall);  // exactly the detector's rise | fall
-                    cs = c1;
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < RZ_MT; ++j) {
-                    const double y = iir.step(coef, X[buf][j][lane]);
-                    const double c1 = cs + y;
+                    const double c1 = cs + iir.step(coef, x[j]);
                     const uint64_t ne = __builtin_amdgcn_fcmp(c1, cs, 6);  // ordered != : the detector's rise | fall
                     chg |= (j == 0 && t0) ? 0ull : ne;
                     cs = c1;
                 }
             }
-            chg_tile = ((chg >> lane) & 1) ? k : chg_tile;
         }
+        chg_tile = ((chg >> lane) & 1) ? kk : chg_tile;
+    };
+    // LDS -> registers, hand-issued: the reads of tile k are in flight while tile k - 1 is computed, and the one wait sits
+    // at the end of the iteration (the compiler's own placement waited right behind the reads, once per tile)
+    const unsigned lds_lane = (unsigned)(size_t)(&X[0][0][lane]);
+    auto fetch = [&](int kk, double (&x)[RZ_MT]) {
+        const int buf = (kk < m_end ? kk : 0) % 3;  // (past the end: any buffer, the values are not used)
+        const unsigned addr = lds_lane + (unsigned)buf * (RZ_MT * RZ_ROW * 8);
+#pragma unroll
+        for (int j = 0; j < RZ_MT; ++j) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(x[j]) : "v"(addr), "n"(j * RZ_ROW * 8));
+    };
+    auto landed = [&](double (&x)[RZ_MT]) {
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]), "+v"(x[8]),
+                       "+v"(x[9]), "+v"(x[10]), "+v"(x[11]), "+v"(x[12]), "+v"(x[13]), "+v"(x[14]), "+v"(x[15]));
+    };
+    double xa[RZ_MT], xb[RZ_MT];
+    pin_coef<N>(coef);
+    __syncthreads();
+    // iteration k: LDS -> registers for tile k (written before the last barrier), arithmetic on tile k - 1
+    fetch(0, xa);
+    landed(xa);
+    __syncthreads();  // k = 0
+    int k = 1;
+    for (; k + 1 < nstep; k += 2) {
+        fetch(k, xb);
+        tile(k - 1, xa);
+        landed(xb);
+        __syncthreads();
+        fetch(k + 1, xa);
+        tile(k, xb);
+        landed(xa);
+        __syncthreads();
+    }
+    if (k < nstep) {
+        tile(k - 1, xa);
         __syncthreads();
     }
 }
@@ -506,6 +654,7 @@ __global__ __launch_bounds__(320) void bandpass_rzcc_fast_kernel(const double *_
             for (int i = 0; i < N - 1; ++i) iir.z[i] = ckd[((size_t)(p - 1) * N + i) * nl + lane_c];
             cs = ckd[((size_t)(p - 1) * N + (N - 1)) * nl + lane_c];
         }
+        pin_coef<N>(coef);
         __syncthreads();
         for (int k = 0; k < NSTEP; ++k) {
             if (k < NM) {
@@ -950,7 +1099,7 @@ static void launch_rz(const IirCoef &coef, const double *h, int nlanes, int C, i
     double *ckd = scratch ? reinterpret_cast<double *>(scratch + sc.ckd) : nullptr;
     int *cki = scratch ? reinterpret_cast<int *>(scratch + sc.cki) : nullptr;
     if (g.P > 1)
-        hipLaunchKernelGGL((rzcc_scan_kernel<N>), dim3(nblk), dim3(128), 0, stream, h, coef, nlanes, C, T, Ts, xin, M, shift,
+        hipLaunchKernelGGL((rzcc_scan_kernel<N>), dim3(nblk), dim3(192), 0, stream, h, coef, nlanes, C, T, Ts, xin, M, shift,
                            g, ckd, cki);
     dim3 grid(nblk * g.P), block(spikes ? 320 : 128);
     if (pre && spikes)

@@ -590,6 +590,84 @@ def gen_speech():
          spikes_head=spikes[:3000], n_spikes=np.int64((spikes != 0).sum()), y_rows=y[row_idx], row_idx=row_idx)
 
 
+def gen_speech_sweep():
+    """The speech accuracy sweep of paper_plots/target_snn_localization.py:213-245 (no bandwidth correction of the SNR,
+    `snr_db_target = snr_db` at :227), 3 of the 11 SNRs x 2 trials with the reference's draw order
+    (rand(1) then randn(T, M) inside apply_to_template).  Inputs are rebuilt from speech_trial.npz's PCM."""
+    z0 = np.load(os.path.join(OUT, "speech_trial.npz"))
+    rate = int(z0["rate"])
+    sig_test = z0["pcm16"].astype(np.float64) / 32768.0
+    beamf, geometry, fs, fd, fr = cfg2_beamformer(True)
+    z = np.load(os.path.join(OUT, "bf_mat_chirp449_bipolar.npz"))
+    bf_mat, doa_list = z["bf_mat"], z["doa_list"]
+    time_test = np.arange(len(sig_test)) / rate
+    time_fs = np.linspace(time_test[0], time_test[-1], int(len(sig_test) / rate * fs))
+    sig_fs = np.interp(time_fs, time_test, sig_test)
+    snr_db_vec = np.array([-10.0, 5.0, 20.0])
+    num_sim = 2
+    seed = 11
+    np.random.seed(seed)
+    shape = (len(snr_db_vec), num_sim)
+    doa, amax, err, pmax = np.zeros(shape), np.zeros(shape, dtype=np.int64), np.zeros(shape), np.zeros(shape)
+    for i, snr_db in enumerate(snr_db_vec):
+        for sim in range(num_sim):
+            d = np.random.rand(1)[0] * 2 * np.pi
+            y = quiet(beamf.apply_to_template, bf_mat=bf_mat, template=(time_fs, sig_fs, d), snr_db=snr_db)
+            power = np.mean(np.abs(y) ** 2, axis=0)
+            k = int(np.argmax(power))
+            doa[i, sim], amax[i, sim], pmax[i, sim] = d, k, power[k]
+            err[i, sim] = np.arcsin(np.abs(np.sin(doa_list[k] - d)))
+            del y
+    save("speech_sweep.npz", seed=np.int64(seed), snr_db_vec=snr_db_vec, num_sim=np.int64(num_sim), doa=doa, argmax=amax, err=err, pmax=pmax,
+         T=np.int64(len(time_fs) - 1))
+
+
+def _reference_function(relpath, name, namespace):
+    """Execute ONE function definition of a reference file whose module cannot be imported here (its other imports --
+    rockpool, cvxpy, soundfile -- are not installed).  The source is read from /root/reference at generation time and
+    never stored; only the function's outputs go into the fixture."""
+    import ast
+
+    src = open(os.path.join(REF, relpath)).read()
+    tree = ast.parse(src)
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == name]
+    assert len(fn) == 1, (relpath, name)
+    mod = ast.Module(body=fn, type_ignores=[])
+    exec(compile(mod, os.path.join(REF, relpath), "exec"), namespace)
+    return namespace[name]
+
+
+def gen_synth_xylo():
+    """Array-signal synthesis of the Xylo sweep (micloc/xylo_snn_localization.py:44-71 `signal_from_template`: t + delays,
+    no min-shift, no clamp) and of the multi-target figures (paper_plots/multiple_targets_snn.py:87-160
+    `signal_multiple_targets`), evaluated by the reference's own function bodies."""
+    from numbers import Number
+    from typing import List, Tuple
+
+    from micloc.array_geometry import ArrayGeometry
+
+    ns = dict(np=np, Number=Number, Tuple=Tuple, List=List, ArrayGeometry=ArrayGeometry)
+    sft = _reference_function("micloc/xylo_snn_localization.py", "signal_from_template", dict(ns))
+    smt = _reference_function("paper_plots/multiple_targets_snn.py", "signal_multiple_targets", dict(ns))
+    geometry = CenterCircularArray(radius=4.5e-2, num_mic=7)
+    fs = 48_000
+    t = np.arange(0, 25e-3, step=1 / fs)
+    period = t[-1]
+    s = np.sin(2 * np.pi * np.cumsum(1000 + 1000 * (t % period) / period) / fs)
+    out = dict(time=t, sig=s)
+    out["fixed_doa"] = np.float64(2.3456)
+    out["fixed_sig"] = sft(geometry=geometry, template=(t, s, 2.3456))
+    mv = np.linspace(-1.0, 2.5, len(t))
+    out["moving_doa"] = mv
+    out["moving_sig"] = sft(geometry=geometry, template=(t, s, mv))
+    doa_ts = np.stack([np.linspace(0.3, 1.1, len(t)), np.full(len(t), -2.0), 2.0 + 0.5 * np.sin(2 * np.pi * 40 * t)], axis=1)
+    pow_ts = np.stack([np.ones(len(t)), 0.5 + 0.5 * (t > 10e-3), np.linspace(0.0, 2.0, len(t))], axis=1)
+    out["multi_doa"] = doa_ts
+    out["multi_power"] = pow_ts
+    out["multi_sig"] = smt(geometry, t, s, doa_ts, pow_ts)
+    save("synth_xylo.npz", **out)
+
+
 GENS = {
     "kat_init": gen_kat_init,
     "bf_mat_chirp": gen_bf_mat_chirp,
@@ -604,6 +682,8 @@ GENS = {
     "filterbank": gen_filterbank,
     "speech": gen_speech,
     "sweep_full": gen_sweep_full,
+    "speech_sweep": gen_speech_sweep,
+    "synth_xylo": gen_synth_xylo,
 }
 
 if __name__ == "__main__":
