@@ -37,6 +37,23 @@ class MiclocConfig(ctypes.Structure):
     ]
 
 
+class MiclocSynthArgs(ctypes.Structure):
+    _fields_ = [
+        ("time", c_void_p), ("sig", c_void_p), ("slopes", c_void_p),
+        ("T", c_int), ("B", c_int), ("K", c_int), ("M", c_int),
+        ("delays", c_void_p),
+        ("doa", c_void_p),
+        ("moving", c_int),
+        ("r_vec", c_void_p), ("theta_vec", c_void_p),
+        ("speed", ctypes.c_double),
+        ("shift", c_void_p),
+        ("gain", c_void_p),
+        ("mode", c_int),
+        ("fs", ctypes.c_double),
+        ("x", c_void_p),
+    ]
+
+
 # every symbol include/micloc_hip.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "micloc_plan_create": (c_int, [ctypes.POINTER(MiclocConfig), ctypes.POINTER(c_void_p)]),
@@ -66,10 +83,20 @@ SYMBOLS = {
     "micloc_lif_covariance_f64": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "micloc_snn_pipeline_cov_f64": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "micloc_synth_delay_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, ctypes.c_double, c_void_p, c_void_p]),
+    "micloc_synth_targets_f64": (c_int, [c_void_p, c_void_p]),
+    "micloc_delay_min_f64": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, ctypes.c_double, c_void_p, c_void_p]),
+    "micloc_uniform_f64": (c_int, [c_void_p, c_size_t, ctypes.c_uint64, ctypes.c_uint32, c_void_p, ctypes.c_double, ctypes.c_double, c_void_p]),
+    "micloc_counter_add_u32": (c_int, [c_void_p, ctypes.c_uint32, c_void_p]),
+    "micloc_awgn_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "micloc_awgn_f64": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, ctypes.c_uint64, ctypes.c_uint32, c_void_p, ctypes.c_uint32,
+                                c_void_p, c_size_t, c_void_p]),
     "micloc_doa_error_f64": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "micloc_xylo_workspace_bytes": (c_size_t, [c_int, c_int]),
     "micloc_xylo_lif_i16": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                     c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "micloc_xylo_upload": (c_int, [c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "micloc_xylo_lif_resident_i16": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "micloc_peak_location_i32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "micloc_abi_version": (c_int, []),
     "micloc_status_string": (ctypes.c_char_p, [c_int]),
     "micloc_last_hip_error": (c_int, []),

@@ -602,6 +602,74 @@ int micloc_synth_delay_f64(const double *time, const double *sig, const double *
     return MICLOC_OK;
 }
 
+int micloc_synth_targets_f64(const micloc_synth_args *a, void *stream)
+{
+    if (!a || !a->time || !a->sig || !a->slopes || !a->x || a->T < 2 || bad_batch(a->B) || a->K < 1 || a->M < 1 || !(a->fs > 0.0))
+        return MICLOC_ERR_INVALID;
+    if (a->mode != MICLOC_SYNTH_APPLY_TO_TEMPLATE && a->mode != MICLOC_SYNTH_SIGNAL_FROM_TEMPLATE) return MICLOC_ERR_INVALID;
+    if (!a->delays && (!a->doa || !a->r_vec || !a->theta_vec || !(a->speed > 0.0))) return MICLOC_ERR_INVALID;
+    SynthArgs k{};
+    k.time = a->time;
+    k.sig = a->sig;
+    k.slopes = a->slopes;
+    k.T = a->T;
+    k.B = a->B;
+    k.K = a->K;
+    k.M = a->M;
+    k.delays = a->delays;
+    k.doa = a->doa;
+    k.moving = a->moving ? 1 : 0;
+    k.r_vec = a->r_vec;
+    k.theta_vec = a->theta_vec;
+    k.speed = a->speed;
+    k.shift = a->shift;
+    k.gain = a->gain;
+    k.mode = a->mode;
+    k.inv_step = a->fs;
+    k.x = a->x;
+    HIP_TRY(launch_synth_targets(k, (hipStream_t)stream));
+    return MICLOC_OK;
+}
+
+int micloc_delay_min_f64(const double *doa, int B, int K, int moving_T, const double *r_vec, const double *theta_vec, int M,
+                         double speed, double *shift, void *stream)
+{
+    if (!doa || !r_vec || !theta_vec || !shift || bad_batch(B) || K < 1 || moving_T < 1 || M < 1 || !(speed > 0.0)) return MICLOC_ERR_INVALID;
+    HIP_TRY(launch_delay_min(doa, B, K, moving_T, r_vec, theta_vec, M, speed, shift, (hipStream_t)stream));
+    return MICLOC_OK;
+}
+
+// ---- counter-based random numbers ----------------------------------------------------------------------------
+int micloc_uniform_f64(double *out, size_t n, uint64_t seed, uint32_t substream, const uint32_t *epoch, double lo, double hi,
+                       void *stream)
+{
+    if (!out || n < 1) return MICLOC_ERR_INVALID;
+    HIP_TRY(launch_uniform(out, n, seed, substream, epoch, lo, hi, (hipStream_t)stream));
+    return MICLOC_OK;
+}
+
+int micloc_counter_add_u32(uint32_t *counter, uint32_t inc, void *stream)
+{
+    if (!counter) return MICLOC_ERR_INVALID;
+    HIP_TRY(launch_counter_add(counter, inc, (hipStream_t)stream));
+    return MICLOC_OK;
+}
+
+size_t micloc_awgn_workspace_bytes(int B, int T, int M)
+{
+    if (B < 1 || T < 1 || M < 1) return 0;
+    return awgn_ws_bytes(B, (size_t)T * M);
+}
+
+int micloc_awgn_f64(double *x, int B, int T, int M, const double *snr_db, const double *sigma, uint64_t seed, uint32_t substream,
+                    const uint32_t *epoch, uint32_t first_trial, void *ws, size_t ws_bytes, void *stream)
+{
+    if (!x || bad_batch(B) || T < 1 || M < 1 || (!snr_db && !sigma)) return MICLOC_ERR_INVALID;
+    if (!sigma && bad_ws(ws, ws_bytes, awgn_ws_bytes(B, (size_t)T * M))) return MICLOC_ERR_WORKSPACE;
+    HIP_TRY(launch_awgn(x, B, (size_t)T * M, snr_db, sigma, seed, substream, epoch, first_trial, ws, (hipStream_t)stream));
+    return MICLOC_OK;
+}
+
 // ---- per-trial DoA error and per-SNR mean absolute error ------------------------------------------------------
 int micloc_doa_error_f64(const int32_t *argmax, const double *doa_list, int G, const double *doa_true, int B, int groups,
                          double *err, double *mae, void *stream)
@@ -632,6 +700,39 @@ int micloc_xylo_lif_i16(const uint8_t *spikes_in, int B, int T, int Cin, const i
     if (bad_ws(ws, ws_bytes, xylo_ws_bytes(Cin, N))) return MICLOC_ERR_WORKSPACE;
     HIP_TRY(launch_xylo(spikes_in, B, T, Cin, W_in, N, w_rec, dash_syn, dash_mem, thr, max_spikes, spikes_out, rate, ws,
                         (hipStream_t)stream));
+    return MICLOC_OK;
+}
+
+// Two-phase form of the same network: constants uploaded once, then any number of launches that touch no host memory
+// and never synchronise (capturable into a HIP graph).  `ternary_channels` > 0: the input is the encoder's int8 raster.
+int micloc_xylo_upload(int Cin, const int8_t *W_in, int N, const uint8_t *dash_syn, const uint8_t *dash_mem, const int16_t *thr,
+                       void *ws, size_t ws_bytes, void *stream)
+{
+    if (!W_in || !dash_syn || !dash_mem || !thr || Cin < 1 || N < 1) return MICLOC_ERR_INVALID;
+    if (Cin > 64) return MICLOC_ERR_SHAPE;
+    for (int g = 0; g < N; ++g)
+        if (thr[g] <= 0 || dash_syn[g] > 15 || dash_mem[g] > 15) return MICLOC_ERR_INVALID;
+    if (bad_ws(ws, ws_bytes, xylo_ws_bytes(Cin, N))) return MICLOC_ERR_WORKSPACE;
+    HIP_TRY(xylo_upload(Cin, W_in, N, dash_syn, dash_mem, thr, ws, (hipStream_t)stream));
+    return MICLOC_OK;
+}
+
+int micloc_xylo_lif_resident_i16(const void *spikes_in, int ternary_channels, int B, int T, int Cin, int N, int w_rec,
+                                 int max_spikes, uint8_t *spikes_out, int32_t *rate, void *ws, size_t ws_bytes, void *stream)
+{
+    if (!spikes_in || bad_batch(B) || T < 1 || Cin < 1 || N < 1 || max_spikes < 1 || (!spikes_out && !rate)) return MICLOC_ERR_INVALID;
+    if (Cin > 64 || (w_rec != 0 && N > 1024)) return MICLOC_ERR_SHAPE;
+    if (ternary_channels < 0 || (ternary_channels > 0 && Cin != 2 * ternary_channels)) return MICLOC_ERR_SHAPE;
+    if (bad_ws(ws, ws_bytes, xylo_ws_bytes(Cin, N))) return MICLOC_ERR_WORKSPACE;
+    HIP_TRY(launch_xylo_resident(spikes_in, ternary_channels, B, T, Cin, N, w_rec, max_spikes, spikes_out, rate, ws, (hipStream_t)stream));
+    return MICLOC_OK;
+}
+
+int micloc_peak_location_i32(const int32_t *rate, int B, int G, int bands, int win_size, int32_t *index, void *stream)
+{
+    if (!rate || !index || bad_batch(B) || G < 1 || bands < 1) return MICLOC_ERR_INVALID;
+    if (win_size < 1 || win_size % 2 != 1 || win_size > G / 2 || G > 16384) return MICLOC_ERR_INVALID;  // utils.py:96-107
+    HIP_TRY(launch_peak_location(rate, B, G, bands, win_size, index, (hipStream_t)stream));
     return MICLOC_OK;
 }
 

@@ -92,12 +92,44 @@ hipError_t launch_xylo(const uint8_t *spikes_in, int B, int T, int Cin, const in
                        const uint8_t *dash_syn_host, const uint8_t *dash_mem_host, const int16_t *thr_host,
                        int max_spikes, uint8_t *spikes_out, int32_t *rate, void *ws, hipStream_t stream);
 
+hipError_t xylo_upload(int Cin, const int8_t *W_in_host, int N, const uint8_t *dash_syn_host, const uint8_t *dash_mem_host,
+                       const int16_t *thr_host, void *ws, hipStream_t stream);
+hipError_t launch_xylo_resident(const void *spikes_in, int ternary_C, int B, int T, int Cin, int N, int w_rec, int max_spikes,
+                                uint8_t *spikes_out, int32_t *rate, void *ws, hipStream_t stream);
+
 // ---- array-signal synthesis ---------------------------------------------------------------------------------
 hipError_t launch_synth(const double *xp, const double *fp, const double *slopes, int T, const double *delays, int B,
                         int M, double inv_step, double *out, hipStream_t stream);
+struct SynthArgs {
+    const double *time, *sig, *slopes;  // template on the fs grid
+    int T, B, K, M;
+    const double *delays;               // [B][K][Td][M] or nullptr
+    const double *doa;                  // [B][K][Td] (delays == nullptr)
+    int moving;                         // Td = moving ? T : 1
+    const double *r_vec, *theta_vec;    // [M] geometry (delays == nullptr)
+    double speed;
+    const double *shift;                // [B] or nullptr
+    const double *gain;                 // [B][K][T] or nullptr
+    int mode;                           // 0: t - (d - shift), clamped at t0;  1: t + d
+    double inv_step;
+    double *x;                          // [B][T][M]
+};
+hipError_t launch_synth_targets(const SynthArgs &a, hipStream_t stream);
+hipError_t launch_delay_min(const double *doa, int B, int K, int Td, const double *r_vec, const double *theta_vec, int M,
+                            double speed, double *shift, hipStream_t stream);
+
+// ---- counter-based random numbers (Philox-4x32-10) ---------------------------------------------------------------
+hipError_t launch_uniform(double *out, size_t n, uint64_t seed, uint32_t substream, const uint32_t *epoch, double lo, double hi,
+                          hipStream_t stream);
+hipError_t launch_counter_add(uint32_t *counter, uint32_t inc, hipStream_t stream);
+size_t awgn_ws_bytes(int B, size_t n);
+hipError_t launch_awgn(double *x, int B, size_t n, const double *snr_db, const double *sigma, uint64_t seed, uint32_t substream,
+                       const uint32_t *epoch, uint32_t trial0, void *ws, hipStream_t stream);
 
 // ---- sweep results ---------------------------------------------------------------------------------------------
 hipError_t launch_doa_error(const int32_t *argmax, const double *doa_list, int G, const double *doa_true, int B, int groups,
                             double *err, double *mae, hipStream_t stream);
+
+hipError_t launch_peak_location(const int32_t *rate, int B, int G, int F, int win, int32_t *index, hipStream_t stream);
 
 }  // namespace micloc

@@ -39,4 +39,64 @@ hipError_t launch_doa_error(const int32_t *argmax, const double *doa_list, int G
     return hipGetLastError();
 }
 
+// find_peak_location (micloc/utils.py:84-121) of the per-DoA spike counts of the Xylo sweep
+// (paper_plots/target_xylo_localization.py:594-604): power[g] = mean over bands of rate[f * G + g], smoothed with a
+// box-car of `win` samples by a FULL, non-circular convolution, arg-max, minus win // 2, modulo G.  The reference
+// normalises power by its maximum and by T / fs first -- positive factors that do not move the arg-max -- and sums in
+// floating point; here the window sums are exact integers (first maximum wins, as np.argmax), so the two can differ
+// only where the float sums of the reference break an exact integer tie by rounding.
+__global__ __launch_bounds__(256) void peak_location_kernel(const int32_t *__restrict__ rate, int G, int F, int win,
+                                                             int32_t *__restrict__ index)
+{
+    extern __shared__ long long pw[];  // [G]
+    __shared__ long long bestv[256];
+    __shared__ int besti[256];
+    const int b = blockIdx.x;
+    const int32_t *r = rate + (size_t)b * F * G;
+    for (int g = threadIdx.x; g < G; g += 256) {
+        long long s = 0;
+        for (int f = 0; f < F; ++f) s += r[(size_t)f * G + g];
+        pw[g] = s;
+    }
+    __syncthreads();
+    long long bv = -1;
+    int bi = 0x7fffffff;
+    for (int n = threadIdx.x; n < G + win - 1; n += 256) {
+        long long s = 0;
+        for (int k = 0; k < win; ++k) {
+            const int g = n - k;
+            if (g >= 0 && g < G) s += pw[g];
+        }
+        if (s > bv) {  // n ascending per thread: the first maximum of this thread's subsequence
+            bv = s;
+            bi = n;
+        }
+    }
+    bestv[threadIdx.x] = bv;
+    besti[threadIdx.x] = bi;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) {
+        if ((int)threadIdx.x < h) {
+            const long long ov = bestv[threadIdx.x + h];
+            const int oi = besti[threadIdx.x + h];
+            if (ov > bestv[threadIdx.x] || (ov == bestv[threadIdx.x] && oi < besti[threadIdx.x])) {
+                bestv[threadIdx.x] = ov;
+                besti[threadIdx.x] = oi;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        int idx = besti[0] - win / 2;
+        idx %= G;
+        index[b] = idx < 0 ? idx + G : idx;
+    }
+}
+
+hipError_t launch_peak_location(const int32_t *rate, int B, int G, int F, int win, int32_t *index, hipStream_t stream)
+{
+    hipLaunchKernelGGL(peak_location_kernel, dim3(B), dim3(256), (size_t)G * sizeof(long long), stream, rate, G, F, win, index);
+    return hipGetLastError();
+}
+
 }  // namespace micloc

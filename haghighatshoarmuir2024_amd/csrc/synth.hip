@@ -1,16 +1,56 @@
-// Array-signal synthesis on the device: the noise-free part of SNNBeamformer.apply_to_template
-// (reference micloc/snn_beamformer.py:246-267) for a constant DoA per trial:
-//     x[b][t][m] = np.interp(max(time[t] - delay[b][m], time[0]), time, sig)
-// Bit-exact with NumPy's arr_interp: same bracket j (xp[j] <= x < xp[j+1], found from a uniform-grid guess and
-// corrected against the actual grid values), slope (fp[j+1]-fp[j])/(xp[j+1]-xp[j]) taken from a host-computed table
-// (NumPy pre-computes the same table), result slope*(x - xp[j]) + fp[j] as an UNFUSED multiply-add (NumPy's C is
-// built without FMA contraction; this file is compiled with -ffp-contract=off).  The per-trial delays
-// (-r cos(theta_m - doa)/c minus the minimum) come from the host so that cos() is NumPy's.
-// This replaces the reference's T-calls-per-trial Python loop over geometry.delays (60 % of its per-trial time).
+// Array-signal synthesis on the device: the noise-free part of every signal generator of the reference.
+//
+//   SNNBeamformer.apply_to_template     micloc/snn_beamformer.py:239-267     x = interp(max(t - (d - d.min()), t0), t, s)
+//   Beamformer.apply_to_template        micloc/beamformer.py:220-245         (same arithmetic)
+//   signal_from_template (Xylo sweep)   micloc/xylo_snn_localization.py:44-71   x = interp(t + d, t, s)  (no shift, no clamp)
+//   signal_multiple_targets             paper_plots/multiple_targets_snn.py:87-160   x = sum_k power_k[t] * interp(t + d_k, t, s)
+//
+// with d = geometry.delays(doa, normalized=False) = -r_m cos(theta_m - doa) / c per time step (the DoA may move).
+// The interpolation is bit-exact with NumPy's arr_interp: same bracket j (xp[j] <= x < xp[j+1], found from a
+// uniform-grid guess and corrected against the actual grid values), slope (fp[j+1]-fp[j])/(xp[j+1]-xp[j]) taken from
+// a host-computed table (NumPy pre-computes the same table), result slope*(x - xp[j]) + fp[j] as an UNFUSED
+// multiply-add (NumPy's C is built without FMA contraction; this file is compiled with -ffp-contract=off), left /
+// right saturation at fp[0] / fp[T-1].
+//
+// Two sources for the delays:
+//   * a table from the host ([B][K][Td][M], NumPy's cos): bit-exact with the reference -- the parity path;
+//   * computed here from the DoA series and the geometry (device cos, within an ulp of NumPy's): nothing of size
+//     B x T x M crosses PCIe -- the throughput path.  This replaces the reference's T-calls-per-trial Python loop over
+//     geometry.delays (60 % of its per-trial time, snn_beamformer.py:254-256).
 #include "micloc_internal.h"
 
 namespace micloc {
 
+__device__ __forceinline__ double interp_one(const double *__restrict__ xp, const double *__restrict__ fp,
+                                             const double *__restrict__ slopes, int T, double x, double x0, double inv_step)
+{
+    if (x < x0) return fp[0];  // np.interp: left = fp[0]
+    // bracket: guess from the (nominally) uniform grid, then correct against the stored grid
+    int j = (int)((x - x0) * inv_step);
+    j = j < 0 ? 0 : (j > T - 1 ? T - 1 : j);
+    while (j > 0 && xp[j] > x) --j;
+    while (j < T - 1 && xp[j + 1] <= x) ++j;
+    if (j == T - 1) return fp[j];  // x >= xp[T-1]: right = fp[T-1]
+    const double xj = xp[j];
+    return (xj == x) ? fp[j] : slopes[j] * (x - xj) + fp[j];
+}
+
+__device__ __forceinline__ double mic_delay(const SynthArgs &a, int b, int k, int t, int m)
+{
+    const int Td = a.moving ? a.T : 1;
+    const int td = a.moving ? t : 0;
+    const size_t bk = (size_t)b * a.K + k;
+    double d;
+    if (a.delays) {
+        d = a.delays[(bk * Td + td) * a.M + m];
+    } else {
+        // ArrayGeometry.delays (array_geometry.py:52): -r_vec * cos(theta_vec - theta) / speed, in that order
+        d = -a.r_vec[m] * cos(a.theta_vec[m] - a.doa[bk * Td + td]) / a.speed;
+    }
+    return d;
+}
+
+// constant-DoA, one target, host delays: the original fast path (one delay load per output)
 __global__ __launch_bounds__(256) void synth_kernel(const double *__restrict__ xp, const double *__restrict__ fp,
                                                      const double *__restrict__ slopes, int T,
                                                      const double *__restrict__ delays, int M, double inv_step,
@@ -24,19 +64,7 @@ __global__ __launch_bounds__(256) void synth_kernel(const double *__restrict__ x
     const double x0 = xp[0];
     double x = xp[t] - delays[(size_t)b * M + m];
     x = x < x0 ? x0 : x;
-    // bracket: guess from the (nominally) uniform grid, then correct against the stored grid
-    int j = (int)((x - x0) * inv_step);
-    j = j < 0 ? 0 : (j > T - 1 ? T - 1 : j);
-    while (j > 0 && xp[j] > x) --j;
-    while (j < T - 1 && xp[j + 1] <= x) ++j;
-    double r;
-    if (j == T - 1) {
-        r = fp[j];
-    } else {
-        const double xj = xp[j];
-        r = (xj == x) ? fp[j] : slopes[j] * (x - xj) + fp[j];
-    }
-    out[(size_t)b * T * M + idx] = r;
+    out[(size_t)b * T * M + idx] = interp_one(xp, fp, slopes, T, x, x0, inv_step);
 }
 
 hipError_t launch_synth(const double *xp, const double *fp, const double *slopes, int T, const double *delays, int B,
@@ -45,6 +73,75 @@ hipError_t launch_synth(const double *xp, const double *fp, const double *slopes
     const size_t n = (size_t)T * M;
     dim3 grid((unsigned)((n + 255) / 256), B), block(256);
     hipLaunchKernelGGL(synth_kernel, grid, block, 0, stream, xp, fp, slopes, T, delays, M, inv_step, out);
+    return hipGetLastError();
+}
+
+// general form: K targets, moving DoAs, per-sample gains, either delay source, both conventions
+__global__ __launch_bounds__(256) void synth_targets_kernel(SynthArgs a)
+{
+    const int b = blockIdx.y;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;  // flat (t, m)
+    if (idx >= (size_t)a.T * a.M) return;
+    const int t = (int)(idx / a.M);
+    const int m = (int)(idx - (size_t)t * a.M);
+    const double x0 = a.time[0];
+    const double tt = a.time[t];
+    const double shift = a.shift ? a.shift[b] : 0.0;
+    double acc = 0.0;
+    for (int k = 0; k < a.K; ++k) {
+        double d = mic_delay(a, b, k, t, m);
+        double x;
+        if (a.mode == 0) {
+            if (a.shift) d = d - shift;  // delays - delays.min()  (snn_beamformer.py:257)
+            x = tt - d;                  // :259
+            x = x < x0 ? x0 : x;         // :260
+        } else {
+            x = tt + d;  // xylo_snn_localization.py:64, multiple_targets_snn.py:147
+        }
+        double r = interp_one(a.time, a.sig, a.slopes, a.T, x, x0, a.inv_step);
+        if (a.gain) r = a.gain[((size_t)b * a.K + k) * a.T + t] * r;  // multiple_targets_snn.py:155
+        acc = (a.K == 1) ? r : acc + r;                               // :157 (sig_in = 0; sig_in += sig_target)
+    }
+    a.x[(size_t)b * a.T * a.M + idx] = acc;
+}
+
+hipError_t launch_synth_targets(const SynthArgs &a, hipStream_t stream)
+{
+    const size_t n = (size_t)a.T * a.M;
+    dim3 grid((unsigned)((n + 255) / 256), a.B), block(256);
+    hipLaunchKernelGGL(synth_targets_kernel, grid, block, 0, stream, a);
+    return hipGetLastError();
+}
+
+// shift[b] = min over targets, time steps and microphones of the un-normalised delays (apply_to_template's
+// `delays.min()`, snn_beamformer.py:257), from the DoA series.  One workgroup per trial, fixed-order reduction.
+__global__ __launch_bounds__(256) void delay_min_kernel(const double *__restrict__ doa, int K, int Td, const double *__restrict__ r_vec,
+                                                         const double *__restrict__ theta_vec, int M, double speed,
+                                                         double *__restrict__ shift)
+{
+    __shared__ double red[256];
+    const int b = blockIdx.x;
+    const size_t n = (size_t)K * Td * M;
+    double mn = __builtin_inf();
+    for (size_t i = threadIdx.x; i < n; i += 256) {
+        const size_t kt = i / M;
+        const int m = (int)(i - kt * M);
+        const double d = -r_vec[m] * cos(theta_vec[m] - doa[(size_t)b * K * Td + kt]) / speed;
+        mn = d < mn ? d : mn;
+    }
+    red[threadIdx.x] = mn;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) {
+        if ((int)threadIdx.x < h) red[threadIdx.x] = red[threadIdx.x + h] < red[threadIdx.x] ? red[threadIdx.x + h] : red[threadIdx.x];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) shift[b] = red[0];
+}
+
+hipError_t launch_delay_min(const double *doa, int B, int K, int Td, const double *r_vec, const double *theta_vec, int M,
+                            double speed, double *shift, hipStream_t stream)
+{
+    hipLaunchKernelGGL(delay_min_kernel, dim3(B), dim3(256), 0, stream, doa, K, Td, r_vec, theta_vec, M, speed, shift);
     return hipGetLastError();
 }
 

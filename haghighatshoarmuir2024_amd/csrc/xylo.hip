@@ -15,6 +15,9 @@
 
 #include "micloc_internal.h"
 
+// (the recurrent instantiations keep a barrier inside the step loop, which the requested unrolling skips)
+#pragma clang diagnostic ignored "-Wpass-failed"
+
 namespace micloc {
 
 constexpr int XY_TT = 256;   // time steps staged per LDS tile
@@ -29,51 +32,73 @@ __device__ __forceinline__ int xy_decay(int v, int dash)
     return v - dv;
 }
 
-template <bool REC>
-__global__ __launch_bounds__(1024) void xylo_lif_kernel(const uint8_t *__restrict__ spikes_in, int T, int Cin, int nq,
-                                                         const int *__restrict__ Wpk /*[nq][N]*/, int N, int w_rec,
+// exact floor(v / th) for 0 < th <= v <= 32767 without the integer-division sequence: fp32 quotient, corrected by +-1
+__device__ __forceinline__ int xy_div(int v, int th)
+{
+    int n = (int)((float)v * __builtin_amdgcn_rcpf((float)th));
+    n = n * th > v ? n - 1 : n;
+    n = (n + 1) * th <= v ? n + 1 : n;
+    return n;
+}
+
+// NQ = dwords of packed input per step (compile time: the contraction unrolls into NQ v_dot4 with no branches; the
+// staged row is read with wide, wave-uniform LDS loads)
+template <bool REC, int NQ>
+__global__ __launch_bounds__(1024) void xylo_lif_kernel(const uint8_t *__restrict__ spikes_in, int ternary_C, int T, int Cin,
+                                                         const int *__restrict__ Wpk /*[nq][N]*/, int nq, int N, int w_rec,
                                                          const uint8_t *__restrict__ dash_syn,
                                                          const uint8_t *__restrict__ dash_mem,
                                                          const short *__restrict__ thr, int max_spikes,
                                                          uint8_t *__restrict__ spikes_out, int *__restrict__ rate)
 {
-    __shared__ int tile[XY_TT][XY_MAXQ];
+    __shared__ __attribute__((aligned(16))) int tile[XY_TT][NQ];
     __shared__ int wsum[2][16];
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     const int b = blockIdx.y;
     const bool act = g < N;
-    int w[XY_MAXQ];
+    int w[NQ];
 #pragma unroll
-    for (int k = 0; k < XY_MAXQ; ++k) w[k] = (act && k < nq) ? Wpk[(size_t)k * N + g] : 0;
+    for (int k = 0; k < NQ; ++k) w[k] = (act && k < nq) ? Wpk[(size_t)k * N + g] : 0;
     const int ds = act ? dash_syn[g] : 0, dm = act ? dash_mem[g] : 0;
     const int th = act ? thr[g] : 32767;
     int isyn = 0, vmem = 0, total = 0, prev_total = 0;
-    const uint8_t *sb = spikes_in + (size_t)b * T * Cin;
+    // ternary_C > 0: the input is the encoder's int8 raster [B][T][ternary_C] in {-1, 0, +1}; channel c carries its +1
+    // events, channel ternary_C + c its -1 events (Demo.spike_encoding's split, xylo_snn_localization.py:350-354)
+    const int Crow = ternary_C > 0 ? ternary_C : Cin;
+    const uint8_t *sb = spikes_in + (size_t)b * T * Crow;
+    const int8_t *sbt = reinterpret_cast<const int8_t *>(sb);
     uint8_t *ob = spikes_out ? spikes_out + (size_t)b * T * N : nullptr;
     const int nwaves = blockDim.x >> 6;
 
     for (int t0 = 0; t0 < T; t0 += XY_TT) {
         const int steps = (T - t0) < XY_TT ? (T - t0) : XY_TT;
         __syncthreads();
-        // stage `steps` rows of Cin bytes, zero padded to nq dwords
+        // stage `steps` rows of Cin bytes, zero padded to NQ dwords
         uint8_t *tb = reinterpret_cast<uint8_t *>(&tile[0][0]);
-        for (int e = threadIdx.x; e < steps * XY_MAXQ * 4; e += blockDim.x) {
-            const int r = e / (XY_MAXQ * 4), c = e % (XY_MAXQ * 4);
-            tb[e] = c < Cin ? sb[(size_t)(t0 + r) * Cin + c] : 0;
+        for (int e = threadIdx.x; e < steps * NQ * 4; e += blockDim.x) {
+            const int r = e / (NQ * 4), c = e % (NQ * 4);
+            uint8_t v = 0;
+            if (c < Cin) {
+                if (ternary_C > 0)
+                    v = c < ternary_C ? (uint8_t)(sbt[(size_t)(t0 + r) * Crow + c] > 0) : (uint8_t)(sbt[(size_t)(t0 + r) * Crow + c - ternary_C] < 0);
+                else
+                    v = sb[(size_t)(t0 + r) * Cin + c];
+            }
+            tb[e] = v;
         }
         __syncthreads();
+#pragma unroll 4
         for (int j = 0; j < steps; ++j) {
             int in = 0;
 #pragma unroll
-            for (int k = 0; k < XY_MAXQ; ++k)
-                if (k < nq) in = __builtin_amdgcn_sdot4(w[k], tile[j][k], in, false);
+            for (int k = 0; k < NQ; ++k) in = __builtin_amdgcn_sdot4(w[k], tile[j][k], in, false);
             int i2 = xy_decay(isyn, ds);
             int v2 = xy_decay(vmem, dm);
             i2 = xy_sat16(i2 + in + (REC ? w_rec * prev_total : 0));
             v2 = xy_sat16(v2 + i2);
             int n = 0;
             if (v2 >= th) {
-                n = v2 / th;  // th > 0: subtractive reset until below threshold ...
+                n = xy_div(v2, th);                   // th > 0: subtractive reset until below threshold ...
                 n = n < max_spikes ? n : max_spikes;  // ... or until the per-step cap
                 v2 -= n * th;
             }
@@ -106,9 +131,9 @@ size_t xylo_ws_bytes(int Cin, int N)
     return bytes;
 }
 
-hipError_t launch_xylo(const uint8_t *spikes_in, int B, int T, int Cin, const int8_t *W_in_host, int N, int w_rec,
-                       const uint8_t *dash_syn_host, const uint8_t *dash_mem_host, const int16_t *thr_host,
-                       int max_spikes, uint8_t *spikes_out, int32_t *rate, void *ws, hipStream_t stream)
+// Uploads the packed weights and per-neuron constants into `ws` (synchronises the stream once).
+hipError_t xylo_upload(int Cin, const int8_t *W_in_host, int N, const uint8_t *dash_syn_host, const uint8_t *dash_mem_host,
+                       const int16_t *thr_host, void *ws, hipStream_t stream)
 {
     const int nq = (Cin + 3) / 4;
     if (nq > XY_MAXQ) return hipErrorInvalidValue;
@@ -136,18 +161,55 @@ hipError_t launch_xylo(const uint8_t *spikes_in, int B, int T, int Cin, const in
     if ((e = hipMemcpyAsync(dds, dash_syn_host, (size_t)N, hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
     if ((e = hipMemcpyAsync(ddm, dash_mem_host, (size_t)N, hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
     if ((e = hipMemcpyAsync(dth, thr_host, (size_t)N * 2, hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
-    if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;  // `pk` is a host temporary
-    if (w_rec != 0) {
-        if (N > 1024) return hipErrorInvalidValue;
-        dim3 block(((N + 63) / 64) * 64), grid(1, B);
-        hipLaunchKernelGGL(xylo_lif_kernel<true>, grid, block, 0, stream, spikes_in, T, Cin, nq, dW, N, w_rec, dds, ddm,
-                           dth, max_spikes, spikes_out, rate);
-    } else {
-        dim3 block(256), grid((N + 255) / 256, B);
-        hipLaunchKernelGGL(xylo_lif_kernel<false>, grid, block, 0, stream, spikes_in, T, Cin, nq, dW, N, 0, dds, ddm, dth,
-                           max_spikes, spikes_out, rate);
-    }
+    return hipStreamSynchronize(stream);  // `pk` is a host temporary
+}
+
+// Runs the network whose constants xylo_upload placed in `ws`: no host access, no synchronisation (graph-capturable).
+hipError_t launch_xylo_resident(const void *spikes_in, int ternary_C, int B, int T, int Cin, int N, int w_rec, int max_spikes,
+                                uint8_t *spikes_out, int32_t *rate, void *ws, hipStream_t stream)
+{
+    const int nq = (Cin + 3) / 4;
+    if (nq > XY_MAXQ) return hipErrorInvalidValue;
+    unsigned char *base = reinterpret_cast<unsigned char *>(ws);
+    int *dW = reinterpret_cast<int *>(base);
+    size_t off = ((size_t)nq * N * sizeof(int) + 255) & ~(size_t)255;
+    const size_t seg = ((size_t)N * 2 + 255) & ~(size_t)255;
+    uint8_t *dds = base + off;
+    uint8_t *ddm = base + off + seg;
+    short *dth = reinterpret_cast<short *>(base + off + 2 * seg);
+    const uint8_t *sp = reinterpret_cast<const uint8_t *>(spikes_in);
+    if (w_rec != 0 && N > 1024) return hipErrorInvalidValue;
+    const dim3 block(w_rec != 0 ? ((N + 63) / 64) * 64 : 256), grid(w_rec != 0 ? 1 : (N + 255) / 256, B);
+#define XY_LAUNCH(NQ)                                                                                                          \
+    do {                                                                                                                       \
+        if (w_rec != 0)                                                                                                        \
+            hipLaunchKernelGGL((xylo_lif_kernel<true, NQ>), grid, block, 0, stream, sp, ternary_C, T, Cin, dW, nq, N, w_rec, dds, \
+                               ddm, dth, max_spikes, spikes_out, rate);                                                        \
+        else                                                                                                                   \
+            hipLaunchKernelGGL((xylo_lif_kernel<false, NQ>), grid, block, 0, stream, sp, ternary_C, T, Cin, dW, nq, N, 0, dds,    \
+                               ddm, dth, max_spikes, spikes_out, rate);                                                        \
+    } while (0)
+    if (nq <= 2)
+        XY_LAUNCH(2);
+    else if (nq <= 4)
+        XY_LAUNCH(4);
+    else if (nq <= 7)
+        XY_LAUNCH(7);
+    else if (nq <= 8)
+        XY_LAUNCH(8);
+    else
+        XY_LAUNCH(16);
+#undef XY_LAUNCH
     return hipGetLastError();
+}
+
+hipError_t launch_xylo(const uint8_t *spikes_in, int B, int T, int Cin, const int8_t *W_in_host, int N, int w_rec,
+                       const uint8_t *dash_syn_host, const uint8_t *dash_mem_host, const int16_t *thr_host,
+                       int max_spikes, uint8_t *spikes_out, int32_t *rate, void *ws, hipStream_t stream)
+{
+    hipError_t e0 = xylo_upload(Cin, W_in_host, N, dash_syn_host, dash_mem_host, thr_host, ws, stream);
+    if (e0 != hipSuccess) return e0;
+    return launch_xylo_resident(spikes_in, 0, B, T, Cin, N, w_rec, max_spikes, spikes_out, rate, ws, stream);
 }
 
 }  // namespace micloc

@@ -361,6 +361,171 @@ def synth_delay(time_in, sig_in, delays, fs, device=None):
     return x
 
 
+class Template:
+    """A source signal on the fs grid, resident on the device (time, values, np.interp's slope table)."""
+
+    def __init__(self, time_in, sig_in, fs, device=None):
+        torch = _torch()
+        self.device = require_gpu(device)
+        time_in = np.ascontiguousarray(time_in, dtype=np.float64)
+        sig_in = np.ascontiguousarray(sig_in, dtype=np.float64)
+        if time_in.ndim != 1 or time_in.shape != sig_in.shape or len(time_in) < 2:
+            raise ValueError("template needs a time vector and a signal of the same length >= 2")
+        self.T = len(time_in)
+        self.fs = float(fs)
+        self.time_host = time_in
+        self.time = torch.from_numpy(time_in).to(self.device)
+        self.sig = torch.from_numpy(sig_in).to(self.device)
+        self.slopes = torch.from_numpy(np.ascontiguousarray(np.diff(sig_in) / np.diff(time_in))).to(self.device)
+
+
+class Geometry:
+    """Microphone polar coordinates on the device (for delays computed in the synthesis kernel)."""
+
+    def __init__(self, geometry, device=None):
+        torch = _torch()
+        self.device = require_gpu(device)
+        self.M = len(geometry.r_vec)
+        self.r_vec = torch.from_numpy(np.ascontiguousarray(geometry.r_vec, dtype=np.float64)).to(self.device)
+        self.theta_vec = torch.from_numpy(np.ascontiguousarray(geometry.theta_vec, dtype=np.float64)).to(self.device)
+        self.speed = float(geometry.speed)
+
+
+def _as_dev(a, device):
+    torch = _torch()
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(device)
+    return a.to(device=device, dtype=torch.float64).contiguous()
+
+
+def synth_targets(template, mode, delays=None, doa=None, geometry=None, moving=False, shift=None, gain=None, out=None):
+    """micloc_synth_targets_f64: x [B, T, M] = sum_k gain * interp(...) (see include/micloc_hip.h).
+
+    delays [B, K, (T,) M] (host NumPy -> bit-exact parity) or doa [B, K(, T)] + `geometry` (runtime.Geometry: delays
+    computed in the kernel).  mode: "apply_to_template" (t - (d - shift), clamped) or "signal_from_template" (t + d)."""
+    torch = _torch()
+    lib = _lib.load()
+    dev = template.device
+    T = template.T
+    args = _lib.MiclocSynthArgs()
+    keep = []
+    if delays is not None:
+        d = _as_dev(delays, dev)
+        if d.dim() != (4 if moving else 3):
+            raise ValueError("delays must be [B, K, M] (constant DoA) or [B, K, T, M] (moving)")
+        B, K, M = d.shape[0], d.shape[1], d.shape[-1]
+        if moving and d.shape[2] != T:
+            raise ValueError("moving delays need one row per template sample")
+        args.delays = d.data_ptr()
+        keep.append(d)
+    else:
+        if doa is None or geometry is None:
+            raise ValueError("either delays or (doa, geometry) must be given")
+        a = _as_dev(doa, dev)
+        if a.dim() != (3 if moving else 2):
+            raise ValueError("doa must be [B, K] (constant) or [B, K, T] (moving)")
+        B, K, M = a.shape[0], a.shape[1], geometry.M
+        if moving and a.shape[2] != T:
+            raise ValueError("moving DoAs need one value per template sample")
+        args.doa = a.data_ptr()
+        args.r_vec, args.theta_vec, args.speed = geometry.r_vec.data_ptr(), geometry.theta_vec.data_ptr(), geometry.speed
+        keep.append(a)
+    sh = _as_dev(shift, dev)
+    gn = _as_dev(gain, dev)
+    if sh is not None and tuple(sh.shape) != (B,):
+        raise ValueError("shift must be [B]")
+    if gn is not None and tuple(gn.shape) != (B, K, T):
+        raise ValueError("gain must be [B, K, T]")
+    x = out if out is not None else torch.empty((B, T, M), dtype=torch.float64, device=dev)
+    if tuple(x.shape) != (B, T, M) or x.dtype != torch.float64 or not x.is_contiguous():
+        raise ValueError("out must be a contiguous float64 [B, T, M] tensor")
+    args.time, args.sig, args.slopes = template.time.data_ptr(), template.sig.data_ptr(), template.slopes.data_ptr()
+    args.T, args.B, args.K, args.M = T, B, K, M
+    args.moving = int(bool(moving))
+    args.shift = sh.data_ptr() if sh is not None else None
+    args.gain = gn.data_ptr() if gn is not None else None
+    args.mode = {"apply_to_template": 0, "signal_from_template": 1}[mode]
+    args.fs = template.fs
+    args.x = x.data_ptr()
+    _lib.check(lib.micloc_synth_targets_f64(ctypes.byref(args), _stream(dev)), "synth_targets")
+    return x
+
+
+def delay_min(doa, geometry, moving=False, out=None):
+    """shift[b] = min over targets / time / microphones of the un-normalised delays (snn_beamformer.py:257) on the device."""
+    torch = _torch()
+    lib = _lib.load()
+    a = _as_dev(doa, geometry.device)
+    B, K = a.shape[0], a.shape[1]
+    Td = a.shape[2] if moving else 1
+    sh = out if out is not None else torch.empty((B,), dtype=torch.float64, device=a.device)
+    _lib.check(lib.micloc_delay_min_f64(_ptr(a), B, K, Td, _ptr(geometry.r_vec), _ptr(geometry.theta_vec), geometry.M, geometry.speed,
+                                        _ptr(sh), _stream(a.device)), "delay_min")
+    return sh
+
+
+def uniform(n, seed, substream=0, lo=0.0, hi=1.0, device=None, out=None, epoch=None):
+    """n Philox-4x32-10 uniforms in [lo, hi) on the device (np.random.rand's range, 53 bits)."""
+    torch = _torch()
+    lib = _lib.load()
+    device = require_gpu(device) if out is None else out.device
+    u = out if out is not None else torch.empty((int(n),), dtype=torch.float64, device=device)
+    _lib.check(lib.micloc_uniform_f64(_ptr(u), u.numel(), int(seed), int(substream), _ptr(epoch), float(lo), float(hi), _stream(device)), "uniform")
+    return u
+
+
+def awgn_(x, snr_db=None, sigma=None, seed=0, substream=0, first_trial=0, ws=None, epoch=None):
+    """In place: x[b] += sigma_b N(0, 1), sigma_b = sqrt(mean(x[b]^2)) / sqrt(10^(snr_db[b]/10)) (snn_beamformer.py:270-275),
+    Philox-4x32-10 + Box-Muller on the device.  x [B, T, M] device tensor; snr_db / sigma [B] (device tensor or NumPy)."""
+    lib = _lib.load()
+    B, T, M = x.shape
+    dev = x.device
+    torch = _torch()
+    if snr_db is not None and not isinstance(snr_db, torch.Tensor):
+        snr_db = np.array(np.broadcast_to(np.asarray(snr_db, dtype=np.float64), (B,)))
+    s_db = _as_dev(snr_db, dev)
+    sg = _as_dev(sigma, dev)
+    if s_db is None and sg is None:
+        raise ValueError("awgn_ needs snr_db or sigma")
+    nbytes = lib.micloc_awgn_workspace_bytes(B, T, M)
+    if ws is None:
+        ws = _op_workspace(dev, nbytes)  # (a caller that captures the call into a HIP graph passes its own buffer)
+    elif ws.numel() < nbytes:
+        raise ValueError("awgn workspace too small")
+    _lib.check(lib.micloc_awgn_f64(_ptr(x), B, T, M, _ptr(s_db), _ptr(sg), int(seed), int(substream), _ptr(epoch), int(first_trial), _ptr(ws), nbytes,
+                                   _stream(dev)), "awgn")
+    return x
+
+
+def peak_location(counts, G, win_size, out=None):
+    """micloc_peak_location_i32: counts int32 [B, bands * G] -> index int32 [B] (find_peak_location of the per-DoA counts)."""
+    torch = _torch()
+    B, FG = counts.shape
+    if FG % G != 0:
+        raise ValueError("the number of hidden neurons must be a multiple of the DoA grid size")
+    if win_size % 2 != 1:
+        raise ValueError("averaging window size should be odd to not create confusion in peak index!")
+    if win_size > G // 2:
+        raise ValueError("size of averaging window is larger than half the length of input signal!")
+    idx = out if out is not None else torch.empty((B,), dtype=torch.int32, device=counts.device)
+    _lib.check(_lib.load().micloc_peak_location_i32(_ptr(counts), B, int(G), FG // int(G), int(win_size), _ptr(idx), _stream(counts.device)),
+               "peak_location")
+    return idx
+
+
+def counter_add_(counter, inc=1):
+    """*counter += inc on the device (counter: uint32/int32 device tensor of one element): the `epoch` of the generators."""
+    _lib.check(_lib.load().micloc_counter_add_u32(_ptr(counter), int(inc), _stream(counter.device)), "counter_add")
+    return counter
+
+
+def awgn_workspace(B, T, M, device):
+    torch = _torch()
+    return torch.empty(int(_lib.load().micloc_awgn_workspace_bytes(int(B), int(T), int(M))), dtype=torch.uint8, device=device)
+
+
 def doa_error(argmax, doa_list, doa_true, groups=1, want_err=True):
     """Device tensors argmax [B] int32, doa_list [G] f64, doa_true [B] f64 -> (err [B] or None, mae [groups]):
     arcsin|sin(doa_list[argmax] - doa_true)| and its mean per SNR group (target_snn_localization.py:464-467, :520)."""

@@ -141,18 +141,14 @@ class SNNBeamformer:
         sig_in_vec += noise
         return self.apply_to_signal(bf_mat=bf_mat, sig_in_vec=(time_in, sig_in_vec))
 
-    def synthesize_batch(self, template, doas):
-        """Noise-free array signals for a batch of constant DoAs, synthesised on the device (bit-exact with the host
-        path / the reference's np.interp).  template = (time_temp, sig_temp); returns (time_in [T] numpy, x [B, T, M] device)."""
-        time_temp, sig_temp = template
-        time_temp = np.asarray(time_temp, dtype=np.float64)
-        time_in = np.arange(time_temp.min(), time_temp.max(), step=1 / self.fs)
-        sig_in = np.interp(time_in, time_temp, np.asarray(sig_temp, dtype=np.float64))
-        doas = np.atleast_1d(np.asarray(doas, dtype=np.float64))
-        # reference :239-257 with a scalar DoA: doa_in = np.interp(time_in, time_temp, doa * ones) == doa exactly
-        delays = self.geometry.delays(doas, normalized=False)
-        delays = delays - delays.min(axis=1, keepdims=True)
-        return time_in, runtime.synth_delay(time_in, sig_in, delays, self.fs, device=self.device)
+    def synthesize_batch(self, template, doas, device_delays=False):
+        """Noise-free array signals for a batch of trials, synthesised on the device (synthesis.apply_to_template_batch).
+        template = (time_temp, sig_temp); doas [B] (constant DoA per trial) or [B, len(time_temp)] (moving DoAs).
+        device_delays=False: delays from NumPy's cos, bit-exact with the host path / the reference's np.interp;
+        True: delays computed in the kernel (throughput runs).  Returns (time_in [T] numpy, x [B, T, M] device)."""
+        from . import synthesis
+
+        return synthesis.apply_to_template_batch(self.geometry, self.fs, template, doas, device=self.device, device_delays=device_delays)
 
     # ---- batched device entry points (not in the reference) --------------------------------------------------
     def localize_batch(self, bf_mat, sig_batch, time_vec=None, return_spikes=False, power_mode="direct"):

@@ -7,8 +7,11 @@ parity mode      every rank replays the reference's global NumPy stream (rand(1)
                  legacy MT19937) and keeps its own shard, so results are identical to the single-process
                  reference for any world size.
 throughput mode  DoAs from a seeded host generator, clean array signals synthesised on the device
-                 (micloc_synth_delay_f64, bit-exact with np.interp), noise drawn on the device (torch Philox generator
-                 seeded per rank).
+                 (csrc/synth.hip, bit-exact with np.interp), noise from the Philox-4x32-10 + Box-Muller kernel
+                 (csrc/rng.hip), numbered by global trial so that the draw does not depend on the sharding.
+
+Sweeps: noisy_target_sweep (target_snn_localization.py:435-467), speech_target_sweep (:213-245), xylo_target_sweep
+(target_xylo_localization.py:540-608; integer-LIF stage parity-unpinned).
 """
 import numpy as np
 
@@ -92,63 +95,193 @@ def device_localizer(beamf, bf_mat, max_batch=1100):
     return run
 
 
+def _template_sweep(beamf, bf_mat, doa_list, time_test, sig_test, snr_db_trial, num_sim, seed, mode, rank, world_size, group,
+                    localizer, batch_trials):
+    """The Monte-Carlo loop shared by the noisy-target and the speech sweep (target_snn_localization.py:447-467 / :224-245):
+    per trial `doa = rand(1)[0] * 2 pi`, apply_to_template at `snr_db_trial[trial]`, power, arg-max, pi-periodic error.
+    Trials are processed in batches of `batch_trials` (host memory: a speech trial is 18.6 MB)."""
+    total = len(snr_db_trial)
+    lo, hi = shard_range(total, rank, world_size)
+    localizer = localizer or device_localizer(beamf, bf_mat, max_batch=batch_trials)
+    M = len(beamf.geometry)
+    doa_all = np.zeros(total)
+    argmax_parts, pmax_parts = [], []
+
+    def flush(sig_batch, time_in):
+        a, p = localizer(sig_batch, time_in)
+        argmax_parts.append(np.asarray(a, dtype=np.int64))
+        pmax_parts.append(np.asarray(p, dtype=np.float64))
+
+    if mode == "parity":
+        # the reference's global MT19937 stream, replayed on every rank; a rank keeps the trials of its shard
+        np.random.seed(seed)
+        T = len(np.arange(time_test.min(), time_test.max(), step=1 / beamf.fs))
+        sigs, time_in = [], None
+        for trial in range(total):
+            doa = np.random.rand(1)[0] * 2 * np.pi
+            doa_all[trial] = doa
+            if lo <= trial < hi:
+                time_in, sig = synthesize_array_signal(beamf.geometry, beamf.fs, time_test, sig_test, doa)
+                sig += np.sqrt(np.mean(sig**2)) / np.sqrt(10 ** (snr_db_trial[trial] / 10)) * np.random.randn(*sig.shape)
+                sigs.append(sig)
+                if len(sigs) == batch_trials:
+                    flush(np.stack(sigs), time_in)
+                    sigs = []
+            else:
+                np.random.randn(T, M)  # keep the stream aligned: the reference draws T x M normals for every trial
+        if sigs:
+            flush(np.stack(sigs), time_in)
+    elif mode == "throughput":
+        from . import synthesis
+
+        rng = np.random.RandomState(seed)
+        doa_all[:] = rng.rand(total) * 2 * np.pi
+        for s0 in range(lo, hi, batch_trials):
+            s1 = min(hi, s0 + batch_trials)
+            # noise-free array signals synthesised on the device (bit-exact with the host np.interp path), noise from the
+            # Philox kernel, numbered by GLOBAL trial: the same draw for any sharding
+            time_in, x = beamf.synthesize_batch((time_test, sig_test), doa_all[s0:s1])
+            synthesis.add_noise_(x, snr_db_trial[s0:s1], seed=seed, first_trial=s0)
+            flush(x, time_in)
+    else:
+        raise ValueError("mode must be 'parity' or 'throughput'")
+
+    argmax = np.concatenate(argmax_parts) if argmax_parts else np.zeros(0, dtype=np.int64)
+    pmax = np.concatenate(pmax_parts) if pmax_parts else np.zeros(0)
+    full = gather_shards({"argmax": argmax, "pmax": pmax}, total, rank, world_size, group)
+    err = doa_error(np.asarray(doa_list)[full["argmax"]], doa_all)
+    shape = (total // num_sim, num_sim)
+    return dict(doa=doa_all.reshape(shape), argmax=full["argmax"].reshape(shape), pmax=full["pmax"].reshape(shape), err=err.reshape(shape),
+                mae_deg=np.mean(err.reshape(shape), axis=1) * 180 / np.pi)
+
+
 def noisy_target_sweep(beamf, bf_mat, doa_list, snr_db_vec=None, num_sim=100, seed=0, mode="parity", rank=0, world_size=1,
-                       group=None, freq_design=2000.0, test_duration=100e-3, snr_gain_due_to_bandwidth=None, localizer=None):
-    """Returns dict(doa, argmax, err, pmax: [num_snr, num_sim]; mae_deg [num_snr]) on every rank."""
+                       group=None, freq_design=2000.0, test_duration=100e-3, snr_gain_due_to_bandwidth=None, localizer=None,
+                       batch_trials=1100):
+    """paper_plots/target_snn_localization.py:435-467.  Returns dict(doa, argmax, err, pmax: [num_snr, num_sim];
+    mae_deg [num_snr]) on every rank."""
     fs = beamf.fs
-    if snr_db_vec is None:
-        snr_db_vec = np.linspace(-10, 20, 11)
-    snr_db_vec = np.asarray(snr_db_vec, dtype=np.float64)
+    snr_db_vec = np.asarray(np.linspace(-10, 20, 11) if snr_db_vec is None else snr_db_vec, dtype=np.float64)
     if snr_gain_due_to_bandwidth is None:
         snr_gain_due_to_bandwidth = (fs / 2) / 1000.0  # (fs/2)/(f_max - f_min) with the paper's [1, 2] kHz band
     time_test = np.arange(0, test_duration, step=1 / fs)
     sig_test = np.sin(2 * np.pi * freq_design * time_test)
-    total = len(snr_db_vec) * num_sim
-    lo, hi = shard_range(total, rank, world_size)
-    localizer = localizer or device_localizer(beamf, bf_mat)
+    snr_trial = np.repeat(snr_db_vec - 10 * np.log10(snr_gain_due_to_bandwidth), num_sim)  # :449
+    res = _template_sweep(beamf, bf_mat, doa_list, time_test, sig_test, snr_trial, num_sim, seed, mode, rank, world_size, group,
+                          localizer, batch_trials)
+    res["snr_db_vec"] = snr_db_vec
+    return res
 
+
+def speech_source(fs, flac_path=None, pcm16=None, rate=None):
+    """The speech test signal of target_snn_localization.py:148-154: the LibriSpeech utterance (FLAC file decoded by
+    haghighatshoarmuir2024_amd.flac, or already-decoded int16 PCM), resampled to `fs` with np.interp on a linspace grid.
+    Returns (time_fs, sig_fs)."""
+    if pcm16 is None:
+        from . import flac
+
+        pcm, rate, _ = flac.decode(open(flac_path, "rb").read())
+        sig = pcm[:, 0].astype(np.float64) / 32768.0  # soundfile.read returns float64 in [-1, 1)
+    else:
+        sig = np.asarray(pcm16).astype(np.float64) / 32768.0
+    rate = int(rate)
+    time_test = np.arange(len(sig)) / rate
+    time_fs = np.linspace(time_test[0], time_test[-1], int(len(sig) / rate * fs))
+    return time_fs, np.interp(time_fs, time_test, sig)
+
+
+def speech_target_sweep(beamf, bf_mat, doa_list, source, snr_db_vec=None, num_sim=20, seed=0, mode="parity", rank=0, world_size=1,
+                        group=None, localizer=None, batch_trials=25):
+    """The speech accuracy sweep of paper_plots/target_snn_localization.py:213-245: `source` = (time_fs, sig_test) from
+    `speech_source`, 11 SNRs x 20 trials, NO bandwidth correction of the SNR (`snr_db_target = snr_db`, :227)."""
+    snr_db_vec = np.asarray(np.linspace(-10, 20, 11) if snr_db_vec is None else snr_db_vec, dtype=np.float64)
+    time_fs, sig_test = source
+    res = _template_sweep(beamf, bf_mat, doa_list, np.asarray(time_fs, dtype=np.float64), np.asarray(sig_test, dtype=np.float64),
+                          np.repeat(snr_db_vec, num_sim), num_sim, seed, mode, rank, world_size, group, localizer, batch_trials)
+    res["snr_db_vec"] = snr_db_vec
+    return res
+
+
+def xylo_target_sweep(demo, snr_db_vec=None, num_sim=100, seed=0, mode="parity", rank=0, world_size=1, group=None,
+                      test_duration=1000e-3, snr_gain_due_to_bandwidth=None, batch_trials=50, device_delays=None, peak=None):
+    """The Xylo accuracy sweep of paper_plots/target_xylo_localization.py:540-608 (and its `_unipolar` twin): chirp test
+    signal over the design band (:549-560), per trial `signal_from_template` -> AWGN -> `spike_encoding` -> `xylo_process`
+    -> spike rate -> `find_peak_location(win_size)` with win_size = 2 * ((num_grid // 32) // 2) + 1 (:600-603) -> error.
+
+    PARITY UNPINNED for the integer-LIF stage (rockpool / XyloSim absent: xylo_snn_localization.py module docstring);
+    everything around it follows the reference's arithmetic.  `demo` is a xylo_snn_localization.Demo with one band."""
+    from . import synthesis
+    from .utils import find_peak_location
+    from .xylo_snn_localization import signal_from_template
+
+    fs = demo.fs
+    snr_db_vec = np.asarray(np.linspace(-10, 20, 11) if snr_db_vec is None else snr_db_vec, dtype=np.float64)
+    f_min, f_max = [float(v) for v in demo.freq_bands[0]]
+    if snr_gain_due_to_bandwidth is None:
+        snr_gain_due_to_bandwidth = (fs / 2) / (f_max - f_min)
+    time_test = np.arange(0, test_duration, step=1 / fs)
+    period = time_test[-1]
+    freq_inst = f_min + (f_max - f_min) * (time_test % period) / period
+    sig_test = np.sin(2 * np.pi * np.cumsum(freq_inst) * 1 / fs)
+    geometry = demo.beamfs[0].geometry
+    doa_list = demo.doa_list
+    num_grid = len(doa_list)
+    win_size = 2 * ((num_grid // 32) // 2) + 1
+    total = len(snr_db_vec) * num_sim
+    snr_trial = np.repeat(snr_db_vec - 10 * np.log10(snr_gain_due_to_bandwidth), num_sim)
+    lo, hi = shard_range(total, rank, world_size)
+    if device_delays is None:
+        device_delays = mode == "throughput"
     doa_all = np.zeros(total)
-    sigs = []
-    time_in = None
+    idx_parts = []
+
+    if peak is None:
+        peak = "device" if mode == "throughput" else "host"
+
+    def flush(x):
+        if peak == "device":  # find_peak_location on the device (exact integer window sums): only indices come back
+            idx_parts.extend(int(v) for v in demo.peak_batch(x, win_size).cpu().numpy())
+            return
+        rate = demo.rate_batch(x).cpu().numpy()  # [B, G]: mean(spikes_out) * fs per DoA
+        for p in rate:
+            mx = p.max()
+            p = p / mx if mx > 0 else p  # :595 (an all-silent output divides 0 by 0 in the reference)
+            idx_parts.append(int(find_peak_location(sig_in=p, win_size=win_size)))
+
     if mode == "parity":
         np.random.seed(seed)
+        T, M = len(time_test), len(geometry)
+        sigs = []
         for trial in range(total):
-            snr_db = snr_db_vec[trial // num_sim] - 10 * np.log10(snr_gain_due_to_bandwidth)
             doa = np.random.rand(1)[0] * 2 * np.pi
             doa_all[trial] = doa
             if lo <= trial < hi:
-                time_in, sig = synthesize_array_signal(beamf.geometry, fs, time_test, sig_test, doa)
-                sig += np.sqrt(np.mean(sig**2)) / np.sqrt(10 ** (snr_db / 10)) * np.random.randn(*sig.shape)
-                sigs.append(sig)
+                sig = signal_from_template(geometry, (time_test, sig_test, doa))
+                noise_sigma = np.sqrt(np.mean(sig**2) / 10 ** (snr_trial[trial] / 10))
+                sigs.append(sig + noise_sigma * np.random.randn(*sig.shape))
+                if len(sigs) == batch_trials:
+                    flush(np.stack(sigs))
+                    sigs = []
             else:
-                # keep the global stream aligned: the reference draws T x M normals for every trial
-                np.random.randn(len(time_test) - 1, len(beamf.geometry))
-        sig_batch = np.stack(sigs) if sigs else np.zeros((0, len(time_test) - 1, len(beamf.geometry)))
+                np.random.randn(T, M)
+        if sigs:
+            flush(np.stack(sigs))
     elif mode == "throughput":
-        import torch
-
         rng = np.random.RandomState(seed)
         doa_all[:] = rng.rand(total) * 2 * np.pi
-        # noise-free array signals synthesised on the device (bit-exact with the host np.interp path)
-        time_in, clean = beamf.synthesize_batch((time_test, sig_test), doa_all[lo:hi])
-        gen = torch.Generator(device=clean.device)
-        gen.manual_seed(seed * 1_000_003 + rank)
-        snr_db = torch.from_numpy(snr_db_vec[np.arange(lo, hi) // num_sim] - 10 * np.log10(snr_gain_due_to_bandwidth)).to(clean.device)
-        sigma = torch.sqrt(torch.mean(clean**2, dim=(1, 2))) / torch.sqrt(10 ** (snr_db / 10))
-        sig_batch = clean + sigma[:, None, None] * torch.randn(clean.shape, generator=gen, device=clean.device, dtype=torch.float64)
+        for s0 in range(lo, hi, batch_trials):
+            s1 = min(hi, s0 + batch_trials)
+            x = synthesis.signal_from_template_batch(geometry, (time_test, sig_test), doa_all[s0:s1], device=demo.device, device_delays=device_delays)
+            synthesis.add_noise_(x, snr_trial[s0:s1], seed=seed, first_trial=s0)
+            flush(x)
     else:
         raise ValueError("mode must be 'parity' or 'throughput'")
 
-    if hi > lo:
-        argmax, pmax = localizer(sig_batch, time_in)
-    else:
-        argmax, pmax = np.zeros(0, dtype=np.int64), np.zeros(0)
-    full = gather_shards({"argmax": np.asarray(argmax, dtype=np.int64), "pmax": np.asarray(pmax, dtype=np.float64)}, total, rank, world_size, group)
-    doa_list = np.asarray(doa_list)
-    err = doa_error(doa_list[full["argmax"]], doa_all)
+    full = gather_shards({"index": np.asarray(idx_parts, dtype=np.int64)}, total, rank, world_size, group)
+    err = doa_error(np.asarray(doa_list)[full["index"]], doa_all)
     shape = (len(snr_db_vec), num_sim)
-    return dict(doa=doa_all.reshape(shape), argmax=full["argmax"].reshape(shape), pmax=full["pmax"].reshape(shape), err=err.reshape(shape),
-                mae_deg=np.mean(err.reshape(shape), axis=1) * 180 / np.pi, snr_db_vec=snr_db_vec)
+    return dict(doa=doa_all.reshape(shape), index=full["index"].reshape(shape), err=err.reshape(shape),
+                mae_deg=np.mean(err.reshape(shape), axis=1) * 180 / np.pi, snr_db_vec=snr_db_vec, win_size=win_size, parity="unpinned (integer LIF)")
 
 
 def main(argv=None):

@@ -108,6 +108,45 @@ def xylo_lif(spikes_in, spec, max_spikes=31, want_spikes=True, device=None):
     return out, rate
 
 
+class XyloNetwork:
+    """The quantised hidden layer resident on the device (micloc_xylo_upload once, then micloc_xylo_lif_resident_i16 per
+    batch: no host access, no synchronisation -- capturable into a HIP graph).  PARITY UNPINNED like xylo_lif."""
+
+    def __init__(self, spec, device=None):
+        import torch
+
+        self.lib = _lib.load()
+        self.device = runtime.require_gpu(device)
+        W = np.ascontiguousarray(spec["W_in"], dtype=np.int8)
+        self.Cin, self.N = W.shape
+        self.w_rec = int(spec["w_rec"])
+        ds = np.ascontiguousarray(spec["dash_syn"], dtype=np.uint8)
+        dm = np.ascontiguousarray(spec["dash_mem"], dtype=np.uint8)
+        th = np.ascontiguousarray(spec["threshold"], dtype=np.int16)
+        self.nbytes = self.lib.micloc_xylo_workspace_bytes(self.Cin, self.N)
+        self.ws = torch.empty(int(self.nbytes), dtype=torch.uint8, device=self.device)
+        vp = ctypes.c_void_p
+        _lib.check(self.lib.micloc_xylo_upload(self.Cin, vp(W.ctypes.data), self.N, vp(ds.ctypes.data), vp(dm.ctypes.data), vp(th.ctypes.data),
+                                               runtime._ptr(self.ws), self.nbytes, runtime._stream(self.device)), "xylo_upload")
+
+    def run(self, spikes, ternary=False, want_spikes=False, max_spikes=31):
+        """spikes: uint8 events [B, T, Cin], or (ternary=True) the encoder's int8 raster [B, T, Cin / 2] in {-1, 0, +1}.
+        Returns (spikes_out uint8 [B, T, N] or None, rate int32 [B, N]) as device tensors."""
+        import torch
+
+        B, T, C = spikes.shape
+        if (2 * C if ternary else C) != self.Cin:
+            raise ValueError(f"number of input spike channels {2 * C if ternary else C} should match the weight matrix {self.Cin}")
+        if spikes.dtype != (torch.int8 if ternary else torch.uint8) or not spikes.is_contiguous():
+            raise ValueError("spikes must be a contiguous int8 (ternary) / uint8 (events) device tensor")
+        out = torch.empty((B, T, self.N), dtype=torch.uint8, device=self.device) if want_spikes else None
+        rate = torch.empty((B, self.N), dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.micloc_xylo_lif_resident_i16(runtime._ptr(spikes), C if ternary else 0, B, T, self.Cin, self.N, self.w_rec, int(max_spikes),
+                                                         runtime._ptr(out), runtime._ptr(rate), runtime._ptr(self.ws), self.nbytes,
+                                                         runtime._stream(self.device)), "xylo_lif_resident")
+        return out, rate
+
+
 class Demo:
     def __init__(self, geometry, freq_bands, doa_list, recording_duration=0.25, kernel_duration=10e-3, bipolar_spikes=True,
                  xylosim_version=True, fs=48_000, device=None):
@@ -137,6 +176,7 @@ class Demo:
         self.fs = fs
         self.dt = 1.0 / fs
         self._band_plans = None
+        self._net = None
         self._initialize_snn_module(target_dt=1e-3)
 
     def _initialize_snn_module(self, target_dt):
@@ -174,13 +214,47 @@ class Demo:
         out, _ = xylo_lif(np.asarray(spikes_in), self.spec, want_spikes=True, device=self.device)
         return out.cpu().numpy().astype(np.int64)
 
+    def network(self):
+        if self._net is None:
+            self._net = XyloNetwork(self.spec, device=self.device)
+        return self._net
+
+    def raster_device(self, sig_batch):
+        """[B, T, M] -> the encoder's int8 raster [B, T, 2M * F] in {-1, 0, +1} (bands concatenated on the channel axis);
+        the +/- split of spike_encoding happens inside the LIF kernel's staging loop."""
+        import torch
+
+        per_band = []
+        for plan in self._plans():
+            x = plan.to_device(sig_batch)
+            h = plan.stht(x)
+            _, spikes = plan.bandpass_rzcc(h, x.shape[1], want_pre=False, want_spikes=True)
+            per_band.append(spikes)
+        return per_band[0] if len(per_band) == 1 else torch.cat(per_band, dim=2).contiguous()
+
+    def counts_batch(self, sig_batch):
+        """[B, T, M] noisy array signals -> output spike counts per hidden neuron, int32 device tensor [B, F * G]; nothing of
+        size T x N is materialised and only micloc kernels run."""
+        import torch
+
+        raster = self.raster_device(sig_batch)
+        if not self.bipolar_spikes:  # unipolar encoder: the raster holds 0 / +1 only and IS the event tensor
+            return self.network().run(raster.view(dtype=torch.uint8), ternary=False)[1]
+        return self.network().run(raster, ternary=True)[1]
+
     def rate_batch(self, sig_batch):
-        """[B, T, M] noisy array signals -> spike rate per DoA [B, G] (device tensor), nothing T x N materialised."""
-        spikes = self.spike_encoding_device(sig_batch)
-        _, rate = xylo_lif(spikes, self.spec, want_spikes=False, device=self.device)
-        T = spikes.shape[1]
-        rate_channels = rate.double() / T * self.fs
-        return rate_channels.reshape(rate.shape[0], -1, len(self.doa_list)).mean(dim=1)
+        """[B, T, M] noisy array signals -> spike rate per DoA [B, G] (device tensor): mean(spikes_out) * fs averaged over
+        the bands (extract_rate, xylo_snn_localization.py:379-398)."""
+        counts = self.counts_batch(sig_batch)
+        T = sig_batch.shape[1]
+        rate_channels = counts.double() / T * self.fs
+        return rate_channels.reshape(counts.shape[0], -1, len(self.doa_list)).mean(dim=1)
+
+    def peak_batch(self, sig_batch, win_size):
+        """[B, T, M] -> find_peak_location(rate / rate.max(), win_size) per trial on the device (int32 tensor [B]):
+        the estimator of paper_plots/target_xylo_localization.py:594-604."""
+        counts = self.counts_batch(sig_batch)
+        return runtime.peak_location(counts, len(self.doa_list), win_size)
 
     def extract_rate(self, spikes_in):
         rate_channels = np.mean(spikes_in, axis=0) * self.fs

@@ -180,6 +180,57 @@ int micloc_snn_pipeline_cov_f64(const micloc_plan *plan, const double *x, int B,
 int micloc_synth_delay_f64(const double *time, const double *sig, const double *slopes, int T, const double *delays,
                            int B, int M, double fs, double *x, void *stream);
 
+/* General form: every noise-free signal generator of the reference (all pointers are DEVICE buffers).
+ *   x[b][t][m] = sum_k gain[b][k][t] * np.interp(arg, time, sig),   arg = max(time[t] - (d - shift[b]), time[0])   (mode 0)
+ *                                                                   arg = time[t] + d                             (mode 1)
+ *   d = delay of microphone m for target k of trial b at time t (geometry.delays(doa, normalized=False))
+ * mode MICLOC_SYNTH_APPLY_TO_TEMPLATE   = SNNBeamformer / Beamformer.apply_to_template (snn_beamformer.py:239-267,
+ *      beamformer.py:220-245; `shift` = delays.min() of :257), also with a moving DoA (`moving` = 1);
+ * mode MICLOC_SYNTH_SIGNAL_FROM_TEMPLATE = signal_from_template (xylo_snn_localization.py:44-71: no shift, no clamp, np.interp
+ *      saturates) and, with K > 1 and `gain`, signal_multiple_targets (paper_plots/multiple_targets_snn.py:87-160).
+ * Delay source: `delays` [B][K][Td][M] (Td = T if moving else 1) computed by the caller (NumPy cos: bit-exact parity with
+ * the reference), or, with delays == NULL, computed on the device from `doa` [B][K][Td] and the geometry r_vec / theta_vec
+ * [M], `speed` (-r cos(theta_m - doa) / speed; device cos, within an ulp of NumPy's: throughput runs, nothing of size
+ * B x T x M crosses PCIe).  `shift` [B] and `gain` [B][K][T] may be NULL.  time / sig [T], slopes [T-1], x [B][T][M]. */
+#define MICLOC_SYNTH_APPLY_TO_TEMPLATE 0
+#define MICLOC_SYNTH_SIGNAL_FROM_TEMPLATE 1
+typedef struct micloc_synth_args {
+    const double *time, *sig, *slopes;
+    int T, B, K, M;
+    const double *delays;
+    const double *doa;
+    int moving;
+    const double *r_vec, *theta_vec;
+    double speed;
+    const double *shift;
+    const double *gain;
+    int mode;
+    double fs;
+    double *x;
+} micloc_synth_args;
+int micloc_synth_targets_f64(const micloc_synth_args *args, void *stream);
+/* shift[b] = min over targets, time steps and microphones of -r cos(theta_m - doa) / speed  (snn_beamformer.py:257's
+ * `delays.min()`), from doa [B][K][moving_T]; device buffers. */
+int micloc_delay_min_f64(const double *doa, int B, int K, int moving_T, const double *r_vec, const double *theta_vec, int M,
+                         double speed, double *shift, void *stream);
+
+/* ---- counter-based random numbers (throughput-mode sweeps) --------------------------------------- */
+/* Philox-4x32-10 keyed by `seed`; counter = (index, trial, substream).  The reference draws from NumPy's sequential
+ * global MT19937 stream (target_snn_localization.py:452, snn_beamformer.py:273); parity runs replay that on the host,
+ * throughput runs use these: out[i] = lo + (hi - lo) * u_i, u in [0, 1) with 53 bits (np.random.rand's range), and
+ * x[b] += sigma_b * N(0, 1) (Box-Muller, fp64) with sigma_b = sqrt(mean(x[b]^2)) / sqrt(10^(snr_db[b] / 10))
+ * (snn_beamformer.py:270-275) computed on the device from snr_db [B], or taken from `sigma` [B] when it is not NULL.
+ * Trial b of the call uses counter word `first_trial + b`, so a sweep sharded over ranks draws the same noise for a
+ * given global trial whatever the world size.  `epoch` (device uint32, may be NULL) is added to `substream` when the kernel
+ * runs: a HIP graph that contains the generators draws fresh numbers on every replay once micloc_counter_add_u32 (also in
+ * the graph) advances it.  Device buffers; ws from micloc_awgn_workspace_bytes (256-B aligned). */
+int micloc_uniform_f64(double *out, size_t n, uint64_t seed, uint32_t substream, const uint32_t *epoch, double lo, double hi,
+                       void *stream);
+size_t micloc_awgn_workspace_bytes(int B, int T, int M);
+int micloc_awgn_f64(double *x, int B, int T, int M, const double *snr_db, const double *sigma, uint64_t seed, uint32_t substream,
+                    const uint32_t *epoch, uint32_t first_trial, void *ws, size_t ws_bytes, void *stream);
+int micloc_counter_add_u32(uint32_t *counter, uint32_t inc, void *stream); /* *counter += inc (device word) */
+
 /* ---- Monte-Carlo results ---------------------------------------------------------------------- */
 /* err[b] = arcsin|sin(doa_list[argmax[b]] - doa_true[b])| (target_snn_localization.py:464-466; pi-periodic) and
  * mae[s] = mean of err over the `B / groups` consecutive trials of SNR group s (:520).  All pointers are DEVICE buffers
@@ -198,6 +249,22 @@ size_t micloc_xylo_workspace_bytes(int Cin, int N);
 int micloc_xylo_lif_i16(const uint8_t *spikes_in, int B, int T, int Cin, const int8_t *W_in, int N, int w_rec,
                         const uint8_t *dash_syn, const uint8_t *dash_mem, const int16_t *thr, int max_spikes,
                         uint8_t *spikes_out, int32_t *rate, void *ws, size_t ws_bytes, void *stream);
+
+/* The same network in two phases: micloc_xylo_upload places the packed weights / constants in `ws` (synchronises once);
+ * micloc_xylo_lif_resident_i16 then runs any number of batches without touching host memory or synchronising, so it can
+ * be captured into a HIP graph.  ternary_channels > 0: `spikes_in` is the encoder's int8 raster [B][T][ternary_channels]
+ * in {-1, 0, +1} and Cin = 2 * ternary_channels: input channel c carries the +1 events of raster channel c, channel
+ * ternary_channels + c its -1 events -- Demo.spike_encoding's split (xylo_snn_localization.py:350-354) folded into the
+ * kernel's staging loop.  ternary_channels == 0: spikes_in is uint8 [B][T][Cin] as above. */
+int micloc_xylo_upload(int Cin, const int8_t *W_in, int N, const uint8_t *dash_syn, const uint8_t *dash_mem, const int16_t *thr,
+                       void *ws, size_t ws_bytes, void *stream);
+int micloc_xylo_lif_resident_i16(const void *spikes_in, int ternary_channels, int B, int T, int Cin, int N, int w_rec,
+                                 int max_spikes, uint8_t *spikes_out, int32_t *rate, void *ws, size_t ws_bytes, void *stream);
+/* index[b] = find_peak_location(power_b, win_size) (micloc/utils.py:84-121; paper_plots/target_xylo_localization.py:594-604)
+ * with power_b[g] = sum over `bands` of rate[b][f * G + g] (the per-DoA spike counts; the reference's positive scale
+ * factors T / fs and 1 / max do not move the arg-max): box-car of win_size samples, FULL non-circular convolution, first
+ * maximum, minus win_size // 2, modulo G.  Exact integer window sums.  rate [B][bands * G] int32, index [B] (device). */
+int micloc_peak_location_i32(const int32_t *rate, int B, int G, int bands, int win_size, int32_t *index, void *stream);
 
 /* ---- misc ------------------------------------------------------------------------------------- */
 int micloc_abi_version(void);

@@ -435,3 +435,64 @@ void oracle_xylo_lif(const unsigned char *spikes_in, int T, int Cin, const signe
     free(isyn);
     free(vmem);
 }
+
+
+/* ------------------------------------------------------------------------------------------------
+ * Counter-based random numbers of the throughput-mode sweep (csrc/rng.hip): Philox-4x32-10
+ * (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3", SC'11; the Random123
+ * reference implementation, v1.14 philox.h: multipliers 0xD2511F53 / 0xCD9E8D57, Weyl keys 0x9E3779B9 /
+ * 0xBB67AE85), pinned by the known-answer vectors of its kat_vectors file (tests/test_rng_cpu.py).
+ * The reference itself draws from NumPy's sequential MT19937 (paper_plots/target_snn_localization.py:452,
+ * micloc/snn_beamformer.py:270-275); this stream replaces it only where bit parity of the noise is not
+ * asked for.  Same counter layout as the device: key = seed, counter = (index lo, index hi, trial, substream).
+ * ---------------------------------------------------------------------------------------------- */
+void oracle_philox4x32_10(const unsigned int ctr[4], const unsigned int key[2], unsigned int out[4])
+{
+    unsigned int c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = 0xD2511F53ull * c0;
+        const unsigned long long p1 = 0xCD9E8D57ull * c2;
+        const unsigned int n0 = (unsigned int)(p1 >> 32) ^ c1 ^ k0;
+        const unsigned int n1 = (unsigned int)p1;
+        const unsigned int n2 = (unsigned int)(p0 >> 32) ^ c3 ^ k1;
+        const unsigned int n3 = (unsigned int)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+static double u53_co(unsigned int lo, unsigned int hi) { return (double)((((unsigned long long)hi << 32) | lo) >> 11) * 0x1.0p-53; }
+static double u53_oc(unsigned int lo, unsigned int hi) { return (double)(((((unsigned long long)hi << 32) | lo) >> 11) + 1) * 0x1.0p-53; }
+
+/* out[i] = lo + (hi - lo) * u_i, u in [0, 1): two per Philox call */
+void oracle_uniform(double *out, long long n, unsigned long long seed, unsigned int substream, double lo, double hi)
+{
+    const unsigned int key[2] = {(unsigned int)seed, (unsigned int)(seed >> 32)};
+    const double span = hi - lo;
+    for (long long pair = 0; 2 * pair < n; ++pair) {
+        const unsigned int ctr[4] = {(unsigned int)pair, (unsigned int)((unsigned long long)pair >> 32), 0u, substream};
+        unsigned int r[4];
+        oracle_philox4x32_10(ctr, key, r);
+        out[2 * pair] = lo + span * u53_co(r[0], r[1]);
+        if (2 * pair + 1 < n) out[2 * pair + 1] = lo + span * u53_co(r[2], r[3]);
+    }
+}
+
+/* z[e] for the flat [T][M] block of trial `trial`: Box-Muller, pair i -> elements 2i (cos), 2i+1 (sin) */
+void oracle_normals(double *z, long long n, unsigned long long seed, unsigned int substream, unsigned int trial)
+{
+    const unsigned int key[2] = {(unsigned int)seed, (unsigned int)(seed >> 32)};
+    for (long long pair = 0; 2 * pair < n; ++pair) {
+        const unsigned int ctr[4] = {(unsigned int)pair, (unsigned int)((unsigned long long)pair >> 32), trial, substream};
+        unsigned int r[4];
+        oracle_philox4x32_10(ctr, key, r);
+        const double u1 = u53_oc(r[0], r[1]);
+        const double u2 = u53_co(r[2], r[3]);
+        const double rad = sqrt(-2.0 * log(u1));
+        const double ang = 6.283185307179586476925286766559 * u2;
+        z[2 * pair] = rad * cos(ang);
+        if (2 * pair + 1 < n) z[2 * pair + 1] = rad * sin(ang);
+    }
+}

@@ -39,6 +39,10 @@ void oracle_xylo_lif(const unsigned char *spikes_in, int T, int Cin, const signe
                      const unsigned char *dash_syn, const unsigned char *dash_mem, const short *thr, int max_spikes,
                      unsigned char *spikes_out, int *rate);
 
+void oracle_philox4x32_10(const unsigned int ctr[4], const unsigned int key[2], unsigned int out[4]);
+void oracle_uniform(double *out, long long n, unsigned long long seed, unsigned int substream, double lo, double hi);
+void oracle_normals(double *z, long long n, unsigned long long seed, unsigned int substream, unsigned int trial);
+
 #ifdef __cplusplus
 }
 #endif

@@ -64,6 +64,10 @@ def lib():
                                              ctypes.c_int, _dp, _ip]
         L.oracle_xylo_lif.argtypes = [_ubp, ctypes.c_int, ctypes.c_int, _bp, ctypes.c_int, ctypes.c_int, _ubp, _ubp,
                                       ctypes.POINTER(ctypes.c_short), ctypes.c_int, _ubp, _ip]
+        _up = ctypes.POINTER(ctypes.c_uint)
+        L.oracle_philox4x32_10.argtypes = [_up, _up, _up]
+        L.oracle_uniform.argtypes = [_dp, ctypes.c_longlong, ctypes.c_ulonglong, ctypes.c_uint, ctypes.c_double, ctypes.c_double]
+        L.oracle_normals.argtypes = [_dp, ctypes.c_longlong, ctypes.c_ulonglong, ctypes.c_uint, ctypes.c_uint]
         _lib = L
     return _lib
 
@@ -344,3 +348,59 @@ def xylo_lif(spikes_in, W_in, w_rec, dash_syn, dash_mem, thr, max_spikes=31):
                           dm.ctypes.data_as(_ubp), th.ctypes.data_as(ctypes.POINTER(ctypes.c_short)), int(max_spikes),
                           out.ctypes.data_as(_ubp), rate.ctypes.data_as(_ip))
     return out, rate
+
+
+# ------------------------------------------------------------------------------------------------
+# counter-based random numbers of the throughput-mode sweep (csrc/rng.hip) and the signal generators of the
+# other scripts (micloc/xylo_snn_localization.py:44-71, paper_plots/multiple_targets_snn.py:87-160)
+# ------------------------------------------------------------------------------------------------
+def philox4x32_10(ctr, key):
+    c = (ctypes.c_uint * 4)(*[int(v) & 0xFFFFFFFF for v in ctr])
+    k = (ctypes.c_uint * 2)(*[int(v) & 0xFFFFFFFF for v in key])
+    o = (ctypes.c_uint * 4)()
+    lib().oracle_philox4x32_10(c, k, o)
+    return [int(v) for v in o]
+
+
+def uniform(n, seed, substream=0, lo=0.0, hi=1.0):
+    out = np.empty(int(n))
+    lib().oracle_uniform(out.ctypes.data_as(_dp), int(n), int(seed), int(substream), float(lo), float(hi))
+    return out
+
+
+def normals(n, seed, substream, trial):
+    z = np.empty(int(n))
+    lib().oracle_normals(z.ctypes.data_as(_dp), int(n), int(seed), int(substream), int(trial))
+    return z
+
+
+def awgn(x, snr_db, seed, substream=0, first_trial=0):
+    """x [B, T, M] + sigma_b * N(0, 1), sigma_b = sqrt(mean(x_b^2)) / sqrt(10^(snr_db_b / 10)) (snn_beamformer.py:270-275)
+    with the device's Philox stream.  Returns (noisy, sigma)."""
+    x = np.asarray(x, dtype=np.float64)
+    B = x.shape[0]
+    snr_db = np.broadcast_to(np.asarray(snr_db, dtype=np.float64), (B,))
+    sigma = np.sqrt(np.mean(x.reshape(B, -1) ** 2, axis=1)) / np.sqrt(10 ** (snr_db / 10))
+    out = x.copy()
+    for b in range(B):
+        out[b] += sigma[b] * normals(x[b].size, seed, substream, first_trial + b).reshape(x[b].shape)
+    return out, sigma
+
+
+def signal_from_template(r_vec, theta_vec, time_temp, sig_temp, doa, speed=340):
+    """micloc/xylo_snn_localization.py:44-71: interp(t + delays(doa_t), t, s); no min-shift, no clamp."""
+    time_temp = np.asarray(time_temp, dtype=np.float64)
+    doa = np.broadcast_to(np.asarray(doa, dtype=np.float64), time_temp.shape)
+    d = -np.asarray(r_vec)[None, :] * np.cos(np.asarray(theta_vec)[None, :] - doa.reshape(-1, 1)) / speed  # [T, M], array_geometry.py:52
+    td = time_temp.reshape(-1, 1) + d
+    return np.interp(td.ravel(), time_temp, sig_temp).reshape(td.shape)
+
+
+def signal_multiple_targets(r_vec, theta_vec, time_temp, sig_temp, doa_ts, power_ts, speed=340):
+    """paper_plots/multiple_targets_snn.py:87-160: sum over targets of power_k[t] * interp(t + delays(doa_k[t]), t, s)."""
+    doa_ts = np.asarray(doa_ts, dtype=np.float64)
+    power_ts = np.asarray(power_ts, dtype=np.float64)
+    sig_in = 0
+    for k in range(doa_ts.shape[1]):
+        sig_in = sig_in + power_ts[:, k].reshape(-1, 1) * signal_from_template(r_vec, theta_vec, time_temp, sig_temp, doa_ts[:, k], speed)
+    return sig_in

@@ -120,3 +120,59 @@ def test_demo_spike_encoding_pinned_and_end_to_end(cfg2):
     assert max(errs) < 15.0, errs
     with pytest.raises(ValueError):
         demo.estimate_doa_from_rate(rate, "median")
+
+
+@pytest.mark.gpu
+def test_resident_network_ternary_input_and_peak_location(cfg2):
+    """The two-phase form (constants resident, int8 raster in, +/- split inside the kernel) equals the one-shot form and the
+    oracle; the on-device find_peak_location equals the host function wherever the integer window sums have no tie."""
+    import torch
+
+    from haghighatshoarmuir2024_amd import runtime
+    from haghighatshoarmuir2024_amd.utils import find_peak_location
+    from haghighatshoarmuir2024_amd.xylo_snn_localization import XyloNetwork, xylo_lif, xylo_specification
+
+    tau = 1 / (2 * np.pi * 1500)
+    spec = xylo_specification([cfg2["bf_mat"]], [[tau, tau]], fs=48_000, target_dt=1e-3, bipolar_spikes=True)
+    rng = np.random.RandomState(4)
+    B, T, C = 3, 700, 14
+    raster = rng.choice([-1, 0, 1], size=(B, T, C), p=[0.05, 0.9, 0.05]).astype(np.int8)
+    events = np.concatenate([raster > 0, raster < 0], axis=2).astype(np.uint8)
+    net = XyloNetwork(spec)
+    out_t, rate_t = net.run(torch.from_numpy(raster).cuda(), ternary=True, want_spikes=True)
+    out_e, rate_e = net.run(torch.from_numpy(events).cuda(), ternary=False, want_spikes=True)
+    out_1, rate_1 = xylo_lif(events, spec)
+    assert torch.equal(out_t, out_e) and torch.equal(rate_t, rate_e) and torch.equal(out_t, out_1) and torch.equal(rate_t, rate_1)
+    for b in range(B):
+        eo, er = O.xylo_lif(events[b], spec["W_in"], spec["w_rec"], spec["dash_syn"], spec["dash_mem"], spec["threshold"], 31)
+        np.testing.assert_array_equal(out_t[b].cpu().numpy(), eo)
+        np.testing.assert_array_equal(rate_t[b].cpu().numpy(), er)
+    assert int(rate_t.sum()) > 0
+    # a recurrent weight and other channel counts go through the other instantiations
+    for cin, n, w_rec in ((3, 70, -3), (28, 449, -1), (40, 300, 0), (64, 1000, 2)):
+        sp = dict(W_in=rng.randint(-127, 128, size=(cin, n)).astype(np.int8), w_rec=w_rec, dash_syn=np.full(n, 2, np.uint8),
+                  dash_mem=np.full(n, 3, np.uint8), threshold=np.full(n, 300, np.int16))
+        ev = (rng.rand(2, 150, cin) < 0.2).astype(np.uint8)
+        o, r = XyloNetwork(sp).run(torch.from_numpy(ev).cuda(), want_spikes=True)
+        for b in range(2):
+            eo, er = O.xylo_lif(ev[b], sp["W_in"], w_rec, sp["dash_syn"], sp["dash_mem"], sp["threshold"], 31)
+            np.testing.assert_array_equal(o[b].cpu().numpy(), eo)
+            np.testing.assert_array_equal(r[b].cpu().numpy(), er)
+    # peak location: random counts (ties are rare), a flat profile (all ties -> first maximum) and a peak at the wrap-around
+    G = 449
+    counts = rng.poisson(40, size=(6, G)).astype(np.int32)
+    counts[1, 5:9] += 400
+    counts[2, -3:] += 400
+    counts[3, :] = 7
+    counts[4, :] = 0
+    idx = runtime.peak_location(torch.from_numpy(counts).cuda(), G, 15).cpu().numpy()
+    for b in range(6):
+        p = counts[b].astype(np.float64)
+        want = find_peak_location(p, 15)  # exact in fp64 for these integers (window sums < 2^53, no normalisation)
+        assert idx[b] == want, (b, idx[b], want)
+    two = np.concatenate([counts, counts[:, ::-1]], axis=1)  # two bands: the counts are summed per DoA first
+    idx2 = runtime.peak_location(torch.from_numpy(np.ascontiguousarray(two)).cuda(), G, 15).cpu().numpy()
+    for b in range(6):
+        assert idx2[b] == find_peak_location((two[b, :G] + two[b, G:]).astype(np.float64), 15)
+    with pytest.raises(ValueError):
+        runtime.peak_location(torch.from_numpy(counts).cuda(), G, 14)
