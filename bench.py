@@ -17,6 +17,11 @@ RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, RCCL process group); under `pytho
 Other workloads (same JSON contract, their own `config.workload`, not the headline):
   --config speech   BASELINE configs[2], per-GPU share: 125 trials of the LibriSpeech utterance (T = 332 157)
   --config stress   BASELINE configs[4], 64 mics / 96 kHz / 1440 DoAs, `--trials` trials per GPU (default 256)
+  --config xylo     BASELINE configs[3], target_xylo_localization.py: 1 s chirp (T = 48 000), order-1 band-pass, bipolar RZCC,
+                    integer LIF hidden layer (one neuron per DoA), find_peak_location -- PARITY UNPINNED for the LIF stage
+
+`value` times the hot path on a batch resident in HBM (the driver's contract); `value_e2e` adds everything in front of
+it inside the same captured graph: DoA draw, array-signal synthesis and AWGN on the device, fresh numbers every step.
 """
 import argparse
 import json
@@ -43,7 +48,7 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", choices=["noisy", "speech", "stress"], default="noisy")
+    ap.add_argument("--config", choices=["noisy", "speech", "stress", "xylo"], default="noisy")
     ap.add_argument("--grid", type=int, default=None, help="DoA grid size (default: 360; stress: 1440)")
     ap.add_argument("--trials", type=int, default=None, help="trials per rank per step (default: 1100 = 11 SNRs x 100; speech 125; stress 256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -174,14 +179,10 @@ def build_workload(args, rank, device):
     snr_db_vec = np.linspace(-10, 20, 11)
     groups = len(snr_db_vec) if B % len(snr_db_vec) == 0 else 1
     snr_db = snr_db_vec[(np.arange(B) * len(snr_db_vec)) // B] - 10 * np.log10(snr_gain)
-    time_in, clean = beamf.synthesize_batch((time_test, sig_test), doa)  # device synthesis, bit-exact with np.interp
-    gen = torch.Generator(device=device)
-    gen.manual_seed(1234 + rank)
-    sigma = torch.sqrt(torch.mean(clean**2, dim=(1, 2))) / torch.sqrt(10 ** (torch.from_numpy(snr_db).to(device) / 10))
-    x = clean
-    for lo in range(0, B, 64):  # in place, in slices: config 3's batch is 2.3 GB
-        x[lo : lo + 64] += sigma[lo : lo + 64, None, None] * torch.randn(x[lo : lo + 64].shape, generator=gen, device=device, dtype=torch.float64)
-    del clean
+    from haghighatshoarmuir2024_amd import synthesis
+
+    time_in, x = beamf.synthesize_batch((time_test, sig_test), doa)  # device synthesis, bit-exact with np.interp
+    synthesis.add_noise_(x, snr_db, seed=1234, first_trial=rank * B)   # Philox-4x32-10 + Box-Muller kernel, in place
 
     plan = beamf.plan()
     nir = neuron_impulse_response(time_in[: min(len(time_in), 48_000)], beamf.tau_vec)
@@ -190,7 +191,8 @@ def build_workload(args, rank, device):
     if args.encoder_chunk is not None:
         plan.set_encoder_chunk(args.encoder_chunk)
     return dict(beamf=beamf, plan=plan, x=x, doa=torch.from_numpy(doa).to(device), doa_list=torch.from_numpy(doa_list).to(device),
-                bf_mat=bf_mat, nir=nir, snr_groups=groups, fs=fs, encoder_chunk=args.encoder_chunk)
+                bf_mat=bf_mat, nir=nir, snr_groups=groups, fs=fs, encoder_chunk=args.encoder_chunk,
+                template=(time_test, sig_test), snr_db=snr_db, rank=rank)
 
 
 def make_step(wl, nstreams, variants=True):
@@ -226,11 +228,49 @@ def make_step(wl, nstreams, variants=True):
     replay_cov = pipe.capture(lambda plan: body(plan, True)) if small else None
     replay_f32 = pipe.capture(lambda plan: body(plan, "f32")) if small else None
 
+    # end-to-end variant: the whole Monte-Carlo trial on the device, per step and per stream
+    #   epoch += 1 -> DoAs ~ U[0, 2 pi) -> delays.min() -> delayed-template synthesis -> AWGN at the trial's SNR -> hot path
+    # (target_snn_localization.py:452-467; generators: csrc/rng.hip, synthesis: csrc/synth.hip with in-kernel delays)
+    import torch
+
+    from haghighatshoarmuir2024_amd import synthesis
+
+    beamf = wl["beamf"]
+    dev = x.device
+    B, T, M = x.shape
+    t_in, s_in = synthesis._resample(*wl["template"], beamf.fs)
+    tpl = runtime.Template(t_in, s_in, beamf.fs, device=dev)
+    geo = runtime.Geometry(beamf.geometry, device=dev)
+    snr_dev = torch.from_numpy(np.ascontiguousarray(wl["snr_db"])).to(dev)
+    e2e_state = {}
+    for i, p in enumerate(plans):
+        e2e_state[id(p)] = dict(x=torch.empty_like(x), doa=torch.empty((B,), dtype=torch.float64, device=dev),
+                                shift=torch.empty((B,), dtype=torch.float64, device=dev),
+                                epoch=torch.full((1,), (wl["rank"] * 64 + i) << 20, dtype=torch.int32, device=dev),
+                                ws=runtime.awgn_workspace(B, T, M, dev))
+
+    def body_e2e(plan):
+        st = e2e_state[id(plan)]
+        runtime.counter_add_(st["epoch"], 1)
+        runtime.uniform(B, 77, substream=0x40000000, lo=0.0, hi=2 * np.pi, out=st["doa"], epoch=st["epoch"])
+        runtime.delay_min(st["doa"].view(B, 1), geo, out=st["shift"])
+        runtime.synth_targets(tpl, "apply_to_template", doa=st["doa"].view(B, 1), geometry=geo, shift=st["shift"], out=st["x"])
+        runtime.awgn_(st["x"], snr_db=snr_dev, seed=77, substream=0, epoch=st["epoch"], ws=st["ws"])
+        out = plan.snn_pipeline(st["x"], want_power=True)
+        _, mae = runtime.doa_error(out["argmax"], doa_list, st["doa"], groups=S, want_err=False)
+        return out, mae
+
+    replay_e2e = pipe.capture(body_e2e) if variants is not None else None
+
     def step(cov=False):
+        if cov == "e2e":
+            return replay_e2e()
         if cov == "f32":
             return replay_f32()
         return replay_cov() if cov else replay_direct()
 
+    # every tensor a captured graph reads must outlive it: the replay closures hold the graphs and their outputs only
+    step.keepalive = (e2e_state, tpl, geo, snr_dev, x, doa, doa_list, plans)
     return step, pipe
 
 
@@ -416,6 +456,154 @@ def run_stub(args, rank, world):
     return 0
 
 
+XYLO_VALU_PER_NEURON_STEP = 41  # vector instructions per hidden-neuron wave and time step (ISA of xylo_lif_kernel<false, 7>)
+
+
+def run_xylo(args, rank, local_rank, world):
+    """BASELINE configs[3]: the Xylo sweep of paper_plots/target_xylo_localization.py:540-608 as a throughput run.
+    One step = STHT -> order-1 band-pass -> RZCC -> integer LIF hidden layer (spike counts only) -> find_peak_location ->
+    DoA error for a batch of trials resident in HBM.  PARITY UNPINNED for the LIF stage (rockpool / XyloSim absent)."""
+    import torch
+    import torch.distributed as dist
+
+    from haghighatshoarmuir2024_amd import runtime, synthesis
+    from haghighatshoarmuir2024_amd.array_geometry import CenterCircularArray
+    from haghighatshoarmuir2024_amd.xylo_snn_localization import Demo
+
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    use_dist = world > 1
+    group_size = 1
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        group_size = dist.get_world_size()
+    fs, M = 48_000, 7
+    G = args.grid or 360
+    B = args.trials or 1100
+    geometry = CenterCircularArray(radius=4.5e-2, num_mic=M)
+    doa_list = np.linspace(-np.pi, np.pi, G)
+    f_min, f_max = 1000.0, 2000.0
+    demo = Demo(geometry=geometry, freq_bands=[[f_min, f_max]], doa_list=doa_list, recording_duration=0.25, bipolar_spikes=True, fs=fs, device=device)
+    time_test = np.arange(0, 1000e-3, step=1 / fs)  # target_xylo_localization.py:549-560
+    period = time_test[-1]
+    sig_test = np.sin(2 * np.pi * np.cumsum(f_min + (f_max - f_min) * (time_test % period) / period) / fs)
+    rng = np.random.RandomState(2000 + rank)
+    doa = rng.rand(B) * 2 * np.pi
+    snr_db_vec = np.linspace(-10, 20, 11)
+    groups = len(snr_db_vec) if B % len(snr_db_vec) == 0 else 1
+    snr_db = snr_db_vec[(np.arange(B) * len(snr_db_vec)) // B] - 10 * np.log10((fs / 2) / (f_max - f_min))
+    x = synthesis.signal_from_template_batch(geometry, (time_test, sig_test), doa, device=device, device_delays=True)
+    synthesis.add_noise_(x, snr_db, seed=4321, first_trial=rank * B)
+    T = x.shape[1]
+    win = 2 * ((G // 32) // 2) + 1
+    d_doa = torch.from_numpy(doa).to(device)
+    d_list = torch.from_numpy(doa_list).to(device)
+    net = demo.network()
+    plan = demo._plans()[0]
+
+    def body():
+        counts = demo.counts_batch(x)
+        idx = runtime.peak_location(counts, G, win)
+        _, mae = runtime.doa_error(idx, d_list, d_doa, groups=groups, want_err=False)
+        return counts, idx, mae
+
+    s = torch.cuda.Stream(device=device)
+    s.wait_stream(torch.cuda.current_stream(device))
+    with torch.cuda.stream(s):
+        body()
+    s.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s, capture_error_mode="thread_local"):
+        counts, idx, mae = body()
+
+    def barrier():
+        s.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def replay():
+        with torch.cuda.stream(s):
+            g.replay()
+
+    for _ in range(args.warmup):
+        replay()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        replay()
+    barrier()
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+    if use_dist:
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        gathered = [torch.empty_like(mae) for _ in range(world)]
+        dist.all_gather(gathered, mae)
+        mae = torch.stack(gathered).mean(dim=0)
+    dt = float(dt.item())
+    frames = group_size * B * T * args.steps
+    result = None
+    if rank == 0:
+        def timed(fn, iters=5):
+            fn()
+            torch.cuda.synchronize()
+            e0 = [torch.cuda.Event(enable_timing=True) for _ in range(iters)]
+            e1 = [torch.cuda.Event(enable_timing=True) for _ in range(iters)]
+            for i in range(iters):
+                e0[i].record()
+                fn()
+                e1[i].record()
+            torch.cuda.synchronize()
+            return float(np.mean([a.elapsed_time(b) for a, b in zip(e0, e1)]))
+
+        h = plan.stht(x)
+        _, raster = plan.bandpass_rzcc(h, T, want_pre=False, want_spikes=True)
+        st = {"stht_kernel": timed(lambda: plan.stht(x)),
+              "bandpass_rzcc_kernel": timed(lambda: plan.bandpass_rzcc(h, T, want_pre=False, want_spikes=True)),
+              "xylo_lif_kernel": timed(lambda: net.run(raster, ternary=True)),
+              "peak_location_kernel": timed(lambda: runtime.peak_location(counts, G, win))}
+        dom = max(st, key=st.get)
+        N = net.N
+        waves = -(-N // 256) * 4 * B  # 256-neuron workgroups
+        if dom == "xylo_lif_kernel":
+            # integer recurrences, one neuron per lane, sequential in time: bound by vector-instruction issue (4 cycles per wave
+            # instruction per SIMD), neither HBM (28 B of input per frame) nor MFMA
+            ginstr = waves * T * XYLO_VALU_PER_NEURON_STEP / (st[dom] * 1e-3) / 1e9
+            peak = 1024 * 2.4 / 4  # SIMDs x GHz / cycles per wave instruction
+            roof = dict(kernel="xylo_lif_kernel", bound="valu-issue (integer recurrences; neither HBM nor MFMA binds)", achieved=ginstr, peak=peak,
+                        unit="G wave-instructions/s", frac=ginstr / peak, traffic=None,
+                        note=f"{XYLO_VALU_PER_NEURON_STEP} vector instructions per wave and time step, {waves} waves x {T} steps; lanes used {N}/{-(-N // 256) * 256}")
+        else:
+            achieved = B * T * (8 * 2 * M + 2 * M) / (st[dom] * 1e-3) / 1e9
+            roof = dict(kernel=dom, bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS, traffic=None)
+        roof["avg_launch_ms"] = st[dom]
+        roof["stages_ms"] = st
+        value = frames / dt
+        result = {
+            "metric": "audio samples/sec through STHT+RZCC+SNN beamform, 7-mic 48kHz 360-DoA; DoA MAE vs ref",
+            "value": value, "unit": "frames/s (one frame = one audio sample instant across all mics)",
+            "n_gpus": group_size, "rccl_ranks": group_size if use_dist else 0, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64 encoder + int16 LIF state / int8 weights", "data": "synthetic",
+            "parity": "UNPINNED for the integer-LIF stage (rockpool / XyloSim absent); spike encoding and peak finding pinned",
+            "config": {"workload": f"target_xylo_localization sweep (Xylo-A2 integer LIF, bipolar RZCC): {M}-mic, {fs // 1000} kHz, T={T} (1 s chirp), "
+                                   f"{B} trials/GPU/step, {G} hidden neurons = DoA grid, {4 * M} input channels, find_peak_location(win={win})",
+                       "trials_per_gpu": B, "frames_per_trial": T, "num_mic": M, "num_doa": G, "mic_samples_per_s": value * M,
+                       "parallelism": f"trial-sharded x{group_size}", "hip_streams": 1, "hip_graphs": True,
+                       "w_rec_quantised": int(net.w_rec)},
+            "mae_deg_per_snr": [float(v) for v in (mae * 180 / np.pi).cpu().numpy()],
+            "roofline": roof,
+        }
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        sys.stdout.flush()
+        print(json.dumps(result), flush=True)
+    return 0
+
+
 def run(args):
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
@@ -430,6 +618,8 @@ def run(args):
     if local_rank >= torch.cuda.device_count():
         print(f"bench.py: rank {rank} has no device (LOCAL_RANK {local_rank}, {torch.cuda.device_count()} visible)", file=sys.stderr)
         return 2
+    if args.config == "xylo":
+        return run_xylo(args, rank, local_rank, world)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     # MICLOC_FORCE_DIST=1 runs the collective code path with a 1-rank RCCL group (to exercise it on a 1-GPU box)
@@ -479,6 +669,17 @@ def run(args):
     value = frames / dt
     argmax_direct = out["argmax"].clone()  # graph outputs are static buffers: keep a copy for the comparisons below
     power_direct = out["power"].clone()
+
+    # the same K steps with the input side inside the graph (synthesis + noise regenerated every step)
+    dte, (out_e, mae_e) = timed_steps(lambda: step(cov="e2e"))
+    if use_dist:
+        gathered = [torch.empty_like(mae_e) for _ in range(world)]
+        dist.all_gather(gathered, mae_e)
+        mae_e = torch.stack(gathered).mean(dim=0)
+    e2e = {"value": frames / dte, "unit": "frames/s", "ms_per_step": dte / args.steps * 1e3,
+           "mae_deg_per_snr": [float(v) for v in (mae_e * 180 / np.pi).cpu().numpy()],
+           "note": "per step, inside the same HIP graph: DoA draw (Philox), delayed-template synthesis with in-kernel delays, AWGN "
+                   "(Philox + Box-Muller) at the trial's SNR, then the hot path and the DoA error; fresh trials every step"}
 
     cov_variant = f32_variant = None
     if noisy and M * 2 <= 64:
@@ -549,6 +750,8 @@ def run(args):
                        "trials_per_gpu": B, "frames_per_trial": T, "num_mic": M, "num_doa": G, "mic_samples_per_s": value * M,
                        "parallelism": f"trial-sharded x{group_size}", "hip_streams": nstreams, "hip_graphs": True},
             "mae_deg_per_snr": [float(v) for v in (mae * 180 / np.pi).cpu().numpy()],
+            "value_e2e": e2e["value"],
+            "e2e": e2e,
             "roofline": roof,
             # the north star also asks for the fraction of the HBM roofline: algorithmic bytes of the fused sweep
             # (one fp64 frame in, int8 spikes out and back in = 8M + 2M bytes per frame) over the whole job
