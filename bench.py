@@ -164,7 +164,8 @@ def build_workload(args, rank, device):
         bf_mat = rng_w.randn(2 * num_mic, G)
         bf_mat /= np.linalg.norm(bf_mat, axis=0, keepdims=True)
     else:
-        bf_mat = beamf.design_from_template(chirp_template(fs, freq_range), doa_list)
+        # the whole design on the device: delayed templates, chain, covariance, batched Jacobi SVD (micloc_design_vectors_f64)
+        bf_mat = beamf.design_from_template(chirp_template(fs, freq_range), doa_list, svd="device")
 
     # test signals (target_snn_localization.py:435-455 / :148-154,213-245): synthetic, generated here, noise drawn on the device
     if cfg == "speech":

@@ -728,6 +728,15 @@ int micloc_xylo_lif_resident_i16(const void *spikes_in, int ternary_channels, in
     return MICLOC_OK;
 }
 
+int micloc_design_vectors_f64(const double *cov, int n_doa, int C, int bipolar, double rel_prec, double *bf_mat, int G, int g0,
+                              void *stream)
+{
+    if (!cov || !bf_mat || n_doa < 1 || C < 2 || G < 1 || g0 < 0 || g0 + n_doa > G || !(rel_prec > 0.0)) return MICLOC_ERR_INVALID;
+    if (C > 32 || (bipolar && (C & 1))) return MICLOC_ERR_SHAPE;
+    HIP_TRY(launch_design_vec(cov, n_doa, C, bipolar ? 1 : 0, rel_prec, bf_mat, G, g0, (hipStream_t)stream));
+    return MICLOC_OK;
+}
+
 int micloc_peak_location_i32(const int32_t *rate, int B, int G, int bands, int win_size, int32_t *index, void *stream)
 {
     if (!rate || !index || bad_batch(B) || G < 1 || bands < 1) return MICLOC_ERR_INVALID;

@@ -1,0 +1,193 @@
+// Beamforming vectors from membrane covariances, batched over the DoA grid: the decomposition step of
+// SNNBeamformer.design_from_template (reference micloc/snn_beamformer.py:176-203) and _find_dc_removed_sing_vec
+// (:372-422), which the reference hands to LAPACK (np.linalg.svd) once per DoA.
+//
+//   unipolar  (:183-186)  U, D = svd(C);  theta = U^T 1;  root of sum_i theta_i^2 / (D_i - u) on (D_1, D_0) by bisection
+//                         to rel_prec;  w = U (theta / (D - root)) / |.|                      -- independent of the signs of U
+//   bipolar   (:191-203)  C_comp = (C11 + C22)/2 + 1j (C12 + C21^T)/2;  U = svd(C_comp)[0];  w = [Re U[:,0]; Im U[:,0]]
+//
+// One wave per DoA.  The symmetric eigenproblem (n <= 32) is solved by cyclic Jacobi rotations with the matrix and the
+// accumulated rotations in LDS (lane k owns row k); the left singular vectors of the complex d x d matrix C_comp are the
+// eigenvectors of the Hermitian C_comp C_comp^H = P + jQ, obtained from its real embedding [[P, -Q], [Q, P]] (every
+// eigenvalue appears twice, the two eigenvectors [x; y], [-y; x] being u and j u).  A singular vector is defined up to a
+// unit phase and LAPACK's choice is an artefact of its bidiagonalisation; here the phase is fixed by making the
+// largest-magnitude component real and positive.  The beam pattern |W^H W| and the spectrum do not depend on it.
+#include "micloc_internal.h"
+
+namespace micloc {
+
+constexpr int DS_N = 32;        // largest matrix order
+constexpr int DS_LD = DS_N + 1; // padded row
+
+__device__ __forceinline__ void jacobi_eig(double (*A)[DS_LD], double (*V)[DS_LD], int n, int lane)
+{
+    // V = I
+    for (int j = 0; j < n; ++j)
+        if (lane < n) V[lane][j] = lane == j ? 1.0 : 0.0;
+    __syncthreads();
+    for (int sweep = 0; sweep < 40; ++sweep) {
+        // off-diagonal mass against the diagonal (every lane computes the same number: no broadcast needed)
+        double off = 0.0, dg = 0.0;
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j) {
+                const double a = A[i][j];
+                if (i == j)
+                    dg = __builtin_fma(a, a, dg);
+                else
+                    off = __builtin_fma(a, a, off);
+            }
+        if (off <= 1e-30 * dg || off == 0.0) break;
+        for (int p = 0; p < n - 1; ++p)
+            for (int q = p + 1; q < n; ++q) {
+                const double apq = A[p][q];
+                if (apq != 0.0) {  // uniform
+                    const double app = A[p][p], aqq = A[q][q];
+                    const double tau = (aqq - app) / (2.0 * apq);
+                    const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+                    const double c = 1.0 / sqrt(1.0 + t * t), s = t * c;
+                    __syncthreads();
+                    double akp = 0.0, akq = 0.0;
+                    if (lane < n) {
+                        akp = A[lane][p];
+                        akq = A[lane][q];
+                        const double vkp = V[lane][p], vkq = V[lane][q];
+                        V[lane][p] = c * vkp - s * vkq;
+                        V[lane][q] = s * vkp + c * vkq;
+                    }
+                    __syncthreads();
+                    if (lane < n && lane != p && lane != q) {
+                        const double nkp = c * akp - s * akq, nkq = s * akp + c * akq;
+                        A[lane][p] = nkp;
+                        A[p][lane] = nkp;
+                        A[lane][q] = nkq;
+                        A[q][lane] = nkq;
+                    }
+                    if (lane == 0) {
+                        A[p][p] = app - t * apq;
+                        A[q][q] = aqq + t * apq;
+                        A[p][q] = 0.0;
+                        A[q][p] = 0.0;
+                    }
+                    __syncthreads();
+                }
+            }
+    }
+    __syncthreads();
+}
+
+// cov [n_doa][C][C] (row-major, symmetric) -> column g0 + blockIdx.x of bf [C][G]
+__global__ __launch_bounds__(64) void design_vec_kernel(const double *__restrict__ cov, int C, int bipolar, double rel_prec,
+                                                         double *__restrict__ bf, int G, int g0)
+{
+    __shared__ double A[DS_N][DS_LD];
+    __shared__ double V[DS_N][DS_LD];
+    __shared__ double P[DS_N / 2][DS_LD], Q[DS_N / 2][DS_LD];
+    __shared__ double Dv[DS_N], th[DS_N];
+    __shared__ int order[DS_N];
+    const int lane = threadIdx.x;
+    const int n = C;
+    const double *Cm = cov + (size_t)blockIdx.x * C * C;
+    const int g = g0 + blockIdx.x;
+
+    if (!bipolar) {
+        for (int e = lane; e < n * n; e += 64) A[e / n][e % n] = 0.5 * (Cm[e] + Cm[(e % n) * n + e / n]);
+    } else {
+        const int d = C / 2;
+        // C_comp = Pa + j Qb  (:195-199)
+        for (int e = lane; e < d * d; e += 64) {
+            const int i = e / d, j = e % d;
+            P[i][j] = (Cm[(size_t)i * C + j] + Cm[(size_t)(d + i) * C + d + j]) / 2;
+            Q[i][j] = (Cm[(size_t)i * C + d + j] + Cm[(size_t)(d + j) * C + i]) / 2;
+        }
+        __syncthreads();
+        // H = C_comp C_comp^H = (Pa Pa^T + Qb Qb^T) + j (Qb Pa^T - Pa Qb^T); real embedding [[Re, -Im], [Im, Re]]
+        for (int e = lane; e < d * d; e += 64) {
+            const int i = e / d, j = e % d;
+            double re = 0.0, im = 0.0;
+            for (int k = 0; k < d; ++k) {
+                re += P[i][k] * P[j][k] + Q[i][k] * Q[j][k];
+                im += Q[i][k] * P[j][k] - P[i][k] * Q[j][k];
+            }
+            A[i][j] = re;
+            A[d + i][d + j] = re;
+            A[d + i][j] = im;
+            A[i][d + j] = -im;
+        }
+    }
+    __syncthreads();
+    jacobi_eig(A, V, n, lane);
+    if (lane < n) Dv[lane] = A[lane][lane];
+    __syncthreads();
+    // descending order of the eigenvalues (LAPACK's singular-value order); ties: lower index first
+    if (lane < n) {
+        int r = 0;
+        for (int j = 0; j < n; ++j) r += (Dv[j] > Dv[lane]) || (Dv[j] == Dv[lane] && j < lane);
+        order[r] = lane;
+    }
+    __syncthreads();
+
+    if (!bipolar) {
+        // theta = U^T 1 (:393), columns in descending-eigenvalue order
+        if (lane < n) {
+            const int col = order[lane];
+            double s = 0.0;
+            for (int k = 0; k < n; ++k) s += V[k][col];
+            th[lane] = s;
+        }
+        __syncthreads();
+        double u_min = Dv[order[1]], u_max = Dv[order[0]];
+        for (int it = 0; it < 200; ++it) {  // :399-411
+            if ((u_max - u_min) / u_min < rel_prec) break;
+            const double u_mid = (u_min + u_max) / 2;
+            double val = 0.0;
+            for (int i = 0; i < n; ++i) val += th[i] * th[i] / (Dv[order[i]] - u_mid);
+            if (val < 0.0)
+                u_min = u_mid;
+            else
+                u_max = u_mid;
+        }
+        const double root = (u_min + u_max) / 2.0;
+        double w = 0.0;
+        if (lane < n)
+            for (int i = 0; i < n; ++i) w += V[lane][order[i]] * (th[i] / (Dv[order[i]] - root));  // :417
+        __syncthreads();
+        if (lane < n) th[lane] = w;
+        __syncthreads();
+        double nrm = 0.0;
+        for (int i = 0; i < n; ++i) nrm += th[i] * th[i];
+        nrm = sqrt(nrm);
+        if (lane < n) bf[(size_t)lane * G + g] = w / nrm;
+    } else {
+        const int d = C / 2;
+        const int col = order[0];
+        // u = x + j y with [x; y] the top eigenvector; rotate so that the largest component is real and positive
+        int kmax = 0;
+        double best = -1.0;
+        for (int k = 0; k < d; ++k) {
+            const double m2 = V[k][col] * V[k][col] + V[d + k][col] * V[d + k][col];
+            if (m2 > best) {
+                best = m2;
+                kmax = k;
+            }
+        }
+        const double mag = sqrt(best);
+        const double cr = V[kmax][col] / mag, ci = -V[d + kmax][col] / mag;  // conj(u_k) / |u_k|
+        double nrm = 0.0;
+        for (int k = 0; k < n; ++k) nrm += V[k][col] * V[k][col];
+        nrm = sqrt(nrm);
+        if (lane < d) {
+            const double x = V[lane][col] / nrm, y = V[d + lane][col] / nrm;
+            bf[(size_t)lane * G + g] = x * cr - y * ci;
+            bf[(size_t)(d + lane) * G + g] = x * ci + y * cr;
+        }
+    }
+}
+
+hipError_t launch_design_vec(const double *cov, int n_doa, int C, int bipolar, double rel_prec, double *bf, int G, int g0,
+                             hipStream_t stream)
+{
+    hipLaunchKernelGGL(design_vec_kernel, dim3(n_doa), dim3(64), 0, stream, cov, C, bipolar, rel_prec, bf, G, g0);
+    return hipGetLastError();
+}
+
+}  // namespace micloc

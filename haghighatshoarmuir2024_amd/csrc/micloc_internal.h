@@ -130,6 +130,8 @@ hipError_t launch_awgn(double *x, int B, size_t n, const double *snr_db, const d
 hipError_t launch_doa_error(const int32_t *argmax, const double *doa_list, int G, const double *doa_true, int B, int groups,
                             double *err, double *mae, hipStream_t stream);
 
+hipError_t launch_design_vec(const double *cov, int n_doa, int C, int bipolar, double rel_prec, double *bf, int G, int g0,
+                             hipStream_t stream);
 hipError_t launch_peak_location(const int32_t *rate, int B, int G, int F, int win, int32_t *index, hipStream_t stream);
 
 }  // namespace micloc

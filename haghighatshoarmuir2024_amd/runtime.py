@@ -499,6 +499,14 @@ def awgn_(x, snr_db=None, sigma=None, seed=0, substream=0, first_trial=0, ws=Non
     return x
 
 
+def design_vectors(cov, bipolar, bf_mat, g0, rel_prec=1e-8):
+    """micloc_design_vectors_f64: cov [n, C, C] device tensor -> columns g0 .. g0 + n of the device tensor bf_mat [C, G]."""
+    n, C, _ = cov.shape
+    _lib.check(_lib.load().micloc_design_vectors_f64(_ptr(cov), n, C, int(bool(bipolar)), float(rel_prec), _ptr(bf_mat), bf_mat.shape[1], int(g0),
+                                                     _stream(cov.device)), "design_vectors")
+    return bf_mat
+
+
 def peak_location(counts, G, win_size, out=None):
     """micloc_peak_location_i32: counts int32 [B, bands * G] -> index int32 [B] (find_peak_location of the per-DoA counts)."""
     torch = _torch()

@@ -189,7 +189,16 @@ class SNNBeamformer:
         plan.set_bf_mat(np.eye(2 * M))
         return plan.snn_pipeline(plan.to_device(sig_batch), want_y=True, want_power=False)["y"]
 
-    def design_from_template(self, template, doa_list, doa_batch=32):
+    def design_from_template(self, template, doa_list, doa_batch=32, svd="host", device_synthesis=None):
+        """Reference :82-211.  The per-DoA chain (delayed template -> STHT -> band-pass -> RZCC -> LIF -> covariance of the
+        last 3/4) runs on the device for `doa_batch` DoAs at a time.  svd="host": the 2M x 2M decompositions by LAPACK like
+        the reference (same singular-vector phases: bf_mat equals the reference's fixture); svd="device": one batched
+        Jacobi kernel (micloc_design_vectors_f64; columns agree up to the arbitrary unit phase, unipolar ones exactly), with
+        the delayed templates synthesised on the device as well -- nothing but the template and bf_mat crosses PCIe."""
+        if svd not in ("host", "device"):
+            raise ValueError("svd must be 'host' or 'device'")
+        if device_synthesis is None:
+            device_synthesis = svd == "device"
         try:
             time_temp, sig_temp = template
         except Exception:
@@ -201,15 +210,29 @@ class SNNBeamformer:
         doa_list = np.asarray(doa_list, dtype=np.float64)
 
         bf_mat = []
+        bf_dev = None
+        if svd == "device":
+            import torch
+
+            if 2 * len(self.geometry) > 32:
+                raise ValueError("svd='device' supports up to 16 microphones")
+            bf_dev = torch.empty((2 * len(self.geometry), len(doa_list)), dtype=torch.float64, device=runtime.require_gpu(self.device))
         for start in range(0, len(doa_list), doa_batch):
             doas = doa_list[start : start + doa_batch]
             # delayed, clamped copies of the template, one trial per DoA (reference :141-154)
             delays = self.geometry.delays(doas, normalized=True)  # [n, M]
             delays = delays - delays.min(axis=1, keepdims=True)
-            time_delayed = time_temp.reshape(1, 1, -1) - delays[:, :, None]  # [n, M, T]
-            np.maximum(time_delayed, time_temp.min(), out=time_delayed)
-            sig = np.interp(time_delayed.ravel(), time_temp, sig_temp).reshape(time_delayed.shape)
-            sig = np.ascontiguousarray(np.transpose(sig, (0, 2, 1)))  # [n, T, M]
+            if device_synthesis:
+                sig = runtime.synth_delay(time_temp, sig_temp, delays, self.fs, device=self.device)  # [n, T, M], == np.interp bit for bit
+            else:
+                time_delayed = time_temp.reshape(1, 1, -1) - delays[:, :, None]  # [n, M, T]
+                np.maximum(time_delayed, time_temp.min(), out=time_delayed)
+                sig = np.interp(time_delayed.ravel(), time_temp, sig_temp).reshape(time_delayed.shape)
+                sig = np.ascontiguousarray(np.transpose(sig, (0, 2, 1)))  # [n, T, M]
+            if svd == "device":
+                cov_d = self.membrane_covariance_batch(sig, time_vec=time_temp, t_start=sig.shape[1] // 4)
+                runtime.design_vectors(cov_d, self.spk_encoder.bipolar, bf_dev, start, rel_prec=0.00000001)
+                continue
             if sig.shape[2] * 2 <= 64:
                 # membrane covariance over the last 3/4 on the device (MFMA Gram kernel)
                 cov = self.membrane_covariance_batch(sig, time_vec=time_temp, t_start=sig.shape[1] // 4).cpu().numpy()
@@ -226,6 +249,8 @@ class SNNBeamformer:
                     C_comp = (C[:d, :d] + C[d:, d:]) / 2 + 1j * ((C[:d, d:] + C[d:, :d].T) / 2)
                     U, _, _ = np.linalg.svd(C_comp)
                     bf_mat.append(np.concatenate([np.real(U[:, 0]), np.imag(U[:, 0])]))
+        if svd == "device":
+            return bf_dev.cpu().numpy()
         return np.asarray(bf_mat).T
 
     def _find_dc_removed_sing_vec(self, C, rel_prec=0.0001):

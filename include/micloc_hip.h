@@ -172,6 +172,18 @@ int micloc_lif_covariance_f64(const micloc_plan *plan, const int8_t *spikes, int
 int micloc_snn_pipeline_cov_f64(const micloc_plan *plan, const double *x, int B, int T, int t_start, int8_t *spikes,
                                 double *cov, double *power, int32_t *argmax, void *ws, size_t ws_bytes, void *stream);
 
+/* ---- beamforming vectors from membrane covariances (design_from_template's decomposition step) ------ */
+/* Replaces the per-DoA np.linalg.svd calls of SNNBeamformer.design_from_template (snn_beamformer.py:183-203) and
+ * _find_dc_removed_sing_vec (:372-422) by one batched kernel: column g0 + i of bf_mat [C][G] from cov[i] [C][C]
+ * (micloc_lif_covariance_f64's output).  bipolar = 0: the DC-removed conditional singular vector (secular equation solved by
+ * the reference's bisection to rel_prec; the result does not depend on the signs of the singular vectors).  bipolar = 1: the
+ * leading left singular vector of the folded complex covariance, stacked [Re; Im]; its unit phase -- arbitrary by
+ * definition, LAPACK's being an artefact of its bidiagonalisation -- is fixed by making the largest component real and
+ * positive, so columns agree with the reference's up to that phase and |W^H W| agrees.  Cyclic Jacobi in LDS, C <= 32.
+ * Device buffers. */
+int micloc_design_vectors_f64(const double *cov, int n_doa, int C, int bipolar, double rel_prec, double *bf_mat, int G, int g0,
+                              void *stream);
+
 /* ---- array-signal synthesis ------------------------------------------------------------------- */
 /* Noise-free part of SNNBeamformer.apply_to_template for a constant DoA per trial (snn_beamformer.py:246-267):
  * x[b][t][m] = np.interp(max(time[t] - delays[b][m], time[0]), time, sig), bit-exact with NumPy.  All pointers are

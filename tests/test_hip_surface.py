@@ -234,6 +234,54 @@ def test_full_design_bipolar_449_and_config1_unipolar_225(cfg2):
         np.testing.assert_allclose(np.abs(Wu.T @ Wu), np.abs(ref.T @ ref), rtol=0, atol=1e-6)
 
 
+def test_full_design_on_device_jacobi(cfg2):
+    """design_from_template(svd="device"): delayed templates, chain, covariance AND the decompositions on the device (batched
+    Jacobi kernel + secular bisection, micloc_design_vectors_f64) for the complete grids of configs 2 and 1.  Bipolar columns
+    agree with the reference's up to the (arbitrary) unit phase of U[:, 0] and in the beam pattern; unipolar columns directly."""
+    from micloc.array_geometry import CenterCircularArray
+    from micloc.snn_beamformer import SNNBeamformer
+
+    z = golden("bf_mat_chirp449_bipolar.npz")
+    bf = make_beamformer()
+    fs = 48_000
+    time_temp = np.arange(0, 1.0, step=1 / fs)
+    period = time_temp[-1]
+    sig_temp = np.sin(2 * np.pi * np.cumsum(1000 + 1000 * (time_temp % period) / period) / fs)
+    W = bf.design_from_template((time_temp, sig_temp), z["doa_list"], svd="device")
+    assert W.shape == (14, 449)
+    np.testing.assert_allclose(np.linalg.norm(W, axis=0), 1.0, rtol=0, atol=1e-12)
+    Wc, Rc = W[:7] + 1j * W[7:], z["bf_mat"][:7] + 1j * z["bf_mat"][7:]
+    phase = np.sum(np.conj(Wc) * Rc, axis=0)
+    np.testing.assert_allclose(np.abs(phase), 1.0, rtol=0, atol=1e-8)
+    np.testing.assert_allclose(Wc * (phase / np.abs(phase)), Rc, rtol=0, atol=1e-8)
+    # phase convention of the kernel: the largest component of every column is real and positive
+    k = np.argmax(np.abs(Wc), axis=0)
+    top = Wc[k, np.arange(449)]
+    assert np.all(top.real > 0) and np.max(np.abs(top.imag)) < 1e-12
+    # what the scripts plot does not depend on the phase: complex beam pattern |W^H W|
+    np.testing.assert_allclose(np.abs(Wc.conj().T @ Wc), np.abs(Rc.conj().T @ Rc), rtol=0, atol=1e-7)
+    # host-SVD and device-SVD designs localise the golden trials identically
+    zt = golden("trials_cfg2.npz")
+    out_h = bf.localize_batch(z["bf_mat"], zt["sig_in"])
+    out_d = bf.localize_batch(W, zt["sig_in"])
+    ph, pd = out_h["power"].cpu().numpy(), out_d["power"].cpu().numpy()
+    assert np.max(np.abs(np.argmax(ph, axis=1) - np.argmax(pd, axis=1))) <= 3  # (the real projection depends on the phase: neighbours)
+
+    zu = golden("bf_mat_sin225_unipolar.npz")
+    for f in (1000, 2000, 4000):
+        tau = 1 / (2 * np.pi * f)
+        bfu = SNNBeamformer(CenterCircularArray(4.5e-2, 7), 10e-3, [0.5 * f, 2 * f], np.asarray([tau, tau]), bipolar_spikes=False, fs=fs)
+        t = np.arange(0, 0.4, step=1 / fs)
+        Wu = bfu.design_from_template((t, np.sin(2 * np.pi * f * t)), zu["doa_list"], svd="device")
+        ref = zu[f"bf_mat_f{f}"]
+        sgn = np.sign(np.sum(Wu * ref, axis=0))
+        assert np.all(sgn > 0)  # the conditional singular vector has no sign freedom
+        np.testing.assert_allclose(Wu, ref, rtol=0, atol=2e-7)
+        np.testing.assert_allclose(np.abs(Wu.T @ Wu), np.abs(ref.T @ ref), rtol=0, atol=1e-6)
+    with pytest.raises(ValueError):
+        bf.design_from_template((time_temp, sig_temp), z["doa_list"][:2], svd="gpu")
+
+
 def test_live_demo_frame_processing(cfg2):
     """localization_demo_snn.Demo.process_frame == filterbank -> apply_to_signal per band -> summed power -> arg-max,
     checked against the oracle composition; weak packs give NaN (reference :153-159)."""
