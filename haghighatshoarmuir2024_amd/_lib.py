@@ -96,6 +96,11 @@ SYMBOLS = {
                                     c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "micloc_xylo_upload": (c_int, [c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "micloc_xylo_lif_resident_i16": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "micloc_lif_beamform_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),
+    "micloc_stream_state_bytes": (c_size_t, [c_void_p, c_int]),
+    "micloc_stream_encode_f64": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, ctypes.c_longlong, c_int, c_int, c_void_p, c_int, c_void_p, c_size_t,
+                                         c_void_p]),
+    "micloc_stream_overflow": (c_int, [c_void_p, ctypes.POINTER(c_int), c_void_p]),
     "micloc_design_vectors_f64": (c_int, [c_void_p, c_int, c_int, c_int, ctypes.c_double, c_void_p, c_int, c_int, c_void_p]),
     "micloc_peak_location_i32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "micloc_abi_version": (c_int, []),

@@ -334,6 +334,12 @@ size_t micloc_workspace_bytes(const micloc_plan *p, int B, int T)
     return ws_layout(p, B, T).total;
 }
 
+size_t micloc_lif_beamform_workspace_bytes(const micloc_plan *p, int B, int T)
+{
+    if (!p || bad_batch(B) || T < 1 || p->W.GT < 1) return 0;
+    return align256(beamform_partial_bytes(B, T, 16 * p->W.GT));
+}
+
 // ---- stages ----------------------------------------------------------------------------------------------
 int micloc_stht_f64(const micloc_plan *p, const double *x, int B, int T, double *h, int Ts, void *stream)
 {
@@ -456,6 +462,36 @@ int micloc_beamformer_pipeline_f64(const micloc_plan *p, const double *x, int B,
     HIP_TRY(launch_planar_beamform(p->W, pre, B, T, Ts, y, 1, partial, st));
     if (want_power)
         HIP_TRY(launch_power_argmax(partial, B, T, beamform_nchunks_ct(T, p->W.CT), Gp, p->G_out, 1, Gp / 2, power, argmax, st));
+    return MICLOC_OK;
+}
+
+// ---- streaming: the band-pass / RZCC stage tile by tile, exact state hand-off -----------------------------------
+size_t micloc_stream_state_bytes(const micloc_plan *p, int B)
+{
+    if (!p || bad_batch(B)) return 0;
+    return rzcc_stream_state_bytes(B * p->C);
+}
+
+int micloc_stream_encode_f64(const micloc_plan *p, const double *h, int B, int T_tile, int row_stride, long long t_base, int first_tile,
+                             int final_tile, int8_t *spikes, int T_total, void *state, size_t state_bytes, void *stream)
+{
+    if (!p || !h || !spikes || bad_batch(B) || T_tile < 1 || T_total < 1 || t_base < 0 || row_stride < T_tile) return MICLOC_ERR_INVALID;
+    DeviceGuard guard(p->device);
+    if (t_base % 16 != 0 || (!final_tile && T_tile % 16 != 0) || t_base + T_tile > T_total || (first_tile && t_base != 0))
+        return MICLOC_ERR_SHAPE;
+    if (bad_ws(state, state_bytes, rzcc_stream_state_bytes(B * p->C))) return MICLOC_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    if (first_tile) HIP_TRY(launch_zero_fill(spikes, (size_t)B * T_total * p->C, st));
+    HIP_TRY(launch_stream_encode(p->iir, h, B * p->C, p->C, T_tile, row_stride, p->robust_width, p->bipolar, spikes, T_total, t_base,
+                                 first_tile, final_tile, state, st));
+    return MICLOC_OK;
+}
+
+int micloc_stream_overflow(const void *state, int *count, void *stream)
+{
+    if (!state || !count) return MICLOC_ERR_INVALID;
+    HIP_TRY(hipMemcpyAsync(count, state, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     return MICLOC_OK;
 }
 

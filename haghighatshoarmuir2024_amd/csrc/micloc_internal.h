@@ -41,6 +41,12 @@ hipError_t launch_bandpass_rzcc(const IirCoef &coef, const double *h, int nlanes
                                 int robust_width, int bipolar, double *pre, int8_t *spikes, void *scratch,
                                 hipStream_t stream, const double *xin = nullptr, int M = 0, int shift = 0,
                                 int chunk_frames = 0);
+// streaming: one tile per launch, exact state hand-off (rzcc.hip "streaming")
+size_t rzcc_stream_state_bytes(int nlanes);
+hipError_t launch_stream_encode(const IirCoef &coef, const double *h, int nlanes, int C, int T, int Ts, int robust_width,
+                                int bipolar, int8_t *spikes, int Ttot, long long t_base, int first_tile, int final_tile,
+                                void *state, hipStream_t stream);
+hipError_t launch_zero_fill(void *ptr, size_t bytes, hipStream_t stream);
 // row-major [B][T][C] <-> planar [B][C][Ts]
 hipError_t launch_pack_planar(const double *src, double *dst, int B, int T, int C, int Ts, hipStream_t stream);
 hipError_t launch_unpack_planar(const double *src, double *dst, int B, int T, int C, int Ts, hipStream_t stream);

@@ -602,6 +602,29 @@ __global__ __launch_bounds__(192) void rzcc_scan_kernel(const double *__restrict
 // Each stage is a different wave of the workgroup, i.e. a different SIMD of the CU, so the serial chain of
 // one stream costs max(stage) instructions per time step instead of their sum.
 // ---------------------------------------------------------------------------------------------------
+// ---- streaming (tile by tile over launches) ---------------------------------------------------------------------
+// The single-pass form of the kernel is a sequential machine per stream; at the end of a launch every stage has drained
+// (the pipeline skew is inside the launch), so its complete state is small and well defined: DF2T state, running sum,
+// the detector's previous value / last strict change / direction, the candidate ring with the open clusters, and the
+// select waves' cursors.  Dumped at the end of one launch and reloaded at the start of the next, the stream continues
+// with the very same operations -- exact hand-off by construction (reference semantics: the recording is ONE stream,
+// micloc/spike_encoder.py:115-137; the reference's live demo, localization_demo_snn.py:125-193, restarts every 0.25 s
+// frame instead).  Positions are absolute (t_base = frames consumed so far, a multiple of RZ_MT), spikes are scattered
+// into the full-length raster, clusters still open at the end of a tile are emitted by a later launch.  A stream whose
+// candidate ring overflows cannot be redone from its start here (the history is gone): it is counted in `overflow`.
+struct RzStream {
+    double *sd;      // [nblk][N + 1][64]: z_0..z_{N-2}, running sum, detector's previous value
+    int *si;         // [nblk][12][64]: left (absolute), n, flag bits, 2 x (i_next, s_open, l_last, dead), first polarity
+    double *ringV;   // [nblk][RZ_RING][64]
+    int *ringP;      // [nblk][RZ_RING][64]
+    int *overflow;   // number of streams lost to a ring overflow
+    int resume;      // load the state (not the first tile)
+    int final_;      // the stream ends with this tile: close the open clusters
+    int t_base;      // absolute time of this launch's first frame
+    int Ttot;        // frames per trial of the spike raster (row stride of the scatter)
+    int on;
+};
+
 template <int N, bool WANT_PRE, bool WANT_SPIKES>
 __global__ __launch_bounds__(320) void bandpass_rzcc_fast_kernel(const double *__restrict__ h,
                                                                   double *__restrict__ pre,
@@ -611,7 +634,7 @@ __global__ __launch_bounds__(320) void bandpass_rzcc_fast_kernel(const double *_
                                                                   int nlanes, int C, int T, int Ts, int w, int bipolar,
                                                                   const double *__restrict__ xin, int M, int shift,
                                                                   RzGeom g, int nblk, const double *__restrict__ ckd,
-                                                                  const int *__restrict__ cki)
+                                                                  const int *__restrict__ cki, RzStream ss)
 {
     __shared__ __attribute__((aligned(16))) double X[3][RZ_MT][RZ_ROW];
     __shared__ double Y[WANT_PRE ? 2 : 1][WANT_PRE ? RZ_MT : 1][WANT_PRE ? RZ_ROW : 1];
@@ -654,6 +677,12 @@ __global__ __launch_bounds__(320) void bandpass_rzcc_fast_kernel(const double *_
             for (int i = 0; i < N - 1; ++i) iir.z[i] = ckd[((size_t)(p - 1) * N + i) * nl + lane_c];
             cs = ckd[((size_t)(p - 1) * N + (N - 1)) * nl + lane_c];
         }
+        double *const sdb = ss.on ? ss.sd + (size_t)blk * (N + 1) * 64 : nullptr;
+        if (ss.on && ss.resume) {
+#pragma unroll
+            for (int i = 0; i < N - 1; ++i) iir.z[i] = sdb[i * 64 + lane];
+            cs = sdb[(N - 1) * 64 + lane];
+        }
         pin_coef<N>(coef);
         __syncthreads();
         for (int k = 0; k < NSTEP; ++k) {
@@ -678,10 +707,17 @@ __global__ __launch_bounds__(320) void bandpass_rzcc_fast_kernel(const double *_
             }
             __syncthreads();
         }
+        if (ss.on) {
+#pragma unroll
+            for (int i = 0; i < N - 1; ++i) sdb[i * 64 + lane] = iir.z[i];
+            sdb[(N - 1) * 64 + lane] = cs;
+        }
         return;
     }
 
     if (!WANT_SPIKES) return;  // (band-pass-only launches have just the two waves above)
+    int *const sib = ss.on ? ss.si + (size_t)blk * 12 * 64 : nullptr;
+    const int tb0 = ss.on ? ss.t_base : 0;  // absolute time of local frame 0
 
     if (wave == 2) {
         // ------------------------------------ detect ---------------------------------------------------
@@ -708,13 +744,34 @@ __global__ __launch_bounds__(320) void bandpass_rzcc_fast_kernel(const double *_
         const uint64_t bip = bipolar ? ~0ull : 0ull;
         nPub[lane] = 0;
         polPub[lane] = 0;
+        if (ss.on && ss.resume) {
+            double *const sdb = ss.sd + (size_t)blk * (N + 1) * 64;
+            d.prev = sdb[N * 64 + lane];
+            d.lrel = sib[0 * 64 + lane] - tb0;  // relative to the first tile of this launch
+            d.n = sib[1 * 64 + lane];
+            const int bits = sib[2 * 64 + lane];
+            d.dpos = __ballot(bits & 1);
+            d.dneg = __ballot(bits & 2);
+            d.ffall = __ballot(bits & 4);
+            live = __ballot(bits & 8);
+            nPub[lane] = d.n;
+            polPub[lane] = (bits >> 2) & 1;
+            // the candidate ring with the clusters that were still open
+            const double *rv = ss.ringV + (size_t)blk * RZ_RING * 64;
+            const int *rp = ss.ringP + (size_t)blk * RZ_RING * 64;
+            for (int e = 0; e < RZ_RING; ++e) {
+                ringV[e][lane] = rv[e * 64 + lane];
+                ringP[e][lane] = rp[e * 64 + lane];
+            }
+        }
         ovPub[lane] = (int)((~live >> lane) & 1);
         __syncthreads();
         for (int k = 0; k < NSTEP; ++k) {
             if (k >= 1 && k <= NM) {
                 const int m = k - 1;
-                const int tbase = (m_lo + m) * RZ_MT;
-                const int steps = (T - tbase) < RZ_MT ? (T - tbase) : RZ_MT;
+                const int tloc = (m_lo + m) * RZ_MT;  // local time of the tile: input indexing and the ragged end
+                const int tbase = tloc + tb0;         // absolute time: candidate positions
+                const int steps = (T - tloc) < RZ_MT ? (T - tloc) : RZ_MT;
                 // Ring space for a whole tile of appends?  oldPub lags by one barrier and only grows: conservative.
                 {
                     const int o0 = oldPub[0][lane], o1 = oldPub[1][lane];
@@ -749,6 +806,14 @@ __global__ __launch_bounds__(320) void bandpass_rzcc_fast_kernel(const double *_
                     const bool hasdir = ((d.dpos | d.dneg) >> lane) & 1;
                     leftPub[lane] = hasdir ? d.lrel + tbase : tbase + RZ_MT + 1;
                 }
+                if (k == NM && ss.on) {
+                    double *const sdb = ss.sd + (size_t)blk * (N + 1) * 64;
+                    sdb[N * 64 + lane] = d.prev;
+                    sib[0 * 64 + lane] = d.lrel + tbase;  // absolute time of the last strict change
+                    sib[1 * 64 + lane] = d.n;
+                    sib[2 * 64 + lane] = (int)((d.dpos >> lane) & 1) | ((int)((d.dneg >> lane) & 1) << 1) | ((int)((d.ffall >> lane) & 1) << 2) |
+                                         ((int)((live >> lane) & 1) << 3);
+                }
                 d.lrel -= RZ_MT;
                 nPub[lane] = d.n;
                 polPub[lane] = (int)((d.ffall >> lane) & 1);
@@ -768,9 +833,10 @@ __global__ __launch_bounds__(320) void bandpass_rzcc_fast_kernel(const double *_
     int s_open = -1;      // first list index of the open cluster (-1: none)
     int l_last = 0;       // position of the last own candidate
     bool dead = !active;  // ring overflow (or lane out of range): stop selecting; redone by the fallback kernel
+    bool was_dead = false;  // (streaming: already lost in an earlier tile)
     const int b = lane_c / C;
     const int ch = lane_c - b * C;
-    int8_t *sp = spikes + (size_t)b * T * C + ch;
+    int8_t *sp = spikes + (size_t)b * (ss.on ? ss.Ttot : T) * C + ch;
     const int8_t mark = mypol ? -1 : 1;
     const double sgn = mypol ? -1.0 : 1.0;
     const int own_lo = sp_.own_lo, own_hi = sp_.own_hi;
@@ -786,6 +852,14 @@ __global__ __launch_bounds__(320) void bandpass_rzcc_fast_kernel(const double *_
     };
     if (mypol == 0) deadPub[lane] = 0;
     oldPub[mypol][lane] = 0;
+    if (ss.on && ss.resume && mine) {
+        i_next = sib[(3 + 4 * mypol) * 64 + lane];
+        s_open = sib[(4 + 4 * mypol) * 64 + lane];
+        l_last = sib[(5 + 4 * mypol) * 64 + lane];
+        was_dead = sib[(6 + 4 * mypol) * 64 + lane] != 0;
+        dead = dead || was_dead;
+        oldPub[mypol][lane] = dead ? 0x7fffffff : (s_open >= 0 ? s_open : (i_next >= 0 ? i_next : 0));
+    }
     if (!mine) oldPub[mypol][lane] = 0x7fffffff;
     __syncthreads();
     for (int k = 0; k < NSTEP; ++k) {
@@ -810,6 +884,29 @@ __global__ __launch_bounds__(320) void bandpass_rzcc_fast_kernel(const double *_
             oldPub[mypol][lane] = dead ? 0x7fffffff : (s_open >= 0 ? s_open : (i_next >= 0 ? i_next : 0));
         }
         __syncthreads();
+    }
+    if (ss.on) {
+        if (ovPub[lane]) dead = true;
+        if (mine) {
+            sib[(3 + 4 * mypol) * 64 + lane] = i_next;
+            sib[(4 + 4 * mypol) * 64 + lane] = s_open;
+            sib[(5 + 4 * mypol) * 64 + lane] = l_last;
+            sib[(6 + 4 * mypol) * 64 + lane] = dead ? 1 : 0;
+        }
+        // a stream that lost its ring cannot be redone from its start (the history is gone): count it once
+        if (active && mine && dead && !was_dead && atomicExch(&deadPub[lane], 1) == 0) atomicAdd(ss.overflow, 1);
+        __syncthreads();  // (both select waves: the ring is final)
+        if (mypol == 0) {
+            double *rv = ss.ringV + (size_t)blk * RZ_RING * 64;
+            int *rp = ss.ringP + (size_t)blk * RZ_RING * 64;
+            for (int e = 0; e < RZ_RING; ++e) {
+                rv[e * 64 + lane] = ringV[e][lane];
+                rp[e * 64 + lane] = ringP[e][lane];
+            }
+        }
+        if (!ss.final_) return;
+        if (active && mine && !dead && s_open >= 0) close_cluster(s_open, nPub[lane], l_last);  // end of the stream
+        return;
     }
     if (active && mine) {
         if (ovPub[lane]) dead = true;
@@ -1104,13 +1201,13 @@ static void launch_rz(const IirCoef &coef, const double *h, int nlanes, int C, i
     dim3 grid(nblk * g.P), block(spikes ? 320 : 128);
     if (pre && spikes)
         hipLaunchKernelGGL((bandpass_rzcc_fast_kernel<N, true, true>), grid, block, 0, stream, h, pre, spikes,
-                           flag_count, flag_list, coef, nlanes, C, T, Ts, w, bipolar, xin, M, shift, g, nblk, ckd, cki);
+                           flag_count, flag_list, coef, nlanes, C, T, Ts, w, bipolar, xin, M, shift, g, nblk, ckd, cki, RzStream{});
     else if (spikes)
         hipLaunchKernelGGL((bandpass_rzcc_fast_kernel<N, false, true>), grid, block, 0, stream, h, pre, spikes,
-                           flag_count, flag_list, coef, nlanes, C, T, Ts, w, bipolar, xin, M, shift, g, nblk, ckd, cki);
+                           flag_count, flag_list, coef, nlanes, C, T, Ts, w, bipolar, xin, M, shift, g, nblk, ckd, cki, RzStream{});
     else
         hipLaunchKernelGGL((bandpass_rzcc_fast_kernel<N, true, false>), grid, block, 0, stream, h, pre, spikes,
-                           flag_count, flag_list, coef, nlanes, C, T, Ts, w, bipolar, xin, M, shift, g, nblk, ckd, cki);
+                           flag_count, flag_list, coef, nlanes, C, T, Ts, w, bipolar, xin, M, shift, g, nblk, ckd, cki, RzStream{});
     if (spikes)
         hipLaunchKernelGGL((rzcc_unit_fallback_kernel<N>), dim3((sc.nslots + 63) / 64), dim3(64), 0, stream, h, spikes,
                            flag_count, flag_list, reinterpret_cast<int *>(scratch + sc.plist),
@@ -1154,6 +1251,82 @@ hipError_t launch_bandpass_rzcc(const IirCoef &coef, const double *h, int nlanes
 #undef RZ_CASE
     return hipGetLastError();
 }
+
+// ---- streaming launcher ---------------------------------------------------------------------------------------------
+// state buffer: [256 B header: overflow count] [sd] [si] [ringV] [ringP]
+size_t rzcc_stream_state_bytes(int nlanes)
+{
+    const size_t nblk = (nlanes + 63) / 64;
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    return 256 + al(nblk * (MICLOC_MAX_IIR + 1) * 64 * sizeof(double)) + al(nblk * 12 * 64 * sizeof(int)) +
+           al(nblk * RZ_RING * 64 * sizeof(double)) + al(nblk * RZ_RING * 64 * sizeof(int));
+}
+
+template <int N>
+static void launch_rz_stream(const IirCoef &coef, const double *h, int nlanes, int C, int T, int Ts, int w, int bipolar,
+                             int8_t *spikes, const RzStream &ss, hipStream_t stream)
+{
+    const int nblk = (nlanes + 63) / 64;
+    RzGeom g;
+    g.P = 1;
+    g.Lt = (T + RZ_MT - 1) / RZ_MT;
+    g.Vt = 1;
+    g.V2t = 4;
+    hipLaunchKernelGGL((bandpass_rzcc_fast_kernel<N, false, true>), dim3(nblk), dim3(320), 0, stream, h, nullptr, spikes, nullptr, nullptr,
+                       coef, nlanes, C, T, Ts, w, bipolar, nullptr, 0, 0, g, nblk, nullptr, nullptr, ss);
+}
+
+// One tile of every stream: h [nlanes][Ts] planar (local time), T frames (a multiple of RZ_MT unless `final_tile`), absolute
+// start t_base; spikes = the full-length raster [B][Ttot][C] (zeroed by the caller before the first tile).
+hipError_t launch_stream_encode(const IirCoef &coef, const double *h, int nlanes, int C, int T, int Ts, int robust_width,
+                                int bipolar, int8_t *spikes, int Ttot, long long t_base, int first_tile, int final_tile,
+                                void *state, hipStream_t stream)
+{
+    if (t_base % RZ_MT != 0 || (!final_tile && T % RZ_MT != 0) || t_base + T > Ttot) return hipErrorInvalidValue;
+    const size_t nblk = (nlanes + 63) / 64;
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    unsigned char *base = reinterpret_cast<unsigned char *>(state);
+    RzStream ss{};
+    ss.overflow = reinterpret_cast<int *>(base);
+    size_t off = 256;
+    ss.sd = reinterpret_cast<double *>(base + off);
+    off += al(nblk * (MICLOC_MAX_IIR + 1) * 64 * sizeof(double));
+    ss.si = reinterpret_cast<int *>(base + off);
+    off += al(nblk * 12 * 64 * sizeof(int));
+    ss.ringV = reinterpret_cast<double *>(base + off);
+    off += al(nblk * RZ_RING * 64 * sizeof(double));
+    ss.ringP = reinterpret_cast<int *>(base + off);
+    ss.resume = first_tile ? 0 : 1;
+    ss.final_ = final_tile ? 1 : 0;
+    ss.t_base = (int)t_base;
+    ss.Ttot = Ttot;
+    ss.on = 1;
+    if (first_tile) {
+        hipError_t e = zero_fill(base, 256, stream);
+        if (e != hipSuccess) return e;
+    }
+#define RZ_CASE(NN)                                                                                          \
+    case NN:                                                                                                 \
+        launch_rz_stream<NN>(coef, h, nlanes, C, T, Ts, robust_width, bipolar, spikes, ss, stream);          \
+        break;
+    switch (coef.n) {
+        RZ_CASE(1)
+        RZ_CASE(2)
+        RZ_CASE(3)
+        RZ_CASE(4)
+        RZ_CASE(5)
+        RZ_CASE(6)
+        RZ_CASE(7)
+        RZ_CASE(8)
+        RZ_CASE(9)
+        default:
+            return hipErrorInvalidValue;
+    }
+#undef RZ_CASE
+    return hipGetLastError();
+}
+
+hipError_t launch_zero_fill(void *ptr, size_t bytes, hipStream_t stream) { return zero_fill(ptr, bytes, stream); }
 
 // ---- row-major [B][T][C] <-> planar [B][C][Ts] (LDS tile transpose, both sides coalesced) ----------
 __global__ __launch_bounds__(256) void pack_planar_kernel(const double *__restrict__ src, double *__restrict__ dst,

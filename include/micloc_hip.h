@@ -172,6 +172,25 @@ int micloc_lif_covariance_f64(const micloc_plan *plan, const int8_t *spikes, int
 int micloc_snn_pipeline_cov_f64(const micloc_plan *plan, const double *x, int B, int T, int t_start, int8_t *spikes,
                                 double *cov, double *power, int32_t *argmax, void *ws, size_t ws_bytes, void *stream);
 
+/* ---- streaming: a recording delivered tile by tile ------------------------------------------------- */
+/* The band-pass / RZCC stage as a resumable machine: micloc_stream_encode_f64 consumes T_tile frames of every stream
+ * (h: planar [B][2M][row_stride] STHT output of the tile, local time) starting at absolute frame t_base and scatters the
+ * spikes of every cluster that CLOSED into the full-length raster spikes [B][T_total][2M] (zeroed by the first_tile call);
+ * DF2T state, running sum, detector state, candidate ring (open clusters) and selection cursors live in `state`
+ * (micloc_stream_state_bytes, 256-B aligned) between calls, so that the tiles together perform exactly the operations of
+ * one micloc_bandpass_rzcc_f64 launch over the whole recording -- bit-identical spikes for any tiling.  Reference: the
+ * encoder treats a recording as ONE stream (snn_beamformer.py:330-338, spike_encoder.py:115-137); its live demo
+ * (localization_demo_snn.py:125-193) restarts every 0.25 s frame instead.  t_base and every T_tile but the last are
+ * multiples of 16; final_tile closes the clusters still open.  A stream whose candidate ring overflows (> 63 pending
+ * candidates: out-of-band input) cannot be redone from its start here; micloc_stream_overflow returns how many were lost
+ * (synchronises the stream) -- callers must treat a non-zero count as an error. */
+size_t micloc_lif_beamform_workspace_bytes(const micloc_plan *plan, int B, int T); /* ws of micloc_lif_beamform_f64 alone (bf_mat set) */
+size_t micloc_stream_state_bytes(const micloc_plan *plan, int B);
+int micloc_stream_encode_f64(const micloc_plan *plan, const double *h, int B, int T_tile, int row_stride, long long t_base,
+                             int first_tile, int final_tile, int8_t *spikes, int T_total, void *state, size_t state_bytes,
+                             void *stream);
+int micloc_stream_overflow(const void *state, int *count, void *stream);
+
 /* ---- beamforming vectors from membrane covariances (design_from_template's decomposition step) ------ */
 /* Replaces the per-DoA np.linalg.svd calls of SNNBeamformer.design_from_template (snn_beamformer.py:183-203) and
  * _find_dc_removed_sing_vec (:372-422) by one batched kernel: column g0 + i of bf_mat [C][G] from cov[i] [C][C]

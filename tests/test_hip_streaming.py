@@ -1,0 +1,122 @@
+"""Streaming with exact state hand-off (streaming.StreamingLocalizer, micloc_stream_encode_f64): a recording pushed tile by
+tile gives the spikes, power and arg-max of the one-shot call bit for bit, for any tiling -- including the reference's own
+golden trials and the speech-length trial."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from conftest import golden
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _beamformer(bipolar=True):
+    from micloc.array_geometry import CenterCircularArray
+    from micloc.snn_beamformer import SNNBeamformer
+
+    tau = 1 / (2 * np.pi * 2000)
+    return SNNBeamformer(CenterCircularArray(4.5e-2, 7), 10e-3, [1000.0, 2000.0], np.asarray([tau, tau]), bipolar_spikes=bipolar, fs=48_000)
+
+
+def _stream(bf, W, x, tiles, wrap=True):
+    from haghighatshoarmuir2024_amd.streaming import StreamingLocalizer
+
+    B, T, M = x.shape
+    L2 = len(bf.kernel) // 2
+    s = StreamingLocalizer(bf, W, B, T, wrap_tail=x[:, T - L2 :, :] if wrap else None)
+    t = 0
+    for n in tiles:
+        s.push(x[:, t : t + n, :])
+        t += n
+    assert t == T
+    return s.finish(want_spikes=True)
+
+
+@pytest.mark.parametrize("bipolar", [True, False])
+def test_stream_equals_one_shot_for_any_tiling(cfg2, bipolar):
+    z = golden("trials_cfg2.npz")
+    rng = np.random.RandomState(8)
+    x = np.concatenate([z["sig_in"], rng.randn(5, 4799, 7)])
+    bf = _beamformer(bipolar)
+    W = cfg2["bf_mat"]
+    one = bf.localize_batch(W, x, return_spikes=True)
+    ref_spikes = one["spikes"].cpu().numpy()
+    if bipolar:
+        np.testing.assert_array_equal(ref_spikes[:3], z["spikes"])  # == the reference's own spikes
+    T = x.shape[1]
+    tilings = [[T], [2400, T - 2400], [16] * 20 + [T - 320], [1600, 1600, T - 3200], [4784, 15], [256] * 18 + [T - 256 * 18]]
+    rt = np.random.RandomState(1)
+    cuts = np.sort(rt.choice(np.arange(1, T // 16), size=12, replace=False)) * 16
+    tilings.append(list(np.diff(np.concatenate([[0], cuts, [T]]))))
+    for tiles in tilings:
+        out = _stream(bf, W, x, tiles)
+        np.testing.assert_array_equal(out["spikes"].cpu().numpy(), ref_spikes, err_msg=f"tiles={tiles[:4]}...")
+        np.testing.assert_array_equal(out["power"].cpu().numpy(), one["power"].cpu().numpy())
+        np.testing.assert_array_equal(out["argmax"].cpu().numpy(), one["argmax"].cpu().numpy())
+    # without the wrap-around rows only the encoder's transient differs: a causal stream cannot know the end of the recording
+    out = _stream(bf, W, x, [1600, 1600, T - 3200], wrap=False)
+    assert not np.array_equal(out["spikes"].cpu().numpy(), ref_spikes)
+
+
+def test_stream_plateaus_and_errors(cfg2):
+    """Digital silence across tile boundaries (plateaus of the running sum, clusters open at a boundary), API errors."""
+    from haghighatshoarmuir2024_amd import _lib
+    from haghighatshoarmuir2024_amd.streaming import StreamingLocalizer
+
+    bf = _beamformer()
+    rng = np.random.RandomState(3)
+    T = 3200
+    x = rng.randn(2, T, 7)
+    x[0, 700:2300, :] = 0.0
+    x[1, :1000, 2] = 0.0
+    one = bf.localize_batch(cfg2["bf_mat"], x, return_spikes=True)
+    for tiles in ([800] * 4, [1600, 1600], [704, 16, 16, 2464]):
+        out = _stream(bf, cfg2["bf_mat"], x, tiles)
+        np.testing.assert_array_equal(out["spikes"].cpu().numpy(), one["spikes"].cpu().numpy())
+        np.testing.assert_array_equal(out["power"].cpu().numpy(), one["power"].cpu().numpy())
+    s = StreamingLocalizer(bf, cfg2["bf_mat"], 2, T)
+    with pytest.raises(ValueError):
+        s.push(x[:, :100, :])  # not a multiple of 16 and not the last tile
+    s.push(x[:, :1600, :])
+    with pytest.raises(_lib.MiclocError):
+        s.finish()
+    with pytest.raises(ValueError):
+        s.push(x[:, :, :3])
+    # out-of-band input (alternating samples: one endless cluster) overflows the candidate ring: reported, not silently wrong
+    bad = np.tile(np.where(np.arange(T) % 2 == 0, 1.0, -1.0)[None, :, None], (1, 1, 7)) * (1 + 0.01 * rng.rand(1, T, 7))
+    from haghighatshoarmuir2024_amd import runtime
+
+    spk1 = runtime.rzcc_encode(bad[0], 12, True)  # the one-shot operator handles it (fallback kernel)
+    assert int((spk1 != 0).sum()) > 0
+    s2 = StreamingLocalizer(_beamformer_identity(), np.eye(14)[:, :3], 1, T)
+    s2.push(bad)
+    try:
+        s2.finish()
+    except _lib.MiclocError as e:
+        assert "overflow" in str(e)
+
+
+def _beamformer_identity():
+    """A beamformer whose band contains the alternating test input (so that the band-pass does not remove it)."""
+    from micloc.array_geometry import CenterCircularArray
+    from micloc.snn_beamformer import SNNBeamformer
+
+    tau = 1 / (2 * np.pi * 20000)
+    return SNNBeamformer(CenterCircularArray(4.5e-2, 7), 10e-3, [12000.0, 23000.0], np.asarray([tau, tau]), bipolar_spikes=True, fs=48_000)
+
+
+def test_stream_speech_length(cfg2):
+    """T = 332 157 in 0.25 s tiles (the live demo's frame length): the SHA-256 of the reference's spike raster."""
+    from test_speech_config import speech_trial_input
+
+    z, t, sig = speech_trial_input(cfg2)
+    bf = _beamformer()
+    T = sig.shape[0]
+    tiles = [12000] * (T // 12000) + ([T % 12000] if T % 12000 else [])
+    out = _stream(bf, cfg2["bf_mat"], sig[None], tiles)
+    spikes = out["spikes"][0].cpu().numpy()
+    assert hashlib.sha256(np.ascontiguousarray(spikes).tobytes()).digest() == z["spikes_sha256"].tobytes()
+    np.testing.assert_allclose(out["power"][0].cpu().numpy(), z["power"], rtol=1e-10)
+    assert int(out["argmax"][0]) == int(z["argmax"])
