@@ -110,7 +110,7 @@ WsLayout ws_layout(const micloc_plan *p, int B, int T)
     {
         const size_t pb = beamform_partial_bytes(B, T, Gp);
         const int ct = pad_ct(p->C);
-        const size_t pc = ct <= 4 ? cov_partial_bytes(B, T, ct) : 0;
+        const size_t pc = ct <= 8 ? cov_partial_bytes(B, T, ct) : 0;
         off += pb > pc ? pb : pc;
     }
     w.total = off;
@@ -590,7 +590,7 @@ int micloc_lif_covariance_f64(const micloc_plan *p, const int8_t *spikes, int B,
     const bool want_power = power || argmax;
     if (want_power && (!p->d_W || p->W_is_complex)) return p->d_W ? MICLOC_ERR_SHAPE : MICLOC_ERR_NOT_SET;
     const int CT = pad_ct(p->C);
-    if (CT > 4) return MICLOC_ERR_SHAPE;  // more than 64 channels: not built yet
+    if (CT > 8) return MICLOC_ERR_SHAPE;
     if (bad_ws(ws, ws_bytes, cov_partial_bytes(B, T, CT))) return MICLOC_ERR_WORKSPACE;
     double *partial = reinterpret_cast<double *>(ws);
     hipStream_t st = (hipStream_t)stream;
@@ -610,7 +610,7 @@ int micloc_snn_pipeline_cov_f64(const micloc_plan *p, const double *x, int B, in
     const bool want_power = power || argmax;
     if (want_power && (!p->d_W || p->W_is_complex)) return p->d_W ? MICLOC_ERR_SHAPE : MICLOC_ERR_NOT_SET;
     const int CT = pad_ct(p->C);
-    if (CT > 4) return MICLOC_ERR_SHAPE;
+    if (CT > 8) return MICLOC_ERR_SHAPE;
     const WsLayout w = ws_layout(p, B, T);
     if (bad_ws(ws, ws_bytes, w.total)) return MICLOC_ERR_WORKSPACE;
     unsigned char *base = reinterpret_cast<unsigned char *>(ws);

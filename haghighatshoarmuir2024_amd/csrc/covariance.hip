@@ -141,6 +141,118 @@ __global__ __launch_bounds__(CV_THREADS) void lif_cov_kernel(const int8_t *__res
     }
 }
 
+// ---- more than 64 channels (BASELINE config 5: 64 microphones, C = 128) -------------------------------------------
+// The register-resident form above needs CT membrane fragments per time tile and CT (CT + 1) / 2 Gram accumulators per
+// wave: 36 x 4 doubles at CT = 8 do not fit.  Here the workgroup walks its 512-frame chunk in sub-chunks of 64 frames:
+//   LIF     wave w computes the membrane fragments of time tile (w & 3), channel tiles [HALF (w >> 2), HALF (w >> 2) + HALF)
+//           (the same chronological fma chain as everywhere else) and parks them in LDS in fragment order;
+//   Gram    the CT (CT + 1) / 2 output tiles are dealt round-robin to the 8 waves (<= 5 each: 20 accumulator registers);
+//           a wave reads both operands of every product as 8-byte fragments from LDS (conflict-free: lane-contiguous).
+// 2 C^2 instead of 2 C G flops per frame: 11x fewer than the direct form at C = 128, G = 1440.
+template <int CT>
+__global__ __launch_bounds__(CV_THREADS) void lif_cov_wide_kernel(const int8_t *__restrict__ spikes,
+                                                                   const double *__restrict__ ntab_g, int NK, int C, int T,
+                                                                   int t_start, double *__restrict__ partial)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int Cs = 16 * CT;
+    constexpr int NP = CT * (CT + 1) / 2;
+    constexpr int HALF = (CT + 1) / 2;
+    constexpr int SUB = 64;                       // frames per sub-chunk (4 time tiles)
+    constexpr int MYP = (NP + BF_WAVES - 1) / BF_WAVES;
+    const int tid = threadIdx.x;
+    const int wv = tid >> 6;
+    const int l = tid & 63;
+    const int lc = l & 15;
+    const int q = l >> 4;
+    const int chunk = blockIdx.x;
+    const int nchunks = gridDim.x;
+    const int b = blockIdx.y;
+    const int cs = chunk * BF_CHUNK;
+
+    double *ntab = reinterpret_cast<double *>(smem);
+    const int ntab_len = 4 * NK + 16;
+    double *Vs = ntab + ntab_len;                                 // [4 tt][CT][4 r][64 lanes]
+    int8_t *spk = reinterpret_cast<int8_t *>(Vs + 4 * CT * 256);  // [SUB + 4 NK - 16][Cs]
+    const int R = SUB + 4 * NK - 16;
+    for (int e = tid; e < ntab_len; e += CV_THREADS) ntab[e] = ntab_g[e];
+
+    // the Gram tiles of this wave: p = wv, wv + 8, ...
+    int c1s[MYP], c2s[MYP];
+#pragma unroll
+    for (int i = 0; i < MYP; ++i) {
+        const int p = wv + BF_WAVES * i;
+        int c1 = 0, rem = p < NP ? p : 0;
+        while (rem >= CT - c1) {
+            rem -= CT - c1;
+            ++c1;
+        }
+        c1s[i] = c1;
+        c2s[i] = c1 + rem;
+    }
+    double4_t Racc[MYP];
+#pragma unroll
+    for (int i = 0; i < MYP; ++i) Racc[i] = double4_t{0.0, 0.0, 0.0, 0.0};
+
+    const int8_t *sb = spikes + (size_t)b * T * C;
+    const int tt = wv & 3;
+    const int ct0 = HALF * (wv >> 2);
+    for (int sub = 0; sub < BF_CHUNK / SUB; ++sub) {
+        const int s0 = cs + sub * SUB;
+        if (s0 >= T) break;  // uniform
+        __syncthreads();     // the previous sub-chunk's Gram phase has read Vs; its LIF phase has read spk
+        {
+            const int tau0 = s0 + 16 - 4 * NK;
+            for (int e = tid; e < R * Cs; e += CV_THREADS) {
+                const int rho = e / Cs, c = e % Cs;
+                const int tau = tau0 + rho;
+                spk[e] = (c < C && tau >= 0 && tau < T) ? sb[(size_t)tau * C + c] : (int8_t)0;
+            }
+        }
+        __syncthreads();
+        // ---- LIF: time tile tt, channel tiles ct0 .. ct0 + HALF ----
+        const int tb0 = s0 + 16 * tt;
+#pragma unroll
+        for (int ci = 0; ci < HALF; ++ci) {
+            const int ct = ct0 + ci;
+            if (ct < CT) {  // uniform
+                double4_t acc = double4_t{0.0, 0.0, 0.0, 0.0};
+                const int8_t *sp = spk + (size_t)(16 * tt + q) * Cs + 16 * ct + lc;
+                const double *np_ = ntab + (lc - q + 4 * NK - 16 + 15);
+                for (int ks = 0; ks < NK; ++ks)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(np_[-4 * ks], (double)sp[(size_t)(4 * ks) * Cs], acc, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int t = tb0 + q + 4 * r;
+                    Vs[((size_t)(tt * CT + ct) * 4 + r) * 64 + l] = (t < T && t >= t_start) ? acc[r] : 0.0;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- Gram: R(c1, c2) += V_c1^T V_c2 over the 4 time tiles ----
+#pragma unroll
+        for (int i = 0; i < MYP; ++i) {
+            if (wv + BF_WAVES * i < NP) {  // uniform
+#pragma unroll
+                for (int t4 = 0; t4 < 4; ++t4)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        Racc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(Vs[((size_t)(t4 * CT + c1s[i]) * 4 + r) * 64 + l],
+                                                                       Vs[((size_t)(t4 * CT + c2s[i]) * 4 + r) * 64 + l], Racc[i], 0, 0, 0);
+            }
+        }
+    }
+    double *pout = partial + ((size_t)b * nchunks + chunk) * (NP * 256);
+#pragma unroll
+    for (int i = 0; i < MYP; ++i) {
+        const int p = wv + BF_WAVES * i;
+        if (p < NP) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pout[((size_t)p * 4 + r) * 64 + l] = Racc[i][r];
+        }
+    }
+}
+
 // One workgroup per trial: R = sum over chunks (fixed order), symmetric fill, optional normalised output, and
 // power[g] = w_g^T R w_g / Tn for every DoA; arg-max.
 __global__ __launch_bounds__(256) void cov_power_kernel(const double *__restrict__ partial, int nchunks, int CT, int C,
@@ -185,10 +297,20 @@ __global__ __launch_bounds__(256) void cov_power_kernel(const double *__restrict
     if (power || argmax) {
         for (int g = tid; g < G; g += 256) {
             double p = 0.0;
-            for (int i = 0; i < C; ++i) {
-                double u = 0.0;
-                for (int j = 0; j < C; ++j) u = __builtin_fma(Rs[(size_t)i * Cp + j], Wp[(size_t)j * Gp + g], u);
-                p = __builtin_fma(Wp[(size_t)i * Gp + g], u, p);
+            // rows of R in blocks of 16: a column value of bf_mat is loaded once per block instead of once per row
+            // (the summation order per row i is unchanged: u_i = sum_j R_ij w_j with j ascending, then p += w_i u_i)
+            for (int i0 = 0; i0 < C; i0 += 16) {
+                double u[16];
+#pragma unroll
+                for (int ii = 0; ii < 16; ++ii) u[ii] = 0.0;
+                for (int j = 0; j < C; ++j) {
+                    const double wj = Wp[(size_t)j * Gp + g];
+#pragma unroll
+                    for (int ii = 0; ii < 16; ++ii) u[ii] = __builtin_fma(Rs[(size_t)(i0 + ii) * Cp + j], wj, u[ii]);
+                }
+#pragma unroll
+                for (int ii = 0; ii < 16; ++ii)
+                    if (i0 + ii < C) p = __builtin_fma(Wp[(size_t)(i0 + ii) * Gp + g], u[ii], p);
             }
             p = p * inv;
             if (power) power[(size_t)b * G + g] = p;
@@ -240,6 +362,21 @@ static hipError_t launch_cov_ct(const NeuronTab &nt, const int8_t *spikes, int B
     return hipGetLastError();
 }
 
+template <int CT>
+static hipError_t launch_cov_wide(const NeuronTab &nt, const int8_t *spikes, int B, int T, int C, int t_start, double *partial,
+                                  hipStream_t stream)
+{
+    size_t lds = (size_t)(4 * nt.NK + 16) * sizeof(double) + (size_t)4 * CT * 256 * sizeof(double) + (size_t)(64 + 4 * nt.NK - 16) * 16 * CT;
+    lds = (lds + 15) & ~(size_t)15;
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    auto k = &lif_cov_wide_kernel<CT>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    dim3 grid(beamform_nchunks(T), B), block(CV_THREADS);
+    hipLaunchKernelGGL(k, grid, block, lds, stream, spikes, nt.tab, nt.NK, C, T, t_start, partial);
+    return hipGetLastError();
+}
+
 hipError_t launch_lif_cov(const NeuronTab &nt, const int8_t *spikes, int B, int T, int C, int CT, int t_start,
                           double *partial, hipStream_t stream)
 {
@@ -248,7 +385,11 @@ hipError_t launch_lif_cov(const NeuronTab &nt, const int8_t *spikes, int B, int 
         case 2: return launch_cov_ct<2>(nt, spikes, B, T, C, t_start, partial, stream);
         case 3: return launch_cov_ct<3>(nt, spikes, B, T, C, t_start, partial, stream);
         case 4: return launch_cov_ct<4>(nt, spikes, B, T, C, t_start, partial, stream);
-        default: return hipErrorInvalidValue;  // C > 64: needs the LDS-shared variant (not built yet)
+        case 5: return launch_cov_wide<5>(nt, spikes, B, T, C, t_start, partial, stream);
+        case 6: return launch_cov_wide<6>(nt, spikes, B, T, C, t_start, partial, stream);
+        case 7: return launch_cov_wide<7>(nt, spikes, B, T, C, t_start, partial, stream);
+        case 8: return launch_cov_wide<8>(nt, spikes, B, T, C, t_start, partial, stream);
+        default: return hipErrorInvalidValue;
     }
 }
 
@@ -256,6 +397,15 @@ hipError_t launch_cov_power(const double *partial, int B, int T, int CT, int C, 
                             double *cov_out, double *power, int32_t *argmax, hipStream_t stream)
 {
     const size_t lds = (size_t)(16 * CT) * (16 * CT) * sizeof(double);
+    if (lds > 48 * 1024) {
+        // (the kernel also has 3 KB of static LDS: ask for what is needed, not for the whole 160 KB)
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&cov_power_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();  // do not leave the error behind for the next launch's check
+            return e;
+        }
+    }
     hipLaunchKernelGGL(cov_power_kernel, dim3(B), dim3(256), lds, stream, partial, beamform_nchunks(T), CT, C, Tn, Wp, Gp,
                        G, cov_out, power, argmax);
     return hipGetLastError();

@@ -292,10 +292,11 @@ def test_covariance_form_power_and_membrane_covariance(plan2, cfg2):
 
 
 def test_covariance_form_wide(torch):
-    """C = 32 and C = 48 channels (two / three channel tiles -> 3 / 6 Gram tiles)."""
+    """C = 32 and C = 48 channels (two / three channel tiles -> 3 / 6 Gram tiles); C = 80 and C = 128 channels (the
+    LDS-shared kernel of BASELINE config 5: 36 Gram tiles dealt over the waves), incl. a ragged T and t_start."""
     from haghighatshoarmuir2024_amd.runtime import Plan
 
-    for M, G, T in [(16, 40, 900), (24, 20, 530)]:
+    for M, G, T in [(16, 40, 900), (24, 20, 530), (40, 33, 700), (64, 70, 1111)]:
         fs = 96_000
         rng = np.random.RandomState(M)
         ker = O.stht_kernel(fs, 10e-3)
@@ -313,6 +314,10 @@ def test_covariance_form_wide(torch):
         np.testing.assert_allclose(c["power"].cpu().numpy(), d["power"].cpu().numpy(), rtol=1e-11)
         ref = O.snn_chain(x[1], ker, b, a, O.robust_width(fs, 2000.0), True, nir, W, want=("vmem",))
         np.testing.assert_allclose(c["cov"][1].cpu().numpy(), ref["vmem"].T @ ref["vmem"] / T, rtol=1e-11, atol=1e-18)
+        assert np.array_equal(c["argmax"].cpu().numpy(), d["argmax"].cpu().numpy())
+        ts = T // 4
+        part = p.snn_pipeline_cov(xd, t_start=ts, want_cov=True, want_power=False)["cov"][1].cpu().numpy()
+        np.testing.assert_allclose(part, ref["vmem"][ts:].T @ ref["vmem"][ts:] / (T - ts), rtol=1e-11, atol=1e-18)
 
 
 def test_many_mic_complex_beamformer(torch):

@@ -11,13 +11,16 @@ python3 bench.py --steps 40 --warmup 4 --streams 1 --no-cpu-baseline > $OUT/benc
 python3 bench.py --steps 40 --warmup 4 --grid 449 --no-cpu-baseline > $OUT/bench_n1_grid449.json 2> $OUT/bench_n1_grid449.err
 python3 bench.py --config speech --steps 5 --warmup 1 > $OUT/bench_n1_speech.json 2> $OUT/bench_n1_speech.err
 python3 bench.py --config stress --steps 5 --warmup 1 > $OUT/bench_n1_stress.json 2> $OUT/bench_n1_stress.err
+python3 bench.py --config xylo --steps 3 --warmup 1 > $OUT/bench_n1_xylo.json 2> $OUT/bench_n1_xylo.err
 # per-kernel times: serial steps so that every launch is timed alone
 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace -o run -- python3 bench.py --steps 40 --warmup 4 --no-cpu-baseline --streams 1 > $OUT/trace.log 2>&1
-rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace_speech -o run -- python3 bench.py --config speech --steps 3 --warmup 1 > $OUT/trace_speech.log 2>&1
-rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace_stress -o run -- python3 bench.py --config stress --steps 3 --warmup 1 > $OUT/trace_stress.log 2>&1
+rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace_speech -o run -- python3 bench.py --config speech --steps 3 --warmup 1 --streams 1 > $OUT/trace_speech.log 2>&1
+rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace_stress -o run -- python3 bench.py --config stress --steps 3 --warmup 1 --streams 1 > $OUT/trace_stress.log 2>&1
+rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace_xylo -o run -- python3 bench.py --config xylo --steps 2 --warmup 1 > $OUT/trace_xylo.log 2>&1
 # counters: separate passes, nothing but --pmc (+ kernel trace)
-for cfg in noisy stress; do
-  extra="--config $cfg --steps 6 --warmup 1 --no-cpu-baseline --streams 1"
+for cfg in noisy stress speech; do
+  steps=6; [ $cfg = speech ] && steps=2
+  extra="--config $cfg --steps $steps --warmup 1 --no-cpu-baseline --streams 1"
   rocprofv3 --output-format csv --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch_$cfg -o run -- python3 bench.py $extra > $OUT/pmc_fetch_$cfg.log 2>&1
   rocprofv3 --output-format csv --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write_$cfg -o run -- python3 bench.py $extra > $OUT/pmc_write_$cfg.log 2>&1
   rocprofv3 --output-format csv --kernel-trace --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE -d $OUT/pmc_sq_$cfg -o run -- python3 bench.py $extra > $OUT/pmc_sq_$cfg.log 2>&1
@@ -25,9 +28,11 @@ done
 python3 tools/summarize_profiles.py trace $OUT/trace $OUT/kernel_trace_summary_by_shape.csv
 python3 tools/summarize_profiles.py trace $OUT/trace_speech $OUT/kernel_trace_summary_speech.csv
 python3 tools/summarize_profiles.py trace $OUT/trace_stress $OUT/kernel_trace_summary_stress.csv
+python3 tools/summarize_profiles.py trace $OUT/trace_xylo $OUT/kernel_trace_summary_xylo.csv
 python3 tools/summarize_profiles.py pmc $OUT/pmc_summary.csv pmc_fetch=$OUT/pmc_fetch_noisy pmc_write=$OUT/pmc_write_noisy pmc_sq=$OUT/pmc_sq_noisy
 python3 tools/summarize_profiles.py pmc $OUT/pmc_summary_stress.csv pmc_fetch=$OUT/pmc_fetch_stress pmc_write=$OUT/pmc_write_stress pmc_sq=$OUT/pmc_sq_stress
+python3 tools/summarize_profiles.py pmc $OUT/pmc_summary_speech.csv pmc_fetch=$OUT/pmc_fetch_speech pmc_write=$OUT/pmc_write_speech pmc_sq=$OUT/pmc_sq_speech
 find $OUT/trace -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats_bench_steps40_streams1.csv \;
 # keep the merge-back small: drop the raw per-dispatch traces
-rm -rf $OUT/trace $OUT/trace_speech $OUT/trace_stress $OUT/pmc_fetch_* $OUT/pmc_write_* $OUT/pmc_sq_*
+rm -rf $OUT/trace $OUT/trace_speech $OUT/trace_stress $OUT/trace_xylo $OUT/pmc_fetch_* $OUT/pmc_write_* $OUT/pmc_sq_*
 ls -la $OUT
