@@ -946,52 +946,76 @@ hipError_t launch_planar_beamform(const BeamformW &W, const double *pre, int B, 
 }
 
 // ---- chunk reduction, mean over time, arg-max (first maximum, like np.argmax) --------------------------------
-__global__ __launch_bounds__(256) void power_argmax_kernel(const double *__restrict__ partial, int T, int nchunks,
-                                                            int Gp, int G, int complex_pairs, int Ghp,
-                                                            double *__restrict__ power, int32_t *__restrict__ argmax)
+// S = 1: one thread per DoA sums the chunks in ascending order.  Long recordings (speech: 1298 chunks, 125 trials) leave
+// that form latency bound on a few workgroups, so with S = 4 the chunk range is cut into 4 contiguous slices summed side
+// by side and combined as ((s0 + s1) + (s2 + s3)): still a fixed order, independent of the launch.
+template <int S>
+__global__ __launch_bounds__(256 * S) void power_argmax_kernel(const double *__restrict__ partial, int T, int nchunks,
+                                                                int Gp, int G, int complex_pairs, int Ghp,
+                                                                double *__restrict__ power, int32_t *__restrict__ argmax)
 {
     __shared__ double sv[256];
     __shared__ int si[256];
+    __shared__ double ps[S][256];
     const int b = blockIdx.x;
-    const int tid = threadIdx.x;
+    const int col = threadIdx.x & 255;
+    const int slice = threadIdx.x >> 8;
     const double *pb = partial + (size_t)b * nchunks * Gp;
+    const int c_lo = (int)((long long)slice * nchunks / S), c_hi = (int)((long long)(slice + 1) * nchunks / S);
     double best = -1.0;
     int bi = 0x7fffffff;
-    for (int g = tid; g < G; g += 256) {
+    for (int g0 = 0; g0 < G; g0 += 256) {
+        const int g = g0 + col;
         double s = 0.0;
-        for (int ch = 0; ch < nchunks; ++ch) {
-            s += pb[(size_t)ch * Gp + g];
-            if (complex_pairs) s += pb[(size_t)ch * Gp + Ghp + g];
+        if (g < G) {
+            for (int ch = c_lo; ch < c_hi; ++ch) {
+                s += pb[(size_t)ch * Gp + g];
+                if (complex_pairs) s += pb[(size_t)ch * Gp + Ghp + g];
+            }
         }
-        const double p = s / (double)T;
-        if (power) power[(size_t)b * G + g] = p;
-        if (p > best) {
-            best = p;
-            bi = g;
+        if (S > 1) {
+            ps[slice][col] = s;
+            __syncthreads();
+            if (slice == 0) s = (ps[0][col] + ps[S > 1 ? 1 : 0][col]) + (ps[S > 2 ? 2 : 0][col] + ps[S > 3 ? 3 : 0][col]);
+            __syncthreads();
+        }
+        if (slice == 0 && g < G) {
+            const double p = s / (double)T;
+            if (power) power[(size_t)b * G + g] = p;
+            if (p > best) {
+                best = p;
+                bi = g;
+            }
         }
     }
-    sv[tid] = best;
-    si[tid] = bi;
+    if (slice == 0) {
+        sv[col] = best;
+        si[col] = bi;
+    }
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
-        if (tid < s) {
-            const double ov = sv[tid + s];
-            const int oi = si[tid + s];
-            if (ov > sv[tid] || (ov == sv[tid] && oi < si[tid])) {
-                sv[tid] = ov;
-                si[tid] = oi;
+        if (slice == 0 && col < s) {
+            const double ov = sv[col + s];
+            const int oi = si[col + s];
+            if (ov > sv[col] || (ov == sv[col] && oi < si[col])) {
+                sv[col] = ov;
+                si[col] = oi;
             }
         }
         __syncthreads();
     }
-    if (tid == 0 && argmax) argmax[b] = si[0] == 0x7fffffff ? 0 : si[0];
+    if (threadIdx.x == 0 && argmax) argmax[b] = si[0] == 0x7fffffff ? 0 : si[0];
 }
 
 hipError_t launch_power_argmax(const double *partial, int B, int T, int nchunks, int Gp, int G, int complex_pairs,
                                int Ghalf_pad, double *power, int32_t *argmax, hipStream_t stream)
 {
-    hipLaunchKernelGGL(power_argmax_kernel, dim3(B), dim3(256), 0, stream, partial, T, nchunks, Gp, G, complex_pairs,
-                       Ghalf_pad, power, argmax);
+    if (nchunks >= 128)
+        hipLaunchKernelGGL(power_argmax_kernel<4>, dim3(B), dim3(1024), 0, stream, partial, T, nchunks, Gp, G, complex_pairs, Ghalf_pad,
+                           power, argmax);
+    else
+        hipLaunchKernelGGL(power_argmax_kernel<1>, dim3(B), dim3(256), 0, stream, partial, T, nchunks, Gp, G, complex_pairs, Ghalf_pad,
+                           power, argmax);
     return hipGetLastError();
 }
 

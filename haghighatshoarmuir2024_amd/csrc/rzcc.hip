@@ -160,7 +160,8 @@ __device__ __forceinline__ void detect_step(DetectState &d, double c, int word_b
     const uint64_t rise = __builtin_amdgcn_fcmp(c, d.prev, 2);  // ordered >
     const uint64_t fall = __builtin_amdgcn_fcmp(c, d.prev, 4);  // ordered <
     const uint64_t ev = ((fall & d.dpos) | (bip & rise & d.dneg)) & live;
-    const int slot = d.n & (RZ_RING - 1);  // unconditional store; consumed only if n advances
+    constexpr int RING = (int)(sizeof(ringP) / sizeof(ringP[0]));
+    const int slot = d.n & (RING - 1);  // unconditional store; consumed only if n advances
     ringP[slot][lane] = d.lrel + word_base + J;  // left + t - 1; position = word >> 1 (plateau midpoint)
     ringV[slot][lane] = d.prev;                  // plateau value; minima negate it when they compare
     d.n = add_lane_mask(d.n, ev);
@@ -177,7 +178,8 @@ __device__ __forceinline__ void detect_append(DetectState &d, const double (&c)[
 {
     if constexpr (U < 8) {
         constexpr int J = J0 + U;
-        const int slot = d.n & (RZ_RING - 1);  // unconditional store; consumed only if n advances
+        constexpr int RING = (int)(sizeof(ringP) / sizeof(ringP[0]));
+        const int slot = d.n & (RING - 1);  // unconditional store; consumed only if n advances
         ringP[slot][lane] = d.lrel + word_base + J;  // left + t - 1; position = word >> 1 (plateau midpoint)
         ringV[slot][lane] = J ? c[J ? J - 1 : 0] : d.prev;  // plateau value; minima negate it when they compare
         d.n = add_lane_mask(d.n, ev[U]);
@@ -625,7 +627,10 @@ struct RzStream {
     int on;
 };
 
-template <int N, bool WANT_PRE, bool WANT_SPIKES>
+// RING: candidate ring entries per stream (power of two).  A whole tile of appends (RZ_MT) is reserved before every tile, so
+// the usable depth is RING - RZ_MT.  Measured on the speech workload: RING = 32 (three workgroups per CU instead of two)
+// overflows so often that the unit fallback takes 3x the time saved -- 64 it is.
+template <int N, bool WANT_PRE, bool WANT_SPIKES, int RING = RZ_RING>
 __global__ __launch_bounds__(320) void bandpass_rzcc_fast_kernel(const double *__restrict__ h,
                                                                   double *__restrict__ pre,
                                                                   int8_t *__restrict__ spikes,
@@ -638,8 +643,8 @@ __global__ __launch_bounds__(320) void bandpass_rzcc_fast_kernel(const double *_
 {
     __shared__ __attribute__((aligned(16))) double X[3][RZ_MT][RZ_ROW];
     __shared__ double Y[WANT_PRE ? 2 : 1][WANT_PRE ? RZ_MT : 1][WANT_PRE ? RZ_ROW : 1];
-    __shared__ double ringV[WANT_SPIKES ? RZ_RING : 1][64];
-    __shared__ int ringP[WANT_SPIKES ? RZ_RING : 1][64];
+    __shared__ double ringV[WANT_SPIKES ? RING : 1][64];
+    __shared__ int ringP[WANT_SPIKES ? RING : 1][64];
     __shared__ int nPub[64];
     __shared__ int polPub[64];     // 1: the stream's first candidate is a minimum (candidates alternate from there)
     __shared__ int deadPub[64];
@@ -759,7 +764,7 @@ __global__ __launch_bounds__(320) void bandpass_rzcc_fast_kernel(const double *_
             // the candidate ring with the clusters that were still open
             const double *rv = ss.ringV + (size_t)blk * RZ_RING * 64;
             const int *rp = ss.ringP + (size_t)blk * RZ_RING * 64;
-            for (int e = 0; e < RZ_RING; ++e) {
+            for (int e = 0; e < RING; ++e) {
                 ringV[e][lane] = rv[e * 64 + lane];
                 ringP[e][lane] = rp[e * 64 + lane];
             }
@@ -779,9 +784,9 @@ __global__ __launch_bounds__(320) void bandpass_rzcc_fast_kernel(const double *_
                     // After this tile at most RZ_RING - 1 entries may be pending, so that one slot -- the one in front
                     // of the oldest pending entry -- is always free: a lane that has to stop appending parks its
                     // (unconditional) ring writes there, where the select waves never look.
-                    const uint64_t full = __ballot(d.n + RZ_MT - oldest > RZ_RING - 1);
+                    const uint64_t full = __ballot(d.n + RZ_MT - oldest > RING - 1);
                     if (full & live) {  // uniform
-                        d.n = ((full >> lane) & 1) ? oldest + RZ_RING - 1 : d.n;
+                        d.n = ((full >> lane) & 1) ? oldest + RING - 1 : d.n;
                         live &= ~full;
                         ovPub[lane] = (int)((~live >> lane) & 1);
                     }
@@ -840,8 +845,8 @@ __global__ __launch_bounds__(320) void bandpass_rzcc_fast_kernel(const double *_
     const int8_t mark = mypol ? -1 : 1;
     const double sgn = mypol ? -1.0 : 1.0;
     const int own_lo = sp_.own_lo, own_hi = sp_.own_hi;
-    auto word_at = [&](int i) { return &ringP[i & (RZ_RING - 1)][lane]; };
-    auto val_at = [&](int i) { return &ringV[i & (RZ_RING - 1)][lane]; };
+    auto word_at = [&](int i) { return &ringP[i & (RING - 1)][lane]; };
+    auto val_at = [&](int i) { return &ringV[i & (RING - 1)][lane]; };
     auto close_cluster = [&](int s, int e, int lastpos) {
         const int first = *word_at(s) >> 1;
         if (first < own_lo || first >= own_hi) return;  // the cluster belongs to a neighbouring chunk
@@ -899,7 +904,7 @@ __global__ __launch_bounds__(320) void bandpass_rzcc_fast_kernel(const double *_
         if (mypol == 0) {
             double *rv = ss.ringV + (size_t)blk * RZ_RING * 64;
             int *rp = ss.ringP + (size_t)blk * RZ_RING * 64;
-            for (int e = 0; e < RZ_RING; ++e) {
+            for (int e = 0; e < RING; ++e) {
                 rv[e * 64 + lane] = ringV[e][lane];
                 rp[e * 64 + lane] = ringP[e][lane];
             }

@@ -179,7 +179,11 @@ hipError_t launch_xylo_resident(const void *spikes_in, int ternary_C, int B, int
     short *dth = reinterpret_cast<short *>(base + off + 2 * seg);
     const uint8_t *sp = reinterpret_cast<const uint8_t *>(spikes_in);
     if (w_rec != 0 && N > 1024) return hipErrorInvalidValue;
-    const dim3 block(w_rec != 0 ? ((N + 63) / 64) * 64 : 256), grid(w_rec != 0 ? 1 : (N + 255) / 256, B);
+    // without recurrence the neurons are independent: as few, as full workgroups as possible (N = 360 -> one of 384 threads
+    // instead of 256 + 104: every wave of the launch issues the same instructions whether its lanes are used or not)
+    const int nblocks = w_rec != 0 ? 1 : (N + 511) / 512;
+    const int per = (N + nblocks - 1) / nblocks;
+    const dim3 block(((per + 63) / 64) * 64), grid(nblocks, B);
 #define XY_LAUNCH(NQ)                                                                                                          \
     do {                                                                                                                       \
         if (w_rec != 0)                                                                                                        \
