@@ -25,10 +25,12 @@ constexpr int XY_MAXQ = 16;  // up to 64 input channels
 
 __device__ __forceinline__ int xy_sat16(int v) { return v > 32767 ? 32767 : (v < -32768 ? -32768 : v); }
 
+// v - dv with dv = v >> dash, "at least one LSB" while v != 0.  The arithmetic shift of a negative value is never 0
+// (-1 at least), so the rule only ever fires for 0 < v < 2^dash, where it sets dv = 1:  dv = max(v >> dash, min(v, 1))
+// (v > 0: max(., 1);  v = 0: 0;  v < 0: v >> dash >= v).  Three instructions instead of seven.
 __device__ __forceinline__ int xy_decay(int v, int dash)
 {
-    int dv = v >> dash;
-    dv = (dv == 0 && v != 0) ? (v > 0 ? 1 : -1) : dv;
+    const int dv = max(v >> dash, min(v, 1));
     return v - dv;
 }
 
@@ -96,11 +98,17 @@ __global__ __launch_bounds__(1024) void xylo_lif_kernel(const uint8_t *__restric
             int v2 = xy_decay(vmem, dm);
             i2 = xy_sat16(i2 + in + (REC ? w_rec * prev_total : 0));
             v2 = xy_sat16(v2 + i2);
-            int n = 0;
-            if (v2 >= th) {
-                n = xy_div(v2, th);                   // th > 0: subtractive reset until below threshold ...
-                n = n < max_spikes ? n : max_spikes;  // ... or until the per-step cap
-                v2 -= n * th;
+            // subtractive reset until below threshold or until the per-step cap: almost always zero or one spike, so the
+            // first one is branch-free and only a wave in which some neuron still sits above threshold takes the division
+            int n = v2 >= th ? 1 : 0;
+            v2 -= n ? th : 0;
+            if (__builtin_expect(__any(v2 >= th), 0)) {  // (cap >= 1 by the API contract)
+                if (v2 >= th) {
+                    int more = xy_div(v2, th);
+                    more = more < max_spikes - 1 ? more : max_spikes - 1;
+                    n += more;
+                    v2 -= more * th;
+                }
             }
             isyn = i2;
             vmem = v2;
