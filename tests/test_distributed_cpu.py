@@ -147,3 +147,63 @@ def test_sharded_design_world3(tmp_path):
     np.testing.assert_array_equal(sharded_design(lambda d: ref[:, : len(d)], doa_list), ref)
     with pytest.raises(ValueError):
         sharded_design(lambda d: ref[:, :2], doa_list)
+
+
+def _speech_worker(rank, world, port, out_dir):
+    import sys
+
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    res = _speech_like_sweep(rank, world)
+    np.savez(os.path.join(out_dir, f"s{world}_{rank}.npz"), **{k: v for k, v in res.items() if isinstance(v, np.ndarray)})
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _speech_like_sweep(rank, world):
+    """speech_target_sweep (no bandwidth correction, source resampled from 16 kHz) on a short stand-in utterance, with the
+    CPU oracle as the localizer."""
+    from haghighatshoarmuir2024_amd.sweep import speech_source, speech_target_sweep
+    from micloc.array_geometry import CenterCircularArray
+    from micloc.snn_beamformer import SNNBeamformer, neuron_impulse_response
+    from oracle import oracle as O
+
+    bfz = np.load(os.path.join(ROOT, "tests", "golden", "bf_mat_chirp449_bipolar.npz"))
+    tau = 1.0 / (2 * np.pi * 2000)
+    beamf = SNNBeamformer(CenterCircularArray(4.5e-2, 7), 10e-3, [1000.0, 2000.0], np.asarray([tau, tau]), bipolar_spikes=True, fs=48_000)
+    pcm = np.load(os.path.join(ROOT, "tests", "golden", "speech_trial.npz"))
+    src = speech_source(48_000, pcm16=pcm["pcm16"][20000:20800], rate=int(pcm["rate"]))  # 50 ms of the utterance
+
+    def oracle_localizer(sig_batch, time_vec):
+        nir = neuron_impulse_response(time_vec, beamf.tau_vec)
+        b, a = beamf.bandpass_filter
+        pw, am = O.snn_chain_batch(sig_batch, beamf.kernel, b, a, beamf.spk_encoder.robust_width, True, nir, bfz["bf_mat"])
+        return am.astype(np.int64), pw[np.arange(len(am)), am]
+
+    return speech_target_sweep(beamf, bfz["bf_mat"], bfz["doa_list"], src, snr_db_vec=[0.0, 10.0, 20.0], num_sim=3, seed=21, mode="parity",
+                               rank=rank, world_size=world, localizer=oracle_localizer, batch_trials=2)
+
+
+@pytest.mark.timeout(600)
+def test_speech_sweep_sharding_invariant_world2(tmp_path):
+    """The speech harness (9 trials over 2 ranks, batches of 2) gives every rank the single-process result: the reference's
+    RNG stream stays aligned across shards and batch flushes."""
+    import torch.multiprocessing as mp
+
+    from oracle import oracle as O
+
+    O.build()
+    one = _speech_like_sweep(0, 1)
+    assert one["argmax"].shape == (3, 3) and np.all(np.diff(one["snr_db_vec"]) > 0)
+    port = _free_port()
+    mp.spawn(_speech_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        got = np.load(tmp_path / f"s2_{r}.npz")
+        for key in ("doa", "argmax", "err", "pmax", "mae_deg"):
+            np.testing.assert_array_equal(got[key], one[key], err_msg=f"rank {r} {key}")
