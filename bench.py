@@ -141,6 +141,7 @@ def build_workload(args, rank, device):
     from haghighatshoarmuir2024_amd.snn_beamformer import SNNBeamformer, neuron_impulse_response
 
     cfg = args.config
+    t_design = None
     freq_design = 2000.0
     freq_range = [0.5 * freq_design, freq_design]
     tau = 1.0 / (2 * np.pi * freq_design)
@@ -165,7 +166,12 @@ def build_workload(args, rank, device):
         bf_mat /= np.linalg.norm(bf_mat, axis=0, keepdims=True)
     else:
         # the whole design on the device: delayed templates, chain, covariance, batched Jacobi SVD (micloc_design_vectors_f64)
+        beamf.design_from_template(chirp_template(fs, freq_range), doa_list[:8], svd="device")  # warm-up (allocations, module load)
+        torch.cuda.synchronize()
+        t_design = time.perf_counter()
         bf_mat = beamf.design_from_template(chirp_template(fs, freq_range), doa_list, svd="device")
+        torch.cuda.synchronize()
+        t_design = time.perf_counter() - t_design
 
     # test signals (target_snn_localization.py:435-455 / :148-154,213-245): synthetic, generated here, noise drawn on the device
     if cfg == "speech":
@@ -193,7 +199,7 @@ def build_workload(args, rank, device):
         plan.set_encoder_chunk(args.encoder_chunk)
     return dict(beamf=beamf, plan=plan, x=x, doa=torch.from_numpy(doa).to(device), doa_list=torch.from_numpy(doa_list).to(device),
                 bf_mat=bf_mat, nir=nir, snr_groups=groups, fs=fs, encoder_chunk=args.encoder_chunk,
-                template=(time_test, sig_test), snr_db=snr_db, rank=rank)
+                template=(time_test, sig_test), snr_db=snr_db, rank=rank, design_seconds=t_design)
 
 
 def make_step(wl, nstreams, variants=True):
@@ -752,7 +758,9 @@ def run(args):
             "config": {"workload": f"{names[args.config]}: {M}-mic, {wl['fs'] // 1000} kHz, T={T}, {B} trials/GPU/step, "
                                    f"{G}-DoA grid, bipolar RZCC" + (", bf_mat designed on device from the 1 s chirp" if args.config != "stress" else ""),
                        "trials_per_gpu": B, "frames_per_trial": T, "num_mic": M, "num_doa": G, "mic_samples_per_s": value * M,
-                       "parallelism": f"trial-sharded x{group_size}", "hip_streams": nstreams, "hip_graphs": True},
+                       "parallelism": f"trial-sharded x{group_size}", "hip_streams": nstreams, "hip_graphs": True,
+                       "design_from_template_seconds": wl["design_seconds"],
+                       "design_note": "bf_mat from the 1 s chirp for all G DoAs, entirely on the device (reference: 24.8 s for 449 DoAs on 8 vCPUs, SURVEY 6)"},
             "mae_deg_per_snr": [float(v) for v in (mae * 180 / np.pi).cpu().numpy()],
             "value_e2e": e2e["value"],
             "e2e": e2e,
