@@ -16,11 +16,11 @@
 //     in-order vmcnt queue (measured: a conditional global store in the serial loop cost a vmcnt(0) drain
 //     per chunk and 2.5x the loop time).
 //   * FILTER wave: DF2T recurrence + cumulative sum, in place in LDS.
-//   * DETECT wave: branch-free local-extremum detector.  Per step two fp64 compares give wave-level
-//     lane masks (rise / fall); the direction of the last strict change lives in lane masks too and is
-//     updated on the SALU; a maximum completes when c falls after a rise (scipy _local_maxima_1d:
-//     plateau -> midpoint, edges never peaks), minima mirror it.  Candidates are written unconditionally
-//     into a per-lane LDS ring; the write index only advances on an event (add-with-carry of the mask).
+//   * DETECT wave: bit-parallel local-extremum detector.  Two fp64 compares per step, each folded into a per-lane 16-bit
+//     word (rise / fall bits of the tile) by one add-with-carry; the direction of the last strict change before every
+//     step is the carry chain of ONE addition on those words, a maximum completes where the sum falls after a rise
+//     (scipy _local_maxima_1d: plateau -> midpoint, edges never peaks), minima mirror it; the two or so events of a
+//     tile are appended to a per-lane LDS ring in a short loop.
 //   * SELECT waves (one per polarity): scipy's _select_by_peak_distance (greedy by descending priority,
 //     later peak wins ties) only couples peaks closer than `distance`, so the candidate list splits into
 //     independent clusters at every same-polarity gap >= distance.  After each tile the wave walks the NEW
@@ -34,6 +34,9 @@
 #include "micloc_internal.h"
 
 #include <type_traits>
+
+// (the instantiations that also store the filtered signal are limited by LDS, not by the waves-per-SIMD hint below)
+#pragma clang diagnostic ignored "-Wpass-failed"
 
 namespace micloc {
 
@@ -80,9 +83,9 @@ __device__ __forceinline__ void pin_coef(const IirCoef &coef)
 // Greedy min-distance selection inside one cluster.  Entries live at list indices s, s+stride, ... < e;
 // word >> 1 = position (the low bit is free for the caller), complemented once decided; priority = sgn * value.
 // `at(i)` maps a list index to storage.
-template <typename WordAt, typename ValAt>
-__device__ __forceinline__ void resolve_cluster(int s, int e, int stride, int w, int8_t mark, int8_t *sp, int C,
-                                                WordAt word_at, ValAt val_at, double sgn)
+template <typename WordAt, typename ValAt, typename Emit>
+__device__ __forceinline__ void resolve_cluster(int s, int e, int stride, int w, Emit emit, WordAt word_at, ValAt val_at,
+                                                double sgn)
 {
     int remaining = (e - s + stride - 1) / stride;
     while (remaining > 0) {
@@ -99,7 +102,7 @@ __device__ __forceinline__ void resolve_cluster(int s, int e, int stride, int w,
         }
         const int wb = *word_at(best);
         const int pb = wb >> 1;
-        sp[(size_t)pb * C] = mark;
+        emit(pb);
         *word_at(best) = ~wb;
         --remaining;
         for (int k = best - stride; k >= s; k -= stride) {
@@ -125,128 +128,14 @@ __device__ __forceinline__ void resolve_cluster(int s, int e, int stride, int w,
 
 constexpr int RZ_MT = 16;  // time steps per tile of the wave pipeline (one barrier per tile)
 
-// ---- detect-stage helpers: per-lane updates driven by wave-level lane masks (SGPR pairs) ------------------------
-// v += 1 in the lanes of m (one VALU instruction: add with carry-in)
-__device__ __forceinline__ int add_lane_mask(int v, uint64_t m)
+// ---- detect-stage helper ------------------------------------------------------------------------------------------
+// v = 2 v + (lane's bit of m): one step of building a per-lane bit word out of wave-level compare masks (one VALU
+// instruction: add with carry-in)
+__device__ __forceinline__ int add_lane_mask2(int v, uint64_t m)
 {
     uint64_t carry_out;
-    asm("v_addc_co_u32_e64 %0, %1, %0, 0, %2" : "+v"(v), "=s"(carry_out) : "s"(m));
+    asm("v_addc_co_u32_e64 %0, %1, %0, %0, %2" : "+v"(v), "=s"(carry_out) : "s"(m));
     return v;
-}
-// v = J in the lanes of m (J an inline constant: the lane mask is the only scalar operand)
-template <int J>
-__device__ __forceinline__ int set_lane_mask(int v, uint64_t m)
-{
-    asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(v) : "n"(J), "s"(m));
-    return v;
-}
-
-struct DetectState {
-    double prev;    // previous value of the cumulative sum (NaN before the first sample: no event at t = 0)
-    int lrel;       // time of the last strict change, relative to the current tile
-    int n;          // candidates appended so far
-    uint64_t dpos;  // lanes whose last strict change was a rise
-    uint64_t dneg;  // ... a fall
-    uint64_t ffall; // lanes whose FIRST strict change was a fall (their first candidate is a minimum)
-};
-
-// One time step of the branch-free local-extremum detector (scipy _local_maxima_1d semantics, see the file header).
-// 8 VALU instructions: two fp64 compares, the append counter, the plateau edge, the candidate word and three for the
-// ring address; everything that concerns the direction of the last change is SALU work on lane masks.
-template <int J, typename RingP, typename RingV>
-__device__ __forceinline__ void detect_step(DetectState &d, double c, int word_base, uint64_t bip, uint64_t live, int lane,
-                                            RingP &ringP, RingV &ringV)
-{
-    const uint64_t rise = __builtin_amdgcn_fcmp(c, d.prev, 2);  // ordered >
-    const uint64_t fall = __builtin_amdgcn_fcmp(c, d.prev, 4);  // ordered <
-    const uint64_t ev = ((fall & d.dpos) | (bip & rise & d.dneg)) & live;
-    constexpr int RING = (int)(sizeof(ringP) / sizeof(ringP[0]));
-    const int slot = d.n & (RING - 1);  // unconditional store; consumed only if n advances
-    ringP[slot][lane] = d.lrel + word_base + J;  // left + t - 1; position = word >> 1 (plateau midpoint)
-    ringV[slot][lane] = d.prev;                  // plateau value; minima negate it when they compare
-    d.n = add_lane_mask(d.n, ev);
-    d.ffall |= fall & ~(d.dpos | d.dneg);
-    d.lrel = set_lane_mask<J>(d.lrel, rise | fall);
-    d.dpos = rise | (d.dpos & ~fall);
-    d.dneg = fall | (d.dneg & ~rise);
-    d.prev = c;
-}
-
-template <int J0, int U, typename RingP, typename RingV>
-__device__ __forceinline__ void detect_append(DetectState &d, const double (&c)[RZ_MT], const uint64_t (&chg)[8],
-                                              const uint64_t (&ev)[8], int word_base, int lane, RingP &ringP, RingV &ringV)
-{
-    if constexpr (U < 8) {
-        constexpr int J = J0 + U;
-        constexpr int RING = (int)(sizeof(ringP) / sizeof(ringP[0]));
-        const int slot = d.n & (RING - 1);  // unconditional store; consumed only if n advances
-        ringP[slot][lane] = d.lrel + word_base + J;  // left + t - 1; position = word >> 1 (plateau midpoint)
-        ringV[slot][lane] = J ? c[J ? J - 1 : 0] : d.prev;  // plateau value; minima negate it when they compare
-        d.n = add_lane_mask(d.n, ev[U]);
-        d.lrel = set_lane_mask<J>(d.lrel, chg[U]);
-        detect_append<J0, U + 1>(d, c, chg, ev, word_base, lane, ringP, ringV);
-    }
-}
-
-// Full tile in three phases per half of 8 steps, so that the VALU -> SALU -> VALU round trip of a step (compare, mask
-// logic, per-lane update) is paid once per phase instead of once per step:
-//   A  16 fp64 compares (independent: rise / fall of step j need only c[j-1], c[j])            -> lane masks
-//   B  the direction recurrences and the event masks, pure SALU
-//   C  per-lane appends: ring address, candidate word + value, counter, plateau edge
-// MODE 0: general (some lane has not seen a strict change yet; polarity switch is a run-time mask)
-// MODE 1 / 2: every lane has a direction, so "last change was a fall" is simply ~dpos; bipolar / unipolar fixed at
-//             compile time.  6 instead of 12 SALU instructions per step -- they count: a single wave issues at most one
-//             instruction of ANY kind every ~4 cycles, and this wave is one stage of a latency-bound pipeline.
-template <int J0, int MODE, typename RingP, typename RingV>
-__device__ __forceinline__ void detect_half(DetectState &d, const double (&c)[RZ_MT], int word_base, uint64_t bip,
-                                            uint64_t live, int lane, RingP &ringP, RingV &ringV)
-{
-    uint64_t rise[8], fall[8], ev[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        const double p = (J0 + u) ? c[(J0 + u ? J0 + u : 1) - 1] : d.prev;
-        rise[u] = __builtin_amdgcn_fcmp(c[J0 + u], p, 2);  // ordered >
-        fall[u] = __builtin_amdgcn_fcmp(c[J0 + u], p, 4);  // ordered <
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        if (MODE == 0) {
-            ev[u] = ((fall[u] & d.dpos) | (bip & rise[u] & d.dneg)) & live;
-            d.ffall |= fall[u] & ~(d.dpos | d.dneg);
-            d.dpos = rise[u] | (d.dpos & ~fall[u]);
-            d.dneg = fall[u] | (d.dneg & ~rise[u]);
-        } else {
-            ev[u] = (MODE == 1 ? ((fall[u] & d.dpos) | (rise[u] & ~d.dpos)) : (fall[u] & d.dpos)) & live;
-            d.dpos = rise[u] | (d.dpos & ~fall[u]);
-        }
-        rise[u] |= fall[u];  // strict change
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    detect_append<J0, 0>(d, c, rise, ev, word_base, lane, ringP, ringV);
-}
-
-template <int MODE, typename RingP, typename RingV>
-__device__ __forceinline__ void detect_full(DetectState &d, const double (&c)[RZ_MT], int word_base, uint64_t bip,
-                                            uint64_t live, int lane, RingP &ringP, RingV &ringV)
-{
-    detect_half<0, MODE>(d, c, word_base, bip, live, lane, ringP, ringV);
-    detect_half<8, MODE>(d, c, word_base, bip, live, lane, ringP, ringV);
-    if (MODE != 0) d.dneg = ~d.dpos;
-    d.prev = c[RZ_MT - 1];
-}
-
-// last, partial tile of a stream
-template <int J, typename Tile, typename RingP, typename RingV>
-__device__ __forceinline__ void detect_partial(DetectState &d, const Tile &tile, int steps, int word_base, uint64_t bip,
-                                               uint64_t live, int lane, RingP &ringP, RingV &ringV)
-{
-    if constexpr (J < RZ_MT) {
-        if (J < steps) {  // uniform
-            detect_step<J>(d, tile[J][lane], word_base, bip, live, lane, ringP, ringV);
-            detect_partial<J + 1>(d, tile, steps, word_base, bip, live, lane, ringP, ringV);
-        }
-    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -630,8 +519,11 @@ struct RzStream {
 // RING: candidate ring entries per stream (power of two).  A whole tile of appends (RZ_MT) is reserved before every tile, so
 // the usable depth is RING - RZ_MT.  Measured on the speech workload: RING = 32 (three workgroups per CU instead of two)
 // overflows so often that the unit fallback takes 3x the time saved -- 64 it is.
-template <int N, bool WANT_PRE, bool WANT_SPIKES, int RING = RZ_RING>
-__global__ __launch_bounds__(320) void bandpass_rzcc_fast_kernel(const double *__restrict__ h,
+// WRITER: a seventh wave that stores the spikes (see spq below).  It pays off where the launch is occupancy bound (chunked
+// launches: speech 13.1 -> 12.2 ms for scan + chunks) and costs where one workgroup per CU runs at the pace of its slowest
+// wave (sweep shape: 0.417 -> 0.445 ms), so only chunked launches carry it.
+template <int N, bool WANT_PRE, bool WANT_SPIKES, int RING = RZ_RING, bool WRITER = false>
+__global__ __launch_bounds__(448, 4) void bandpass_rzcc_fast_kernel(const double *__restrict__ h,
                                                                   double *__restrict__ pre,
                                                                   int8_t *__restrict__ spikes,
                                                                   int *__restrict__ flag_count,
@@ -651,9 +543,21 @@ __global__ __launch_bounds__(320) void bandpass_rzcc_fast_kernel(const double *_
     __shared__ int ovPub[64];      // the detect wave found the ring full (or the checkpoint unusable): unit flagged
     __shared__ int leftPub[64];    // time of the last strict change when the detect wave stopped
     __shared__ int oldPub[2][64];  // per polarity: oldest ring entry the select wave still needs
+    // Spike positions on their way to the raster.  A kept peak becomes one byte store into [B][T][C]: 64 lanes, 64 different
+    // cache lines per instruction, in the middle of the select waves' dependent walk -- measured 0.13 of the kernel's 0.41 ms
+    // on the sweep shape.  The select waves only queue the positions; a WRITER wave stores them one tile later, off the
+    // critical path.  A lane that finds its queue full (a long cluster resolved at once) stores directly.
+    constexpr int QN = 8;
+    __shared__ int spq[WRITER ? 2 : 1][WRITER ? QN : 1][64];
+    __shared__ int qwPub[2][64];
 
-    // 0: loader, 1: filter, 2: detect, 3: select maxima, 4: select minima (wave 4 shares its SIMD with the loader)
-    const int wave = threadIdx.x >> 6;
+    // 0: loader, 1: filter, 2: detect, 3: select maxima, 4: select minima.  Launches that do not store the filtered signal
+    // have a second loader wave in front (even / odd tiles, four tiles of global loads in flight instead of two: with
+    // one loader the pipeline ran at the pace of the memory latency).
+    constexpr bool LD2 = WANT_SPIKES && !WANT_PRE;
+    static_assert(!WRITER || LD2, "the writer wave exists in the spikes-only launches");
+    const int wave_hw = threadIdx.x >> 6;
+    const int wave = LD2 ? (wave_hw == 0 ? 0 : wave_hw - 1) : wave_hw;
     const int lane = threadIdx.x & 63;
     const int blk = blockIdx.x % nblk;
     const int p = blockIdx.x / nblk;
@@ -667,7 +571,16 @@ __global__ __launch_bounds__(320) void bandpass_rzcc_fast_kernel(const double *_
     const int lane_c = active ? lane_g : nlanes - 1;  // clamped: inactive lanes shadow the last stream, results unused
     const size_t nl = (size_t)nlanes;
 
-    if (wave == 0) {
+    if (LD2) {
+        if (wave_hw == 0) {
+            rz_loader_np<2, 0>(X, h, xin, base, nlanes, C, T, Ts, M, shift, m_lo, sp_.m_hi, NSTEP, lane);
+            return;
+        }
+        if (wave_hw == 1) {
+            rz_loader_np<2, 1>(X, h, xin, base, nlanes, C, T, Ts, M, shift, m_lo, sp_.m_hi, NSTEP, lane);
+            return;
+        }
+    } else if (wave == 0) {
         rz_loader<WANT_PRE>(X, Y, h, pre, xin, base, nlanes, C, T, Ts, M, shift, m_lo, sp_.m_hi, NSTEP, lane);
         return;
     }
@@ -703,7 +616,26 @@ __global__ __launch_bounds__(320) void bandpass_rzcc_fast_kernel(const double *_
                         X[buf][j][lane] = cs;
                     }
                 };
-                if (steps == RZ_MT) {
+                if (steps == RZ_MT && WANT_SPIKES && !WANT_PRE) {
+                    // the whole tile into registers with hand-issued reads and ONE wait (the compiler's own placement waits
+                    // for every pair of reads in the middle of the dependent arithmetic), then arithmetic, then the stores
+                    double xr[RZ_MT];
+                    const unsigned addr = (unsigned)(size_t)(&X[buf][0][lane]);
+#pragma unroll
+                    for (int j = 0; j < RZ_MT; ++j)
+                        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(xr[j]) : "v"(addr), "n"(j * RZ_ROW * 8));
+                    asm volatile("s_waitcnt lgkmcnt(0)"
+                                 : "+v"(xr[0]), "+v"(xr[1]), "+v"(xr[2]), "+v"(xr[3]), "+v"(xr[4]), "+v"(xr[5]), "+v"(xr[6]), "+v"(xr[7]),
+                                   "+v"(xr[8]), "+v"(xr[9]), "+v"(xr[10]), "+v"(xr[11]), "+v"(xr[12]), "+v"(xr[13]), "+v"(xr[14]),
+                                   "+v"(xr[15]));
+#pragma unroll
+                    for (int j = 0; j < RZ_MT; ++j) {
+                        cs = cs + iir.step(coef, xr[j]);
+                        xr[j] = cs;
+                    }
+#pragma unroll
+                    for (int j = 0; j < RZ_MT; ++j) X[buf][j][lane] = xr[j];
+                } else if (steps == RZ_MT) {
 #pragma unroll
                     for (int j = 0; j < RZ_MT; ++j) one(j);
                 } else {
@@ -724,43 +656,74 @@ __global__ __launch_bounds__(320) void bandpass_rzcc_fast_kernel(const double *_
     int *const sib = ss.on ? ss.si + (size_t)blk * 12 * 64 : nullptr;
     const int tb0 = ss.on ? ss.t_base : 0;  // absolute time of local frame 0
 
+    if (WRITER && wave == 5) {
+        // ------------------------------------ writer ---------------------------------------------------
+        const int bw = lane_c / C;
+        int8_t *spw = spikes + (size_t)bw * (ss.on ? ss.Ttot : T) * C + (lane_c - bw * C);
+        int rd0 = 0, rd1 = 0;
+        auto drain1 = [&](int &rd, auto polc) {
+            constexpr int pol = decltype(polc)::value;
+            const int wr = qwPub[pol][lane];
+            while (__any(rd < wr)) {
+                if (rd < wr) {
+                    const int pos = spq[WRITER ? pol : 0][WRITER ? (rd & (QN - 1)) : 0][lane];
+                    if (active) spw[(size_t)pos * C] = pol ? (int8_t)-1 : (int8_t)1;
+                    ++rd;
+                }
+            }
+        };
+        auto drain = [&]() {
+            drain1(rd0, std::integral_constant<int, 0>{});
+            if (bipolar) drain1(rd1, std::integral_constant<int, 1>{});
+        };
+        qwPub[0][lane] = 0;
+        qwPub[1][lane] = 0;
+        __syncthreads();
+        for (int k = 0; k < NSTEP; ++k) {
+            if (k >= 3) drain();  // what the select waves published at the last barrier
+            __syncthreads();
+        }
+        drain();
+        return;
+    }
+
     if (wave == 2) {
         // ------------------------------------ detect ---------------------------------------------------
         // A maximum completes when c falls after a rise: plateau [left, t-1] -> position (left+t-1)>>1, priority =
         // plateau value = prev.  Minima mirror this (priority -prev).  Maxima and minima alternate strictly, so both
         // share one candidate list and the polarity of candidate i is (first polarity) ^ (i & 1).
-        DetectState d;
-        d.prev = __builtin_nan("");
-        d.lrel = 0;
-        d.n = 0;
-        d.dpos = d.dneg = d.ffall = 0;
-        uint64_t live = ~0ull;  // lanes that may still append (ring space checked before every tile)
+        //
+        // Bit-parallel per lane: the 16 steps of a tile give two 16-bit words per lane, R (the sum rose at step j) and F (it
+        // fell) -- two fp64 compares per step, each folded into its word by one add-with-carry (word = 2 word + mask bit).
+        // Everything sequential in the old formulation (direction of the last strict change, plateau start) is then a
+        // handful of integer operations on whole words: the direction recurrence D_{j+1} = R_j | (D_j & ~(R_j | F_j)) is
+        // the carry chain of ONE addition, events are F & D (maxima) and R & ~D & "moved before" (minima), and the few
+        // events of a tile (about two) are appended in a short loop instead of sixteen unconditional ring writes.
+        // About 10 instead of 17 instructions per step, no scalar-unit dependency chains.
+        double prev = __builtin_nan("");  // previous value of the running sum (NaN: no event at t = 0)
+        int left = tb0;                   // absolute time of the last strict change
+        int n = 0;                        // candidates appended so far
+        int dir = 0;                      // direction of the last strict change: 0 none yet, 1 rise, 2 fall
+        int ffall = 0;                    // the stream's FIRST strict change was a fall (its first candidate is a minimum)
+        bool livel = true;                // this lane may still append (ring space checked before every tile)
         if (p > 0) {
             // detector state at the chunk start, from the scan's checkpoint
-            const int dir = cki[((size_t)(p - 1) * 3 + 0) * nl + lane_c];
-            const int left = cki[((size_t)(p - 1) * 3 + 1) * nl + lane_c];
-            d.prev = ckd[((size_t)(p - 1) * N + (N - 1)) * nl + lane_c];
-            d.lrel = left - m_lo * RZ_MT;
-            d.dpos = __ballot(dir == RZ_DIR_RISE);
-            d.dneg = __ballot(dir == RZ_DIR_FALL);
-            d.ffall = d.dneg;
-            live = ~__ballot(dir == RZ_DIR_UNKNOWN);
+            const int dcode = cki[((size_t)(p - 1) * 3 + 0) * nl + lane_c];
+            left = cki[((size_t)(p - 1) * 3 + 1) * nl + lane_c];
+            prev = ckd[((size_t)(p - 1) * N + (N - 1)) * nl + lane_c];
+            dir = dcode == RZ_DIR_RISE ? 1 : (dcode == RZ_DIR_FALL ? 2 : 0);
+            ffall = dir == 2;
+            livel = dcode != RZ_DIR_UNKNOWN;
         }
-        const uint64_t bip = bipolar ? ~0ull : 0ull;
-        nPub[lane] = 0;
-        polPub[lane] = 0;
         if (ss.on && ss.resume) {
             double *const sdb = ss.sd + (size_t)blk * (N + 1) * 64;
-            d.prev = sdb[N * 64 + lane];
-            d.lrel = sib[0 * 64 + lane] - tb0;  // relative to the first tile of this launch
-            d.n = sib[1 * 64 + lane];
+            prev = sdb[N * 64 + lane];
+            left = sib[0 * 64 + lane];
+            n = sib[1 * 64 + lane];
             const int bits = sib[2 * 64 + lane];
-            d.dpos = __ballot(bits & 1);
-            d.dneg = __ballot(bits & 2);
-            d.ffall = __ballot(bits & 4);
-            live = __ballot(bits & 8);
-            nPub[lane] = d.n;
-            polPub[lane] = (bits >> 2) & 1;
+            dir = (bits & 1) ? 1 : ((bits & 2) ? 2 : 0);
+            ffall = (bits >> 2) & 1;
+            livel = (bits >> 3) & 1;
             // the candidate ring with the clusters that were still open
             const double *rv = ss.ringV + (size_t)blk * RZ_RING * 64;
             const int *rp = ss.ringP + (size_t)blk * RZ_RING * 64;
@@ -769,7 +732,9 @@ __global__ __launch_bounds__(320) void bandpass_rzcc_fast_kernel(const double *_
                 ringP[e][lane] = rp[e * 64 + lane];
             }
         }
-        ovPub[lane] = (int)((~live >> lane) & 1);
+        nPub[lane] = n;
+        polPub[lane] = ffall;
+        ovPub[lane] = livel ? 0 : 1;
         __syncthreads();
         for (int k = 0; k < NSTEP; ++k) {
             if (k >= 1 && k <= NM) {
@@ -781,47 +746,71 @@ __global__ __launch_bounds__(320) void bandpass_rzcc_fast_kernel(const double *_
                 {
                     const int o0 = oldPub[0][lane], o1 = oldPub[1][lane];
                     const int oldest = bipolar ? (o0 < o1 ? o0 : o1) : o0;
-                    // After this tile at most RZ_RING - 1 entries may be pending, so that one slot -- the one in front
-                    // of the oldest pending entry -- is always free: a lane that has to stop appending parks its
-                    // (unconditional) ring writes there, where the select waves never look.
-                    const uint64_t full = __ballot(d.n + RZ_MT - oldest > RING - 1);
-                    if (full & live) {  // uniform
-                        d.n = ((full >> lane) & 1) ? oldest + RING - 1 : d.n;
-                        live &= ~full;
-                        ovPub[lane] = (int)((~live >> lane) & 1);
+                    if (livel && n + RZ_MT - oldest > RING - 1) {
+                        livel = false;
+                        ovPub[lane] = 1;
                     }
                 }
-                // left + t - 1 = (tbase + lrel) + (tbase + j) - 1
-                if (steps == RZ_MT) {
-                    double c[RZ_MT];
+                // ---- A: rise / fall words (bit j = step j of the tile) ----
+                double c[RZ_MT];
 #pragma unroll
-                    for (int j = 0; j < RZ_MT; ++j) c[j] = X[m % 3][j][lane];
-                    if ((d.dpos | d.dneg) != ~0ull)  // uniform
-                        detect_full<0>(d, c, 2 * tbase - 1, bip, live, lane, ringP, ringV);
-                    else if (bipolar)
-                        detect_full<1>(d, c, 2 * tbase - 1, bip, live, lane, ringP, ringV);
-                    else
-                        detect_full<2>(d, c, 2 * tbase - 1, bip, live, lane, ringP, ringV);
-                } else {
-                    detect_partial<0>(d, X[m % 3], steps, 2 * tbase - 1, bip, live, lane, ringP, ringV);
+                for (int jj = 0; jj < RZ_MT; ++jj) c[jj] = X[m % 3][jj][lane];  // (rows past a ragged end: masked below)
+                unsigned Rw = 0, Fw = 0;
+#pragma unroll
+                for (int jj = RZ_MT - 1; jj >= 0; --jj) {
+                    const double pj = jj ? c[jj ? jj - 1 : 0] : prev;
+                    Rw = (unsigned)add_lane_mask2((int)Rw, __builtin_amdgcn_fcmp(c[jj], pj, 2));  // ordered >
+                    Fw = (unsigned)add_lane_mask2((int)Fw, __builtin_amdgcn_fcmp(c[jj], pj, 4));  // ordered <
                 }
+                const unsigned vmask = (1u << steps) - 1u;
+                Rw &= vmask;
+                Fw &= vmask;
+                // ---- B: direction before every step, events ----
+                const unsigned Sw = Rw | Fw;                        // strict changes
+                const unsigned Aw = (Rw | ~Sw) & 0xFFFFu;           // generate | propagate
+                const unsigned Dw = (Aw + Rw + (dir == 1 ? 1u : 0u)) ^ Aw ^ Rw;  // bit j: the last change before step j was a rise
+                const unsigned low = Sw & (0u - Sw);                // lowest strict change of the tile
+                const unsigned Hw = dir != 0 ? 0xFFFFu : (Sw ? (~(low | (low - 1u)) & 0xFFFFu) : 0u);  // a change happened before step j
+                unsigned Ew = (Fw & Dw) | (bipolar ? (Rw & ~Dw & Hw) : 0u);
+                Ew = livel ? Ew : 0u;
+                if (dir == 0 && Sw) ffall = (Fw & low) ? 1 : 0;
+                // ---- C: append the events (time order; maxima and minima alternate) ----
+                while (__any(Ew != 0u)) {
+                    if (Ew) {
+                        const int je = __builtin_ctz(Ew);
+                        Ew &= Ew - 1u;
+                        const unsigned below = Sw & ((1u << je) - 1u);
+                        const int lf = below ? tbase + (31 - __builtin_clz(below)) : left;
+                        // plateau value: the sum just before the step that completes the candidate
+                        const double val = je ? *reinterpret_cast<const double *>(reinterpret_cast<const char *>(&X[m % 3][0][lane]) +
+                                                                                 (size_t)(je - 1) * RZ_ROW * 8)
+                                              : prev;
+                        const int slot = n & (RING - 1);
+                        ringP[slot][lane] = lf + tbase + je - 1;  // left + t - 1; position = word >> 1 (plateau midpoint)
+                        ringV[slot][lane] = val;
+                        ++n;
+                    }
+                }
+                // ---- D: state after the tile ----
+                if (Sw) {
+                    left = tbase + (31 - __builtin_clz(Sw));
+                    dir = (Dw >> RZ_MT) & 1u ? 1 : 2;
+                }
+                prev = steps == RZ_MT ? c[RZ_MT - 1] : X[m % 3][steps - 1][lane];
                 if (k == NM) {
                     // time of the last strict change; a lane that has not moved at all yet cannot complete a candidate
                     // whose plateau starts before the first step after this chunk
-                    const bool hasdir = ((d.dpos | d.dneg) >> lane) & 1;
-                    leftPub[lane] = hasdir ? d.lrel + tbase : tbase + RZ_MT + 1;
+                    leftPub[lane] = dir != 0 ? left : tbase + RZ_MT + 1;
                 }
                 if (k == NM && ss.on) {
                     double *const sdb = ss.sd + (size_t)blk * (N + 1) * 64;
-                    sdb[N * 64 + lane] = d.prev;
-                    sib[0 * 64 + lane] = d.lrel + tbase;  // absolute time of the last strict change
-                    sib[1 * 64 + lane] = d.n;
-                    sib[2 * 64 + lane] = (int)((d.dpos >> lane) & 1) | ((int)((d.dneg >> lane) & 1) << 1) | ((int)((d.ffall >> lane) & 1) << 2) |
-                                         ((int)((live >> lane) & 1) << 3);
+                    sdb[N * 64 + lane] = prev;
+                    sib[0 * 64 + lane] = left;  // absolute time of the last strict change
+                    sib[1 * 64 + lane] = n;
+                    sib[2 * 64 + lane] = (dir == 1 ? 1 : 0) | (dir == 2 ? 2 : 0) | (ffall << 2) | ((livel ? 1 : 0) << 3);
                 }
-                d.lrel -= RZ_MT;
-                nPub[lane] = d.n;
-                polPub[lane] = (int)((d.ffall >> lane) & 1);
+                nPub[lane] = n;
+                polPub[lane] = ffall;
             }
             __syncthreads();
         }
@@ -847,13 +836,22 @@ __global__ __launch_bounds__(320) void bandpass_rzcc_fast_kernel(const double *_
     const int own_lo = sp_.own_lo, own_hi = sp_.own_hi;
     auto word_at = [&](int i) { return &ringP[i & (RING - 1)][lane]; };
     auto val_at = [&](int i) { return &ringV[i & (RING - 1)][lane]; };
+    int widx = 0, w1 = 0, w2 = 0;  // queue write index now / at the last barrier / at the one before
+    auto emit = [&](int pos) {
+        if (WRITER && widx - w2 < QN) {
+            spq[WRITER ? mypol : 0][WRITER ? (widx & (QN - 1)) : 0][lane] = pos;
+            ++widx;
+        } else {
+            sp[(size_t)pos * C] = mark;
+        }
+    };
     auto close_cluster = [&](int s, int e, int lastpos) {
         const int first = *word_at(s) >> 1;
         if (first < own_lo || first >= own_hi) return;  // the cluster belongs to a neighbouring chunk
         if (e - s <= stride)
-            sp[(size_t)lastpos * C] = mark;
+            emit(lastpos);
         else
-            resolve_cluster(s, e, stride, w, mark, sp, C, word_at, val_at, sgn);
+            resolve_cluster(s, e, stride, w, emit, word_at, val_at, sgn);
     };
     if (mypol == 0) deadPub[lane] = 0;
     oldPub[mypol][lane] = 0;
@@ -888,8 +886,15 @@ __global__ __launch_bounds__(320) void bandpass_rzcc_fast_kernel(const double *_
             // everything from the open cluster on must survive in the ring; without one, everything not yet examined
             oldPub[mypol][lane] = dead ? 0x7fffffff : (s_open >= 0 ? s_open : (i_next >= 0 ? i_next : 0));
         }
+        if (WRITER && mine) {
+            qwPub[mypol][lane] = widx;
+            w2 = w1;
+            w1 = widx;
+        }
         __syncthreads();
     }
+    // (clusters closed from here on -- end of the stream / chunk -- are stored directly: the writer has left its loop)
+    w2 = widx - QN;
     if (ss.on) {
         if (ovPub[lane]) dead = true;
         if (mine) {
@@ -1080,7 +1085,7 @@ __global__ __launch_bounds__(64) void rzcc_unit_fallback_kernel(const double *__
                         if (e - s <= stride)
                             sp[(size_t)plast * C] = mark;
                         else
-                            resolve_cluster(s, e, stride, w, mark, sp, C, word_at, val_at, 1.0);
+                            resolve_cluster(s, e, stride, w, [&](int pos) { sp[(size_t)pos * C] = mark; }, word_at, val_at, 1.0);
                     }
                     s = i;
                 }
@@ -1203,9 +1208,12 @@ static void launch_rz(const IirCoef &coef, const double *h, int nlanes, int C, i
     if (g.P > 1)
         hipLaunchKernelGGL((rzcc_scan_kernel<N>), dim3(nblk), dim3(192), 0, stream, h, coef, nlanes, C, T, Ts, xin, M, shift,
                            g, ckd, cki);
-    dim3 grid(nblk * g.P), block(spikes ? 320 : 128);
+    dim3 grid(nblk * g.P), block(spikes ? (pre ? 320 : (g.P > 1 ? 448 : 384)) : 128);
     if (pre && spikes)
         hipLaunchKernelGGL((bandpass_rzcc_fast_kernel<N, true, true>), grid, block, 0, stream, h, pre, spikes,
+                           flag_count, flag_list, coef, nlanes, C, T, Ts, w, bipolar, xin, M, shift, g, nblk, ckd, cki, RzStream{});
+    else if (spikes && g.P > 1)
+        hipLaunchKernelGGL((bandpass_rzcc_fast_kernel<N, false, true, RZ_RING, true>), grid, block, 0, stream, h, pre, spikes,
                            flag_count, flag_list, coef, nlanes, C, T, Ts, w, bipolar, xin, M, shift, g, nblk, ckd, cki, RzStream{});
     else if (spikes)
         hipLaunchKernelGGL((bandpass_rzcc_fast_kernel<N, false, true>), grid, block, 0, stream, h, pre, spikes,
@@ -1277,7 +1285,7 @@ static void launch_rz_stream(const IirCoef &coef, const double *h, int nlanes, i
     g.Lt = (T + RZ_MT - 1) / RZ_MT;
     g.Vt = 1;
     g.V2t = 4;
-    hipLaunchKernelGGL((bandpass_rzcc_fast_kernel<N, false, true>), dim3(nblk), dim3(320), 0, stream, h, nullptr, spikes, nullptr, nullptr,
+    hipLaunchKernelGGL((bandpass_rzcc_fast_kernel<N, false, true>), dim3(nblk), dim3(384), 0, stream, h, nullptr, spikes, nullptr, nullptr,
                        coef, nlanes, C, T, Ts, w, bipolar, nullptr, 0, 0, g, nblk, nullptr, nullptr, ss);
 }
 
