@@ -4,6 +4,8 @@ Bars: bit-exact for the STHT output, the band-passed pre-encoder signal, the spi
 the beamformed signal y and the power within 1e-12 relative of the oracle (both fp64; they differ only
 in the order of the final time reduction) and within 1e-10 of the reference's golden vectors.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -467,7 +469,7 @@ def test_lif_beamform_stage_shapes_vs_oracle(torch, C, G, T, n_nir):
     np.testing.assert_array_equal(out_p["argmax"].cpu().numpy()[clear], out_y["argmax"].cpu().numpy()[clear])
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MICLOC_RANDOM_SEEDS", "12"))))
 def test_fused_pipeline_random_configurations_vs_oracle(torch, seed):
     """Randomised configurations (microphones, STHT length and tap pattern, filter order, robust width, polarity,
     neuron-kernel length, DoA count, trial length, signal character) through the fused pipeline against the oracle:
@@ -513,3 +515,11 @@ def test_fused_pipeline_random_configurations_vs_oracle(torch, seed):
         top = np.sort(pw)[-2:] if G > 1 else np.array([0.0, pw[0]])
         if top[1] - top[0] > 1e-9 * abs(top[1]):
             assert int(out["argmax"][i]) == ref["argmax"]
+    # the same batch with the time axis cut into chunks (scan checkpoints + one workgroup per chunk): identical spikes
+    if T >= 64:
+        lo = 16 * (-(-w // 16) + 1)
+        chunk = int(rng.integers(lo, max(lo + 1, T)))
+        p.set_encoder_chunk(chunk)
+        out2 = p.snn_pipeline(p.to_device(x), want_spikes=True, want_power=True)
+        np.testing.assert_array_equal(out2["spikes"].cpu().numpy(), out["spikes"].cpu().numpy(), err_msg=f"chunk={chunk} T={T} w={w}")
+        np.testing.assert_array_equal(out2["power"].cpu().numpy(), out["power"].cpu().numpy())
