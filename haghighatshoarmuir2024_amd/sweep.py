@@ -285,16 +285,21 @@ def xylo_target_sweep(demo, snr_db_vec=None, num_sim=100, seed=0, mode="parity",
 
 
 def main(argv=None):
-    """`python -m haghighatshoarmuir2024_amd.sweep`: the noisy-target accuracy sweep of
-    paper_plots/target_snn_localization.py:309-520 (design + 11 SNRs x num_sim trials), printing what the script prints."""
+    """`python -m haghighatshoarmuir2024_amd.sweep [--sweep noisy|speech|xylo]`: the accuracy sweeps of the paper scripts
+    (paper_plots/target_snn_localization.py:309-520 noisy target, :97-300 speech target; target_xylo_localization.py:540-608),
+    design + 11 SNRs x num_sim trials, printing what the scripts print (SNR vector and mean absolute errors in degrees)."""
     import argparse
     import os
 
     ap = argparse.ArgumentParser(description=main.__doc__)
-    ap.add_argument("--num-sim", type=int, default=100)
+    ap.add_argument("--sweep", choices=["noisy", "speech", "xylo"], default="noisy")
+    ap.add_argument("--num-sim", type=int, default=None, help="trials per SNR (scripts: 100 noisy / xylo, 20 speech)")
     ap.add_argument("--grid", type=int, default=64 * 7 + 1)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--mode", choices=["parity", "throughput"], default="parity")
+    ap.add_argument("--flac", default=None, help="speech sweep: the LibriSpeech utterance (84-121123-0020.flac of the reference's paper_plots/)")
+    ap.add_argument("--pcm-npz", default=None, help="speech sweep: an .npz with `pcm16` and `rate` instead of the FLAC file")
+    ap.add_argument("--svd", choices=["host", "device"], default="host", help="design_from_template decompositions")
     args = ap.parse_args(argv)
 
     from .array_geometry import CenterCircularArray
@@ -311,16 +316,32 @@ def main(argv=None):
     fs, freq_design = 48_000, 2000.0
     freq_range = [0.5 * freq_design, freq_design]
     tau = 1.0 / (2 * np.pi * freq_design)
-    beamf = SNNBeamformer(CenterCircularArray(radius=4.5e-2, num_mic=7), kernel_duration=10.0e-3, tau_vec=np.asarray([tau, tau]),
-                          freq_range=freq_range, fs=fs, bipolar_spikes=True)
-    time_temp = np.arange(0, 1.0, step=1 / fs)
-    period = time_temp[-1]
-    freq_inst = freq_range[0] + (freq_range[1] - freq_range[0]) * (time_temp % period) / period
-    sig_temp = np.sin(2 * np.pi * np.cumsum(freq_inst) / fs)
+    geometry = CenterCircularArray(radius=4.5e-2, num_mic=7)
     doa_list = np.linspace(-np.pi, np.pi, args.grid)
-    # the design is sharded over the DoA grid as well (one all-gather of the columns)
-    bf_mat = sharded_design(lambda doas: beamf.design_from_template((time_temp, sig_temp), doas), doa_list, rank, world)
-    res = noisy_target_sweep(beamf, bf_mat, doa_list, num_sim=args.num_sim, seed=args.seed, mode=args.mode, rank=rank, world_size=world)
+    if args.sweep == "xylo":
+        from .xylo_snn_localization import Demo
+
+        demo = Demo(geometry=geometry, freq_bands=[freq_range], doa_list=doa_list, recording_duration=0.25, bipolar_spikes=True, fs=fs)
+        res = xylo_target_sweep(demo, num_sim=args.num_sim or 100, seed=args.seed, mode=args.mode, rank=rank, world_size=world)
+    else:
+        beamf = SNNBeamformer(geometry, kernel_duration=10.0e-3, tau_vec=np.asarray([tau, tau]), freq_range=freq_range, fs=fs, bipolar_spikes=True)
+        time_temp = np.arange(0, 1.0, step=1 / fs)
+        period = time_temp[-1]
+        freq_inst = freq_range[0] + (freq_range[1] - freq_range[0]) * (time_temp % period) / period
+        sig_temp = np.sin(2 * np.pi * np.cumsum(freq_inst) / fs)
+        # the design is sharded over the DoA grid as well (one all-gather of the columns)
+        bf_mat = sharded_design(lambda doas: beamf.design_from_template((time_temp, sig_temp), doas, svd=args.svd), doa_list, rank, world)
+        if args.sweep == "speech":
+            if args.pcm_npz:
+                z = np.load(args.pcm_npz)
+                src = speech_source(fs, pcm16=z["pcm16"], rate=int(z["rate"]))
+            elif args.flac:
+                src = speech_source(fs, flac_path=args.flac)
+            else:
+                ap.error("--sweep speech needs --flac or --pcm-npz")
+            res = speech_target_sweep(beamf, bf_mat, doa_list, src, num_sim=args.num_sim or 20, seed=args.seed, mode=args.mode, rank=rank, world_size=world)
+        else:
+            res = noisy_target_sweep(beamf, bf_mat, doa_list, num_sim=args.num_sim or 100, seed=args.seed, mode=args.mode, rank=rank, world_size=world)
     if rank == 0:
         print(f"SNR: {res['snr_db_vec']}")
         print(f"Mean aboslute errors: {res['mae_deg']}")
