@@ -43,6 +43,40 @@ def test_plain_helpers_without_gpu():
     assert lib.micloc_rzcc_encode_f64(None, 1, 1, 1, 1, 0, None, None, 0, None) == _lib.MICLOC_ERR_INVALID
 
 
+def test_round2_entry_points_validate_before_touching_the_device():
+    """The entry points added in round 2 reject bad arguments on the host (no device call is made for them), and their
+    size queries are pure functions."""
+    lib = _lib.load()
+    vp = ctypes.c_void_p
+    one = vp(256)  # a non-null, 256-byte aligned dummy: validation must fail before it is ever dereferenced
+    assert lib.micloc_awgn_workspace_bytes(0, 10, 7) == 0
+    assert lib.micloc_awgn_workspace_bytes(3, 4799, 7) >= (3 * 5 + 3) * 8
+    assert lib.micloc_awgn_f64(None, 1, 1, 1, None, None, 0, 0, None, 0, None, 0, None) == _lib.MICLOC_ERR_INVALID
+    assert lib.micloc_awgn_f64(one, 1, 10, 7, None, None, 0, 0, None, 0, None, 0, None) == _lib.MICLOC_ERR_INVALID  # neither snr nor sigma
+    assert lib.micloc_awgn_f64(one, 1, 10, 7, one, None, 0, 0, None, 0, vp(8), 1 << 20, None) == _lib.MICLOC_ERR_WORKSPACE  # misaligned ws
+    assert lib.micloc_uniform_f64(None, 10, 0, 0, None, 0.0, 1.0, None) == _lib.MICLOC_ERR_INVALID
+    assert lib.micloc_counter_add_u32(None, 1, None) == _lib.MICLOC_ERR_INVALID
+    assert lib.micloc_synth_targets_f64(None, None) == _lib.MICLOC_ERR_INVALID
+    args = _lib.MiclocSynthArgs()
+    args.time = args.sig = args.slopes = args.x = 256
+    args.T, args.B, args.K, args.M, args.fs, args.mode = 100, 1, 1, 7, 48000.0, 2
+    assert lib.micloc_synth_targets_f64(ctypes.byref(args), None) == _lib.MICLOC_ERR_INVALID  # unknown mode
+    args.mode = 0
+    assert lib.micloc_synth_targets_f64(ctypes.byref(args), None) == _lib.MICLOC_ERR_INVALID  # neither delays nor (doa, geometry)
+    assert lib.micloc_delay_min_f64(one, 1, 1, 1, one, one, 7, 0.0, one, None) == _lib.MICLOC_ERR_INVALID  # speed must be positive
+    assert lib.micloc_design_vectors_f64(one, 1, 40, 1, 1e-8, one, 4, 0, None) == _lib.MICLOC_ERR_SHAPE      # more than 32 channels
+    assert lib.micloc_design_vectors_f64(one, 1, 13, 1, 1e-8, one, 4, 0, None) == _lib.MICLOC_ERR_SHAPE      # bipolar needs an even count
+    assert lib.micloc_design_vectors_f64(one, 3, 14, 1, 1e-8, one, 4, 2, None) == _lib.MICLOC_ERR_INVALID    # columns past G
+    assert lib.micloc_peak_location_i32(one, 1, 449, 1, 14, one, None) == _lib.MICLOC_ERR_INVALID            # even window (utils.py:100)
+    assert lib.micloc_peak_location_i32(one, 1, 20, 1, 15, one, None) == _lib.MICLOC_ERR_INVALID             # window > G / 2 (utils.py:105)
+    assert lib.micloc_xylo_upload(65, one, 10, one, one, one, one, 1 << 20, None) == _lib.MICLOC_ERR_SHAPE
+    assert lib.micloc_xylo_lif_resident_i16(one, 7, 1, 10, 28, 10, 0, 31, None, one, one, 1 << 20, None) == _lib.MICLOC_ERR_SHAPE  # Cin != 2 x ternary
+    assert lib.micloc_stream_state_bytes(None, 4) == 0
+    assert lib.micloc_stream_encode_f64(None, one, 1, 16, 16, 0, 1, 0, one, 16, one, 1 << 20, None) == _lib.MICLOC_ERR_INVALID
+    assert lib.micloc_stream_overflow(None, None, None) == _lib.MICLOC_ERR_INVALID
+    assert lib.micloc_lif_beamform_workspace_bytes(None, 1, 10) == 0
+
+
 def test_no_silent_cpu_fallback():
     import torch
 
