@@ -1,4 +1,6 @@
 """GPU tests of the reference call surface (micloc.*) and of the Monte-Carlo sweep against golden data."""
+import os
+
 import numpy as np
 import pytest
 
@@ -349,3 +351,29 @@ def test_pipeline_in_stages_equals_fused_call(cfg2):
     for bad in (0, 8, -1):
         with pytest.raises(_lib.MiclocError):
             p.snn_pipeline(x, stages=bad, out=out)
+
+
+def test_integration_md_ctypes_stub_runs(cfg2):
+    """The ctypes binding INTEGRATION.md shows a reference maintainer (section B) is executed verbatim -- only the library
+    path is made absolute -- and must return what the drop-in class returns."""
+    import re
+
+    from haghighatshoarmuir2024_amd import _lib
+
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(.*?)```", text, flags=re.S)
+    stub = [b for b in blocks if "micloc/_hip.py" in b]
+    assert len(stub) == 1
+    code = stub[0].replace('ctypes.CDLL("libmicloc_hip.so")', f'ctypes.CDLL("{_lib.LIB_PATH}")')
+    ns = {}
+    exec(compile(code, "INTEGRATION.md#B", "exec"), ns)
+    bf = make_beamformer()
+    z = golden("trials_cfg2.npz")
+    sig = z["sig_in"][0]
+    plan = ns["make_plan"](bf, 7)
+    y = ns["apply_to_signal"](plan, sig, cfg2["nir"], cfg2["bf_mat"])
+    want = bf.apply_to_signal(cfg2["bf_mat"], (np.arange(sig.shape[0]) / 48_000, sig))
+    assert y.shape == want.shape == (4799, 449)
+    np.testing.assert_array_equal(y, want)
+    with pytest.raises(ValueError):
+        ns["apply_to_signal"](plan, sig, cfg2["nir"], cfg2["bf_mat"][:10])
