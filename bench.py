@@ -724,7 +724,11 @@ def run(args):
             # latency-bound sequential stage: price it against HBM with its algorithmic bytes (8 B in per channel sample + 1 B spike out)
             achieved = frames_launch * (8 * C + C) / (st[dom] * 1e-3) / 1e9
             roof = dict(kernel=KERNEL_SYMBOL[dom], bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
-                        traffic=args.traffic_bytes)
+                        traffic=args.traffic_bytes,
+                        note="bit-exactness makes the time axis of every (trial, channel) stream a serial dependency chain (DF2T + running "
+                             "sum): this stage is bound by single-wave instruction issue x stream length, not by HBM; long streams are "
+                             "cut into chunks behind a serial scan (rzcc_scan_kernel, ~72 cycles per step on a handful of CUs) that "
+                             "overlaps the neighbouring steps' STHT / beamforming -- see DESIGN.md 4.2")
         else:
             achieved = frames_launch * flops[dom] / (st[dom] * 1e-3) / 1e12
             traffic = args.traffic_bytes
