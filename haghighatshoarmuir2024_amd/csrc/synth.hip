@@ -77,9 +77,19 @@ hipError_t launch_synth(const double *xp, const double *fp, const double *slopes
 }
 
 // general form: K targets, moving DoAs, per-sample gains, either delay source, both conventions
+constexpr int SY_DMAX = 512;  // delays of a constant-DoA trial kept in LDS (K x M)
+
 __global__ __launch_bounds__(256) void synth_targets_kernel(SynthArgs a)
 {
+    // constant DoAs: the K x M delays of the trial do not depend on time -- computed (one cos each) once per workgroup
+    // instead of once per output sample
+    __shared__ double dl[SY_DMAX];
     const int b = blockIdx.y;
+    const bool cached = !a.moving && a.K * a.M <= SY_DMAX;
+    if (cached) {
+        for (int e = threadIdx.x; e < a.K * a.M; e += 256) dl[e] = mic_delay(a, b, e / a.M, 0, e % a.M);
+        __syncthreads();
+    }
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;  // flat (t, m)
     if (idx >= (size_t)a.T * a.M) return;
     const int t = (int)(idx / a.M);
@@ -89,7 +99,7 @@ __global__ __launch_bounds__(256) void synth_targets_kernel(SynthArgs a)
     const double shift = a.shift ? a.shift[b] : 0.0;
     double acc = 0.0;
     for (int k = 0; k < a.K; ++k) {
-        double d = mic_delay(a, b, k, t, m);
+        double d = cached ? dl[k * a.M + m] : mic_delay(a, b, k, t, m);
         double x;
         if (a.mode == 0) {
             if (a.shift) d = d - shift;  // delays - delays.min()  (snn_beamformer.py:257)
