@@ -11,11 +11,14 @@ using namespace micloc;
 
 static thread_local int g_last_hip = 0;
 
+// (a failed runtime call also leaves its code in HIP's sticky "last error": clear it, or the next, unrelated launch
+// check -- hipGetLastError() after a successful launch -- would report it again)
 #define HIP_TRY(expr)                   \
     do {                                \
         hipError_t _e = (expr);         \
         if (_e != hipSuccess) {         \
             g_last_hip = (int)_e;       \
+            (void)hipGetLastError();    \
             return MICLOC_ERR_HIP;      \
         }                               \
     } while (0)
