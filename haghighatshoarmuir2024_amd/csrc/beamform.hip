@@ -18,9 +18,10 @@
 //      HBM when the caller asks for it (API parity with apply_to_signal).
 //
 // Three kernels share these steps and differ in what a wave keeps stationary:
-//   beamform_ws_kernel    bf_mat fragments in registers, membrane fragments parked in LDS   (<= 16 channels, power
-//                         only: the sweep; the fastest form, see its header for why)
-//   beamform_kernel       membrane fragments of 4 time tiles in registers, bf_mat in LDS      (<= 64 channels, y stored)
+//   beamform_ws_kernel    bf_mat fragments in registers, membrane fragments parked in LDS   (<= 16 channels, <= 512
+//                         DoAs: the sweep; the fastest form, see its header for why; with y stored, the rows leave
+//                         through an LDS block as whole-workgroup contiguous stores)
+//   beamform_kernel       membrane fragments of 4 time tiles in registers, bf_mat in LDS      (<= 64 channels)
 //   beamform_slab_kernel  membrane fragments in registers, bf_mat streamed through LDS slabs  (> 64 channels)
 //
 // Summation order (== oracle): LIF over past samples in chronological order (tau ascending),
@@ -442,11 +443,76 @@ __device__ __forceinline__ void ws_stage2(const double *Vl, const double *__rest
     }
 }
 
-template <int NGW, int NT>
-__global__ __launch_bounds__(BF_THREADS, NT == 2 ? 6 : 4) void beamform_ws_kernel(const int8_t *__restrict__ spikes,
-                                                                    const double *__restrict__ ntab_g, int NK,
-                                                                    const double *__restrict__ Wp, int GT, int C, int T,
-                                                                    double *__restrict__ partial)
+// The same ownership with the T x G product stored (API parity with apply_to_signal): HBM-write bound, and what decides
+// the rate is the shape of the stores (tools/store_bw.hip: accumulator tiles stored as they are -- 4 rows x 128 B per
+// instruction -- reach 3.7 TB/s for 64-byte aligned rows and 2.5 TB/s for G = 449; a workgroup writing a contiguous
+// block front to back reaches 5.6 TB/s whatever the row length).  The 8 waves walk the time tiles together, so after each
+// tile the workgroup holds 16 complete rows of y = one contiguous block of 16 G doubles: it is assembled in LDS in
+// memory order and copied out by all 512 threads.  A wave without a DoA tile in its last slot (gt >= GT) multiplies
+// against a clamped fragment and stores nothing, so every wave runs the same code and reaches the same barriers.
+template <int NG, int TILES>
+__device__ __forceinline__ void ws_stage2_y(const double *Vl, const double *__restrict__ Wp, int GT, int G, int wv, int l,
+                                            int tid, int ntile, int nrows, double *stg, double *__restrict__ yb,
+                                            double *__restrict__ pout)
+{
+    const int Gp = 16 * GT;
+    const int lc = l & 15;
+    const int q = l >> 4;
+    double Wf[NG][4];
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+        const int gt = wv + BF_WAVES * j;
+        const double *wp = Wp + 16 * (gt < GT ? gt : GT - 1) + lc;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) Wf[j][k] = wp[(size_t)(4 * k + q) * Gp];
+    }
+    double sq[NG];
+#pragma unroll
+    for (int j = 0; j < NG; ++j) sq[j] = 0.0;
+    for (int t = 0; t < ntile; ++t) {
+        double V[4];
+        const double *p = Vl + (size_t)t * 256 + l;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) V[k] = p[64 * k];
+        double4_t acc[NG];
+#pragma unroll
+        for (int j = 0; j < NG; ++j) acc[j] = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int j = 0; j < NG; ++j) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(V[k], Wf[j][k], acc[j], 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int j = 0; j < NG; ++j) sq[j] = __builtin_fma(acc[j][r], acc[j][r], sq[j]);
+#pragma unroll
+        for (int j = 0; j < NG; ++j) {
+            const int col = 16 * (wv + BF_WAVES * j) + lc;
+            if (col < G) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) stg[(q + 4 * r) * G + col] = acc[j][r];
+            }
+        }
+        __syncthreads();
+        const int rows = nrows - 16 * t < 16 ? nrows - 16 * t : 16;
+        const int n = rows * G;
+        double *yo = yb + (size_t)16 * t * G;
+#pragma unroll 4
+        for (int e = tid; e < n; e += BF_THREADS) yo[e] = stg[e];
+        __syncthreads();  // the block is on its way: the next tile may overwrite it
+    }
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+        const double s = row_sum4(sq[j]);
+        const int gt = wv + BF_WAVES * j;
+        if (pout && l < 16 && gt < GT) pout[16 * gt + l] = s;
+    }
+}
+
+template <int NGW, int NT, bool WANT_Y>
+__global__ __launch_bounds__(BF_THREADS, WANT_Y ? 2 : (NT == 2 ? 6 : 4)) void beamform_ws_kernel(
+    const int8_t *__restrict__ spikes, const double *__restrict__ ntab_g, int NK, const double *__restrict__ Wp, int GT, int C,
+    int T, double *__restrict__ partial, int G, double *__restrict__ y)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int Gp = 16 * GT;
@@ -577,6 +643,12 @@ __global__ __launch_bounds__(BF_THREADS, NT == 2 ? 6 : 4) void beamform_ws_kerne
     int ntile = (T - cs + 15) >> 4;
     ntile = ntile > TILES ? TILES : ntile;
     double *pout = partial + ((size_t)b * nchunks + chunk) * Gp;
+    if constexpr (WANT_Y) {
+        double *stg = ntab + ((ntab_len + 1) & ~1);  // 16 rows x G, exactly as they lie in memory
+        ws_stage2_y<NGW, TILES>(Vl, Wp, GT, G, wv, l, tid, ntile, T - cs, stg, y + ((size_t)b * T + cs) * G,
+                                partial ? pout : nullptr);
+        return;
+    }
     // NGW = ceil(GT / 8): every wave owns NGW or NGW - 1 DoA tiles (wave-uniform choice of the instantiation)
     if (wv + BF_WAVES * (NGW - 1) < GT)
         ws_stage2<NGW, TILES, NT != 2>(Vl, Wp, Gp, wv, l, ntile, pout);
@@ -584,24 +656,25 @@ __global__ __launch_bounds__(BF_THREADS, NT == 2 ? 6 : 4) void beamform_ws_kerne
         ws_stage2<NGW - 1, TILES, NT != 2>(Vl, Wp, Gp, wv, l, ntile, pout);
 }
 
-static size_t ws_lds_bytes(const NeuronTab &nt, int NT)
+static size_t ws_lds_bytes(const NeuronTab &nt, int NT, int Gy = 0)
 {
     const size_t tile = (size_t)(BF_WAVES * NT * 16 + 4 * nt.NK - 16) * 16, vfrag = (size_t)BF_WAVES * NT * 256;
-    return ((tile > vfrag ? tile : vfrag) + (size_t)(4 * nt.NK + 16)) * sizeof(double);
+    const size_t tab = (size_t)(4 * nt.NK + 16);
+    return ((tile > vfrag ? tile : vfrag) + (Gy ? ((tab + 1) & ~(size_t)1) + (size_t)16 * Gy : tab)) * sizeof(double);
 }
 
-template <int NGW, int NT>
+template <int NGW, int NT, bool WANT_Y>
 static hipError_t launch_ws_n(const BeamformW &W, const NeuronTab &nt, const int8_t *spikes, int B, int T,
-                              double *partial, hipStream_t stream)
+                              double *partial, double *y, hipStream_t stream)
 {
-    const size_t lds = ws_lds_bytes(nt, NT);
+    const size_t lds = ws_lds_bytes(nt, NT, WANT_Y ? W.G : 0);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    auto k = &beamform_ws_kernel<NGW, NT>;
+    auto k = &beamform_ws_kernel<NGW, NT, WANT_Y>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        160 * 1024);
     if (e != hipSuccess) return e;
     dim3 grid((T + BF_WAVES * NT * 16 - 1) / (BF_WAVES * NT * 16), B), block(BF_THREADS);
-    hipLaunchKernelGGL(k, grid, block, lds, stream, spikes, nt.tab, nt.NK, W.Wp, W.GT, W.C, T, partial);
+    hipLaunchKernelGGL(k, grid, block, lds, stream, spikes, nt.tab, nt.NK, W.Wp, W.GT, W.C, T, partial, W.G, y);
     return hipGetLastError();
 }
 
@@ -611,29 +684,30 @@ static hipError_t launch_ws_n(const BeamformW &W, const NeuronTab &nt, const int
 // is unchanged).
 constexpr int WS_NT = 2;
 
-static bool ws_eligible(const BeamformW &W, const NeuronTab &nt)
+static bool ws_eligible(const BeamformW &W, const NeuronTab &nt, bool want_y)
 {
-    return W.CT == 1 && W.GT <= 4 * BF_WAVES && ws_lds_bytes(nt, WS_NT) <= 160 * 1024;
+    return W.CT == 1 && W.GT <= 4 * BF_WAVES && ws_lds_bytes(nt, WS_NT, want_y ? W.G : 0) <= 160 * 1024;
 }
 
-template <int NT>
+template <int NT, bool WANT_Y>
 static hipError_t launch_ws_nt(const BeamformW &W, const NeuronTab &nt, const int8_t *spikes, int B, int T,
-                               double *partial, hipStream_t stream)
+                               double *partial, double *y, hipStream_t stream)
 {
     switch ((W.GT + BF_WAVES - 1) / BF_WAVES) {
-        case 1: return launch_ws_n<1, NT>(W, nt, spikes, B, T, partial, stream);
-        case 2: return launch_ws_n<2, NT>(W, nt, spikes, B, T, partial, stream);
-        case 3: return launch_ws_n<3, NT>(W, nt, spikes, B, T, partial, stream);
-        case 4: return launch_ws_n<4, NT>(W, nt, spikes, B, T, partial, stream);
+        case 1: return launch_ws_n<1, NT, WANT_Y>(W, nt, spikes, B, T, partial, y, stream);
+        case 2: return launch_ws_n<2, NT, WANT_Y>(W, nt, spikes, B, T, partial, y, stream);
+        case 3: return launch_ws_n<3, NT, WANT_Y>(W, nt, spikes, B, T, partial, y, stream);
+        case 4: return launch_ws_n<4, NT, WANT_Y>(W, nt, spikes, B, T, partial, y, stream);
         default: return hipErrorInvalidValue;
     }
 }
 
 static hipError_t launch_ws(const BeamformW &W, const NeuronTab &nt, const int8_t *spikes, int B, int T,
-                            double *partial, hipStream_t stream, int *nchunks)
+                            double *partial, double *y, hipStream_t stream, int *nchunks)
 {
     *nchunks = (T + BF_WAVES * WS_NT * 16 - 1) / (BF_WAVES * WS_NT * 16);
-    return launch_ws_nt<WS_NT>(W, nt, spikes, B, T, partial, stream);
+    if (y) return launch_ws_nt<WS_NT, true>(W, nt, spikes, B, T, partial, y, stream);
+    return launch_ws_nt<WS_NT, false>(W, nt, spikes, B, T, partial, nullptr, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -934,7 +1008,7 @@ static hipError_t dispatch_ct(const BeamformW &W, const NeuronTab *nt, const int
 hipError_t launch_lif_beamform(const BeamformW &W, const NeuronTab &nt, const int8_t *spikes, int B, int T, double *y,
                                double *partial, hipStream_t stream, int *nchunks)
 {
-    if (!y && partial && ws_eligible(W, nt)) return launch_ws(W, nt, spikes, B, T, partial, stream, nchunks);
+    if ((partial || y) && ws_eligible(W, nt, y != nullptr)) return launch_ws(W, nt, spikes, B, T, partial, y, stream, nchunks);
     *nchunks = beamform_nchunks_ct(T, W.CT);
     return dispatch_ct<true>(W, &nt, spikes, nullptr, B, T, 0, y, 0, partial, stream);
 }

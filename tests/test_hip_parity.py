@@ -431,6 +431,9 @@ def test_f32_mfma_beamform_variant(plan2, cfg2):
         (14, 360, 512, 4),    # exactly one chunk
         (14, 360, 513, 50),   # one frame into the second chunk, 50 taps (NK = 17: unrolled part + remainder)
         (14, 449, 1037, 35),  # NGW = 4 (script-exact DoA grid)
+        (14, 449, 257, 35),   # one frame into the second 256-frame workgroup of the bf_mat-stationary kernels
+        (14, 1, 300, 35),     # a single DoA column
+        (14, 17, 256, 35),    # one column into the second DoA tile; exactly one workgroup
         (14, 512, 700, 71),   # 32 DoA tiles (largest bf_mat-stationary shape), long kernel
         (2, 24, 1100, 35),    # single microphone
         (16, 100, 600, 35),   # C = 16: no channel padding
@@ -438,8 +441,11 @@ def test_f32_mfma_beamform_variant(plan2, cfg2):
     ],
 )
 def test_lif_beamform_stage_shapes_vs_oracle(torch, C, G, T, n_nir):
-    """Stage API `micloc_lif_beamform_f64`, power-only (bf_mat-stationary kernel where eligible) and with y stored
-    (time-stationary kernel), against the oracle's LIF FIR + beamforming + power on random ternary spike trains."""
+    """Stage API `micloc_lif_beamform_f64`, power-only and with y stored (bf_mat-stationary kernels where eligible, the
+    y rows leaving through an LDS block; time-stationary kernel otherwise), against the oracle's LIF FIR + beamforming +
+    power on random ternary spike trains.  The y-only call writes into the middle of a sentinel-filled buffer: nothing
+    outside [B][T][G] may change."""
+    from haghighatshoarmuir2024_amd import _lib, runtime
     from haghighatshoarmuir2024_amd.runtime import Plan
 
     rng = np.random.default_rng(C * 1000 + G + T)
@@ -454,6 +460,14 @@ def test_lif_beamform_stage_shapes_vs_oracle(torch, C, G, T, n_nir):
     sd = torch.from_numpy(spikes).cuda()
     out_p = p.lif_beamform(sd, want_y=False, want_power=True)
     out_y = p.lif_beamform(sd, want_y=True, want_power=True)
+    # y only (no workspace, no partial sums), guarded on both sides
+    pad = 4096
+    buf = torch.full((pad + B * T * G + pad,), 12345.5, dtype=torch.float64, device="cuda")
+    y_only = buf[pad:pad + B * T * G]
+    _lib.check(p.lib.micloc_lif_beamform_f64(p.handle, runtime._ptr(sd), B, T, runtime._ptr(y_only), None, None, None, 0,
+                                             runtime._stream(p.device)), "lif_beamform")
+    assert bool((buf[:pad] == 12345.5).all()) and bool((buf[-pad:] == 12345.5).all())
+    assert torch.equal(y_only.view(B, T, G), out_y["y"])
     for b in range(B):
         v = O.lif_fir(spikes[b], nir)
         y = O.beamform(v, W)
@@ -464,6 +478,8 @@ def test_lif_beamform_stage_shapes_vs_oracle(torch, C, G, T, n_nir):
             assert int(out["argmax"][b]) == int(np.argmax(out["power"][b].cpu().numpy()))
     # the two kernels agree on the arg-max unless the two best powers tie to rounding
     pw = out_y["power"].cpu().numpy()
+    if G < 2:
+        return
     top2 = np.sort(pw, axis=1)[:, -2:]
     clear = (top2[:, 1] - top2[:, 0]) > 1e-9 * top2[:, 1]
     np.testing.assert_array_equal(out_p["argmax"].cpu().numpy()[clear], out_y["argmax"].cpu().numpy()[clear])
