@@ -464,7 +464,8 @@ def run_stub(args, rank, world):
     return 0
 
 
-XYLO_VALU_PER_NEURON_STEP = 41  # vector instructions per hidden-neuron wave and time step (ISA of xylo_lif_kernel<false, 7>)
+XYLO_VALU_PER_WAVE_STEP = 20  # vector instructions per wave (128 neurons, two per lane) and time step: 18 of the packed update +
+#                               2 v_perm that pair the matrix-core currents (ISA of xylo_lif_pk_kernel<1, false>)
 
 
 def run_xylo(args, rank, local_rank, world):
@@ -572,19 +573,25 @@ def run_xylo(args, rank, local_rank, world):
         dom = max(st, key=st.get)
         N = net.N
         nblocks = -(-N // 512)
-        wg_threads = -(-(-(-N // nblocks)) // 64) * 64
-        waves = nblocks * (wg_threads // 64) * B
+        waves_per_trial = 4 * nblocks if nblocks > 1 else -(-N // 128)
+        waves = waves_per_trial * B
+        lif_ginstr = waves * T * XYLO_VALU_PER_WAVE_STEP / (st["xylo_lif_kernel"] * 1e-3) / 1e9
+        valu_peak = 1024 * 2.4 / 4  # SIMDs x GHz / cycles per wave instruction
+        lif_note = (f"{XYLO_VALU_PER_WAVE_STEP} vector instructions per wave and time step, {waves} waves x {T} steps over 1024 SIMDs "
+                    f"({waves / 1024:.2f} per SIMD: the busiest holds {-(-waves // 1024)}); lanes used {N}/{waves_per_trial * 128} x 2 neurons")
         if dom == "xylo_lif_kernel":
-            # integer recurrences, one neuron per lane, sequential in time: bound by vector-instruction issue (4 cycles per wave
-            # instruction per SIMD), neither HBM (28 B of input per frame) nor MFMA
-            ginstr = waves * T * XYLO_VALU_PER_NEURON_STEP / (st[dom] * 1e-3) / 1e9
-            peak = 1024 * 2.4 / 4  # SIMDs x GHz / cycles per wave instruction
-            roof = dict(kernel="xylo_lif_kernel", bound="valu-issue (integer recurrences; neither HBM nor MFMA binds)", achieved=ginstr, peak=peak,
-                        unit="G wave-instructions/s", frac=ginstr / peak, traffic=None,
-                        note=f"{XYLO_VALU_PER_NEURON_STEP} vector instructions per wave and time step, {waves} waves x {T} steps; lanes used {N}/{nblocks * wg_threads}")
+            # integer recurrences, two neurons per lane, sequential in time: bound by vector-instruction issue (4 cycles per wave
+            # instruction per SIMD), neither HBM (14 B of input per frame) nor MFMA (8 int8 MFMAs per 16 steps and wave)
+            roof = dict(kernel="xylo_lif_pk_kernel", bound="valu-issue (integer recurrences; neither HBM nor MFMA binds)", achieved=lif_ginstr,
+                        peak=valu_peak, unit="G wave-instructions/s", frac=lif_ginstr / valu_peak, traffic=None, note=lif_note)
         else:
             achieved = B * T * (8 * 2 * M + 2 * M) / (st[dom] * 1e-3) / 1e9
-            roof = dict(kernel=dom, bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS, traffic=None)
+            roof = dict(kernel=dom, bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS, traffic=None,
+                        note="the band-pass / RZCC stage is a serial chain per (trial, channel) stream -- latency bound on one wave per 64 streams, "
+                             "data dependent (the order-1 band-pass of this configuration passes ~3x the peak candidates of the order-2 one: 1.0 "
+                             "instead of 0.34 ms per 4800 frames) -- and occupies few SIMD cycles; in the pipelined step it runs beside the "
+                             "other stages.  The stage that fills the SIMDs is the integer LIF: "
+                             f"{lif_ginstr:.0f} of {valu_peak:.0f} G wave-instructions/s = {lif_ginstr / valu_peak:.2f} of the issue bound; " + lif_note)
         roof["avg_launch_ms"] = st[dom]
         roof["stages_ms"] = st
         value = frames / dt

@@ -8,9 +8,11 @@
 // with a per-step spike cap, one shared recurrent weight.  HIP == oracle bit for bit; oracle != checked
 // against XyloSim.
 //
-// Mapping: lane = hidden neuron, workgroup = one trial x up to 1024 neurons, sequential over time (integer
-// state recurrences).  The 28 input channels are packed 4 x int8 per dword and contracted with v_dot4_i32_i8;
-// input spike rows are staged 256 steps at a time in LDS and read as wave-uniform (broadcast) dwords.
+// Two kernels.  xylo_lif_kernel (general: spike counts in, recurrence): lane = hidden neuron, workgroup = one trial x
+// up to 1024 neurons, sequential over time (integer state recurrences); the input channels are packed 4 x int8 per dword
+// and contracted with v_dot4_i32_i8; input spike rows are staged 256 steps at a time in LDS and read as wave-uniform
+// (broadcast) dwords.  xylo_lif_pk_kernel (the sweep: binary events, no recurrence): two neurons per lane in packed
+// 16-bit arithmetic, input currents from the int8 matrix cores -- see its header.
 #include <vector>
 
 #include "micloc_internal.h"
@@ -131,11 +133,230 @@ __global__ __launch_bounds__(1024) void xylo_lif_kernel(const uint8_t *__restric
     if (rate && act) rate[(size_t)b * N + g] = total;
 }
 
-size_t xylo_ws_bytes(int Cin, int N)
+// ---------------------------------------------------------------------------------------------------------------
+// Packed form for the sweep (binary input events, no recurrence): two neurons per lane in 16-bit halves.
+//
+// The state is 16 bit by definition, so every step of the rule has a packed instruction that is exact on it:
+//   decay              v - max(v >> dash, min(v, 1))       v_pk_ashrrev_i16 / v_pk_min_i16 / v_pk_max_i16 / v_pk_sub_i16
+//   sat16(a + b)       both operands 16 bit                v_pk_add_i16 clamp
+//   first spike        d = sat(v - th); m = d >> 15 (all ones below threshold); v = m ? v : d; count += m
+//                                                          v_pk_sub_i16 clamp / v_pk_ashrrev_i16 / v_bfi_b32 / v_pk_add_i16
+// (a shift count above 15 acts like 15 on a 16-bit value, so dash is clamped; the spike count of a 128-step tile is
+// 128 + the sum of the m's and is widened to 32 bit per tile).  9 instructions per neuron-step instead of ~41.
+//
+// The input current in[t][n] = sum_c W_in[c][n] s[t][c] is a plain matrix product of the event raster with the weight
+// matrix, identical for every trial: it runs on the matrix cores (v_mfma_i32_16x16x32_i8, one instruction per 16 steps x
+// 16 neurons; |in| <= 64 x 127 fits 16 bit because the events are 0/1).  A wave owns 128 neurons = 8 column tiles, whose
+// weight fragments it keeps in registers; lane (q, lc) integrates neurons 32 q + lc and 32 q + 16 + lc of the wave.  The
+// accumulators of column tiles 2k and 2k + 1 hold exactly those two neurons in lane (., lc), so one v_perm_b32 per step
+// packs them; the wave parks the packed currents of the next 16 steps in its own LDS slice ([4 steps][lane], 16 B per
+// lane: conflict-free both ways) while it integrates the current 16, and no barrier is needed inside a 128-step tile.
+// The rare second spike within one step (v >= 2 th) leaves the packed path for the exact 32-bit sequence.
+// ---------------------------------------------------------------------------------------------------------------
+typedef short short2_t __attribute__((ext_vector_type(2)));
+typedef int int4_t __attribute__((ext_vector_type(4)));
+
+constexpr int XP_WAVES = 4;                  // 4 x 128 = 512 neurons per workgroup
+constexpr int XP_TT = 128;                   // time steps staged per LDS tile: 4 KB + 8 KB per wave = 28 KB for the sweep's 360
+                                             // neurons, so that 5 workgroups fit a CU and all 1100 trials are resident at once
+                                             // (with 256-step tiles 4 fit, and the 76 left over ran alone afterwards: +45 %)
+constexpr int XP_NEUR = XP_WAVES * 128;
+
+__device__ __forceinline__ short2_t xp_s2(int w) { return __builtin_bit_cast(short2_t, w); }
+__device__ __forceinline__ int xp_i(short2_t v) { return __builtin_bit_cast(int, v); }
+
+__device__ __forceinline__ short2_t xp_decay(short2_t v, short2_t dash)
+{
+    const short2_t one = {1, 1};
+    return v - __builtin_elementwise_max(v >> dash, __builtin_elementwise_min(v, one));
+}
+
+template <int KQ, bool WANT_OUT>
+__global__ __launch_bounds__(XP_WAVES * 64) void xylo_lif_pk_kernel(const int8_t *__restrict__ raster, int tc, int T, int Cin,
+                                                                     const long *__restrict__ Wb /*[Npad][4 KQ]*/, int N,
+                                                                     const uint8_t *__restrict__ dash_syn,
+                                                                     const uint8_t *__restrict__ dash_mem,
+                                                                     const short *__restrict__ thr, int max_spikes,
+                                                                     uint8_t *__restrict__ spikes_out, int *__restrict__ rate)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char tile[XP_TT][32 * KQ];
+    extern __shared__ __attribute__((aligned(16))) int cur_dyn[];  // [waves][2][4][64][4]: only the waves that hold neurons
+    int(*cur)[2][4][64][4] = reinterpret_cast<int(*)[2][4][64][4]>(cur_dyn);
+    int8_t *raw = reinterpret_cast<int8_t *>(cur_dyn);  // staging area for the raster bytes of a tile (between barriers)
+    const int tid = threadIdx.x;
+    const int nthreads = blockDim.x;
+    const int wv = tid >> 6, l = tid & 63, lc = l & 15, q = l >> 4;
+    const int b = blockIdx.y;
+    const int nbase = blockIdx.x * XP_NEUR + wv * 128;
+
+    // weight fragments of the wave's 8 column tiles: lane (q, lc) holds channels 8 q .. 8 q + 7 (+ 32 kq) of neuron 16 j + lc
+    long Bw[8][KQ];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int kq = 0; kq < KQ; ++kq) Bw[j][kq] = Wb[(size_t)(nbase + 16 * j + lc) * (4 * KQ) + 4 * kq + q];
+
+    const int n0 = nbase + 32 * q + lc, n1 = n0 + 16;
+    const bool act0 = n0 < N, act1 = n1 < N;
+    auto clamp15 = [](int d) { return d > 15 ? 15 : d; };
+    const short2_t ds = {(short)(act0 ? clamp15(dash_syn[n0]) : 0), (short)(act1 ? clamp15(dash_syn[n1]) : 0)};
+    const short2_t dm = {(short)(act0 ? clamp15(dash_mem[n0]) : 0), (short)(act1 ? clamp15(dash_mem[n1]) : 0)};
+    const short2_t th = {(short)(act0 ? thr[n0] : 32767), (short)(act1 ? thr[n1] : 32767)};
+    const int th_hi = (int)th.y << 16;  // v.hi >= th.hi  <=>  (int)word >= th.hi << 16
+    short2_t isyn = {0, 0}, vmem = {0, 0};
+    int total0 = 0, total1 = 0;
+
+    const int8_t *sb = raster + (size_t)b * T * tc;
+    uint8_t *ob = WANT_OUT ? spikes_out + (size_t)b * T * N : nullptr;
+
+    // currents of 16 steps (tile16 `i` of the staged rows) -> the wave's LDS slice `buf`
+    auto produce = [&](int i, int buf) {
+        int4_t acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = int4_t{0, 0, 0, 0};
+#pragma unroll
+        for (int kq = 0; kq < KQ; ++kq) {
+            const long a = *reinterpret_cast<const long *>(&tile[16 * i + lc][32 * kq + 8 * q]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = __builtin_amdgcn_mfma_i32_16x16x32_i8(a, Bw[j][kq], acc[j], 0, 0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            int4_t pk;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pk[r] = (int)__builtin_amdgcn_perm((unsigned)acc[2 * k + 1][r], (unsigned)acc[2 * k][r], 0x05040100u);
+            *reinterpret_cast<int4_t *>(&cur[wv][buf][q][16 * k + lc][0]) = pk;  // steps 4 q .. 4 q + 3 of pair lane 16 k + lc
+        }
+    };
+
+    short2_t cnt = {0, 0};
+    auto step = [&](int in_word, int t) {
+        short2_t i2 = xp_decay(isyn, ds);
+        short2_t v2 = xp_decay(vmem, dm);
+        i2 = __builtin_elementwise_add_sat(i2, xp_s2(in_word));
+        v2 = __builtin_elementwise_add_sat(v2, i2);
+        const short2_t d = __builtin_elementwise_sub_sat(v2, th);
+        const short2_t fifteen = {15, 15};
+        const short2_t m = d >> fifteen;  // all ones: below threshold
+        int vw = (xp_i(m) & xp_i(v2)) | (~xp_i(m) & xp_i(d));
+        cnt += m;
+        int extra0 = 0, extra1 = 0;
+        // a second spike in the same step (v >= 2 th): exact 32-bit sequence, per half
+        const bool again = ((short)vw >= th.x) | (vw >= th_hi);
+        if (__builtin_expect(__any(again), 0)) {
+            int lo = (short)vw, hi = vw >> 16;
+            if (lo >= th.x) {
+                int more = xy_div(lo, th.x);
+                more = more < max_spikes - 1 ? more : max_spikes - 1;
+                extra0 = more;
+                lo -= more * th.x;
+            }
+            if (hi >= th.y) {
+                int more = xy_div(hi, th.y);
+                more = more < max_spikes - 1 ? more : max_spikes - 1;
+                extra1 = more;
+                hi -= more * th.y;
+            }
+            vw = (lo & 0xffff) | (hi << 16);
+            total0 += extra0;
+            total1 += extra1;
+        }
+        if constexpr (WANT_OUT) {
+            const size_t row = (size_t)t * N;
+            if (act0) ob[row + n0] = (uint8_t)(1 + m.x + extra0);
+            if (act1) ob[row + n1] = (uint8_t)(1 + m.y + extra1);
+        }
+        isyn = i2;
+        vmem = xp_s2(vw);
+    };
+
+    for (int t0 = 0; t0 < T; t0 += XP_TT) {
+        const int steps = (T - t0) < XP_TT ? (T - t0) : XP_TT;
+        __syncthreads();  // every wave is done with the previous tile and with its slice of `cur`
+        // the 128 x tc raster bytes of this tile are contiguous: one 16-byte load per thread into LDS (the slices of `cur`
+        // are idle between these barriers), then the +1 / -1 split from there (channel c < tc: +1 events, tc + c: -1
+        // events, zero padded to 32 KQ).  A byte-wise gather from global memory costs one exposed latency per element.
+        {
+            const int8_t *src = sb + (size_t)t0 * tc;
+            const uintptr_t a0 = reinterpret_cast<uintptr_t>(src) & ~(uintptr_t)15;  // >= raster: the launcher checks its alignment
+            const int off = (int)(reinterpret_cast<uintptr_t>(src) - a0);
+            const int nvec = (off + steps * tc + 15) >> 4;
+            const uint4 *vsrc = reinterpret_cast<const uint4 *>(a0);
+            const int8_t *rend = raster + (size_t)gridDim.y * T * tc;
+            for (int e = tid; e < nvec; e += nthreads) {
+                uint4 v;
+                if (reinterpret_cast<const int8_t *>(vsrc + e + 1) <= rend) {
+                    v = vsrc[e];
+                } else {  // the last vector of the whole raster: only the bytes that exist
+                    unsigned w4[4] = {0u, 0u, 0u, 0u};
+                    const int8_t *p = reinterpret_cast<const int8_t *>(vsrc + e);
+                    for (int i = 0; i < 16 && p + i < rend; ++i) w4[i >> 2] |= (unsigned)(unsigned char)p[i] << (8 * (i & 3));
+                    v = uint4{w4[0], w4[1], w4[2], w4[3]};
+                }
+                reinterpret_cast<uint4 *>(raw)[e] = v;
+            }
+            __syncthreads();
+            unsigned *tile32 = reinterpret_cast<unsigned *>(&tile[0][0]);
+            for (int e = tid; e < XP_TT * 8 * KQ; e += nthreads) {
+                const int r = e / (8 * KQ), k = e % (8 * KQ);
+                unsigned w = 0;
+                if (r < steps) {
+                    const int8_t *row = raw + off + r * tc;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int c = 4 * k + i;
+                        if (c < 2 * tc && c < Cin) {
+                            const int sv = c < tc ? row[c] : -row[c - tc];
+                            w |= (unsigned)(sv > 0) << (8 * i);
+                        }
+                    }
+                }
+                tile32[e] = w;
+            }
+        }
+        __syncthreads();
+        const int ntile = (steps + 15) >> 4;
+        cnt = short2_t{0, 0};
+        produce(0, 0);
+        for (int i = 0; i < ntile; ++i) {
+            if (i + 1 < ntile) produce(i + 1, (i + 1) & 1);
+            const int jn = steps - 16 * i < 16 ? steps - 16 * i : 16;
+            const int4_t *cw = reinterpret_cast<const int4_t *>(&cur[wv][i & 1][0][l][0]);
+            if (jn == 16) {
+#pragma unroll
+                for (int t4 = 0; t4 < 4; ++t4) {
+                    const int4_t in4 = cw[64 * t4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) step(in4[r], t0 + 16 * i + 4 * t4 + r);
+                }
+            } else {  // the last steps of the signal
+                for (int j = 0; j < jn; ++j) step(cur[wv][i & 1][j >> 2][l][j & 3], t0 + 16 * i + j);
+            }
+        }
+        total0 += steps + cnt.x;
+        total1 += steps + cnt.y;
+    }
+    if (rate) {
+        if (act0) rate[(size_t)b * N + n0] = total0;
+        if (act1) rate[(size_t)b * N + n1] = total1;
+    }
+}
+
+static int xp_npad(int N) { return ((N + XP_NEUR - 1) / XP_NEUR) * XP_NEUR; }
+static int xp_kq(int Cin) { return Cin <= 32 ? 1 : 2; }
+
+static size_t xylo_ws_base_bytes(int Cin, int N)
 {
     const int nq = (Cin + 3) / 4;
     size_t bytes = ((size_t)nq * N * sizeof(int) + 255) & ~(size_t)255;
     bytes += 3 * (((size_t)N * 2 + 255) & ~(size_t)255);
+    return bytes;
+}
+
+size_t xylo_ws_bytes(int Cin, int N)
+{
+    size_t bytes = xylo_ws_base_bytes(Cin, N);
+    if (Cin <= 64) bytes += ((size_t)xp_npad(N) * 32 * xp_kq(Cin) + 255) & ~(size_t)255;  // neuron-major byte matrix (packed form)
     return bytes;
 }
 
@@ -169,7 +390,16 @@ hipError_t xylo_upload(int Cin, const int8_t *W_in_host, int N, const uint8_t *d
     if ((e = hipMemcpyAsync(dds, dash_syn_host, (size_t)N, hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
     if ((e = hipMemcpyAsync(ddm, dash_mem_host, (size_t)N, hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
     if ((e = hipMemcpyAsync(dth, thr_host, (size_t)N * 2, hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
-    return hipStreamSynchronize(stream);  // `pk` is a host temporary
+    std::vector<int8_t> wb;
+    if (Cin <= 64) {
+        // neuron-major bytes for the matrix-core form: Wb[n][c], rows of 32 KQ bytes, neurons padded to whole workgroups
+        const int row = 32 * xp_kq(Cin);
+        wb.assign((size_t)xp_npad(N) * row, 0);
+        for (int c = 0; c < Cin; ++c)
+            for (int g = 0; g < N; ++g) wb[(size_t)g * row + c] = W_in_host[(size_t)c * N + g];
+        if ((e = hipMemcpyAsync(base + xylo_ws_base_bytes(Cin, N), wb.data(), wb.size(), hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
+    }
+    return hipStreamSynchronize(stream);  // `pk` / `wb` are host temporaries
 }
 
 // Runs the network whose constants xylo_upload placed in `ws`: no host access, no synchronisation (graph-capturable).
@@ -187,6 +417,34 @@ hipError_t launch_xylo_resident(const void *spikes_in, int ternary_C, int B, int
     short *dth = reinterpret_cast<short *>(base + off + 2 * seg);
     const uint8_t *sp = reinterpret_cast<const uint8_t *>(spikes_in);
     if (w_rec != 0 && N > 1024) return hipErrorInvalidValue;
+    if (w_rec == 0 && ternary_C > 0 && Cin <= 64 && max_spikes >= 1 && (reinterpret_cast<uintptr_t>(spikes_in) & 15) == 0) {
+        // binary events, independent neurons: two neurons per lane, input currents on the matrix cores
+        const long *dWb = reinterpret_cast<const long *>(base + xylo_ws_base_bytes(Cin, N));
+        // as many waves as hold neurons (N = 360: 3, not 4), the same in every workgroup of the launch
+        const int nblk = xp_npad(N) / XP_NEUR;
+        const int waves = nblk > 1 ? XP_WAVES : (N + 127) / 128;
+        const dim3 pgrid(nblk, B), pblock(waves * 64);
+        size_t plds = (size_t)waves * 2 * 4 * 64 * 4 * sizeof(int);
+        const size_t rawb = (size_t)XP_TT * ternary_C + 48;
+        plds = plds > rawb ? plds : rawb;
+        const int8_t *rs = reinterpret_cast<const int8_t *>(spikes_in);
+#define XP_LAUNCH(KQ, WO)                                                                                                      \
+    hipLaunchKernelGGL((xylo_lif_pk_kernel<KQ, WO>), pgrid, pblock, plds, stream, rs, ternary_C, T, Cin, dWb, N, dds, ddm, dth,       \
+                       max_spikes, spikes_out, rate)
+        if (xp_kq(Cin) == 1) {
+            if (spikes_out)
+                XP_LAUNCH(1, true);
+            else
+                XP_LAUNCH(1, false);
+        } else {
+            if (spikes_out)
+                XP_LAUNCH(2, true);
+            else
+                XP_LAUNCH(2, false);
+        }
+#undef XP_LAUNCH
+        return hipGetLastError();
+    }
     // without recurrence the neurons are independent: as few, as full workgroups as possible (N = 360 -> one of 384 threads
     // instead of 256 + 104: every wave of the launch issues the same instructions whether its lanes are used or not)
     const int nblocks = w_rec != 0 ? 1 : (N + 511) / 512;

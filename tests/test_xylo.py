@@ -123,6 +123,48 @@ def test_demo_spike_encoding_pinned_and_end_to_end(cfg2):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize(
+    "C,N,T,thr_lo,thr_hi,max_spikes,dash_hi",
+    [
+        (14, 449, 700, 50, 4000, 31, 6),    # the sweep's network size; first spikes only
+        (14, 449, 1037, 5, 60, 31, 3),      # thresholds far below the input current: many spikes per step (exact 32-bit path)
+        (14, 449, 300, 5, 60, 1, 3),        # ... with the per-step cap at 1
+        (14, 449, 300, 5, 60, 3, 3),        # ... and at 3
+        (7, 17, 257, 100, 900, 31, 15),     # one neuron into the second column tile; decay shifts up to 15
+        (1, 1, 16, 1, 2, 31, 2),            # one channel, one neuron, exactly one 16-step tile
+        (20, 513, 255, 200, 3000, 31, 15),  # 40 input channels (two 32-channel k-steps), a second workgroup
+        (32, 1100, 15, 30000, 32767, 31, 4),  # 64 channels, thresholds at the top of the range, shorter than a tile
+        (14, 130, 1, 10, 50, 31, 2),        # a single step
+    ],
+)
+def test_packed_xylo_kernel_equals_oracle(C, N, T, thr_lo, thr_hi, max_spikes, dash_hi):
+    """The sweep's form of the integer LIF (ternary raster in, no recurrence: two neurons per lane in 16-bit halves, input
+    currents on the int8 matrix cores) against the oracle, spike raster and counts, bit for bit."""
+    import torch
+
+    from haghighatshoarmuir2024_amd.xylo_snn_localization import XyloNetwork
+
+    rng = np.random.RandomState(C * 1000 + N + T)
+    Cin = 2 * C
+    spec = dict(W_in=rng.randint(-127, 128, size=(Cin, N)).astype(np.int8), w_rec=0,
+                dash_syn=rng.randint(0, dash_hi + 1, size=N).astype(np.uint8), dash_mem=rng.randint(0, dash_hi + 1, size=N).astype(np.uint8),
+                threshold=rng.randint(thr_lo, thr_hi + 1, size=N).astype(np.int16))
+    B = 3
+    raster = rng.choice([-1, 0, 1], size=(B, T, C), p=[0.15, 0.7, 0.15]).astype(np.int8)
+    raster[1] = rng.choice([-1, 1], size=(T, C))  # every channel fires at every step: the largest input currents
+    events = np.concatenate([raster > 0, raster < 0], axis=2).astype(np.uint8)
+    net = XyloNetwork(spec)
+    out, rate = net.run(torch.from_numpy(raster).cuda(), ternary=True, want_spikes=True, max_spikes=max_spikes)
+    _, rate_only = net.run(torch.from_numpy(raster).cuda(), ternary=True, want_spikes=False, max_spikes=max_spikes)
+    assert torch.equal(rate, rate_only)
+    for b in range(B):
+        eo, er = O.xylo_lif(events[b], spec["W_in"], 0, spec["dash_syn"], spec["dash_mem"], spec["threshold"], max_spikes)
+        np.testing.assert_array_equal(out[b].cpu().numpy(), eo)
+        np.testing.assert_array_equal(rate[b].cpu().numpy(), er)
+    assert int(rate.sum()) > 0 or thr_lo >= 30000 or N < 100
+
+
+@pytest.mark.gpu
 def test_resident_network_ternary_input_and_peak_location(cfg2):
     """The two-phase form (constants resident, int8 raster in, +/- split inside the kernel) equals the one-shot form and the
     oracle; the on-device find_peak_location equals the host function wherever the integer window sums have no tie."""
