@@ -26,6 +26,8 @@
 //
 // Summation order (== oracle): LIF over past samples in chronological order (tau ascending),
 // beamforming over channels ascending; both as fused multiply-add chains starting from +0.
+#include <cstdlib>
+
 #include "micloc_internal.h"
 
 namespace micloc {
@@ -337,6 +339,86 @@ __global__ __launch_bounds__(BF_THREADS) void beamform_kernel(const int8_t *__re
 // and bf_mat never goes through LDS.  VALU/LDS instructions per 16 MFMAs: ~25 instead of ~50.
 // ---------------------------------------------------------------------------------------------------------------
 
+// KV > 0 (14 channels -- the 7-microphone array; also 6 and 10): the last k-step would multiply KV real channels and
+// 4 - KV rows of zero padding.  A 16x16x4 fp64 MFMA holds the SIMD for 64 cycles and fp64 VALU work is not hidden behind
+// it (tools/mfma_valu_overlap.hip), so the last KV channels are cheaper as 4 KV plain FMAs on the accumulators (17.6
+// cycles each set of 4): 3 MFMAs + 8 FMAs = 227 instead of 256 cycles per (time tile, DoA tile) for C = 14.  The order of
+// the sum is unchanged -- channels 0..11 inside the MFMAs, then 12, 13 -- so y and the power stay bit-identical.
+// KM = k-steps on the matrix cores, KV = channels 4 KM .. 4 KM + KV - 1 on the vector ALU (fewer than 13 channels: only the
+// k-steps that hold channels at all).
+template <int NG, int TILES, int KM, int KV>
+__device__ __forceinline__ void ws_stage2_kv(const double *Vl, const double *__restrict__ Wp, int Gp, int wv, int l, int ntile,
+                                             double *__restrict__ pout)
+{
+    if constexpr (NG > 0) {
+        const int lc = l & 15;
+        const int q = l >> 4;
+        constexpr int KVD = KV > 0 ? KV : 1;
+        double Wf[NG][KM], Wv[NG][KVD];
+#pragma unroll
+        for (int j = 0; j < NG; ++j) {
+            const double *wp = Wp + 16 * (wv + BF_WAVES * j) + lc;
+#pragma unroll
+            for (int k = 0; k < KM; ++k) Wf[j][k] = wp[(size_t)(4 * k + q) * Gp];
+#pragma unroll
+            for (int i = 0; i < KV; ++i) Wv[j][i] = wp[(size_t)(4 * KM + i) * Gp];
+        }
+        double sq[NG];
+#pragma unroll
+        for (int j = 0; j < NG; ++j) sq[j] = 0.0;
+        auto ldv = [&](int tile, double (&V)[KM]) {
+            const double *p = Vl + (size_t)(tile < TILES ? tile : TILES - 1) * 256 + l;
+#pragma unroll
+            for (int k = 0; k < KM; ++k) V[k] = p[64 * k];
+        };
+        // membrane values of channels 4 KM + i at this lane's accumulator rows t = q + 4 r: fragment KM keeps channel
+        // 4 KM + i at lane index 16 i + t
+        auto ldvv = [&](int tile, double (&Vv)[KVD][4]) {
+            const double *p = Vl + (size_t)tile * 256 + 64 * KM + q;
+#pragma unroll
+            for (int i = 0; i < KV; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Vv[i][r] = p[16 * i + 4 * r];
+        };
+        auto tile_step = [&](int tile, const double (&V)[KM]) {
+            double Vv[KVD][4];
+            ldvv(tile, Vv);
+            double4_t acc[NG];
+#pragma unroll
+            for (int j = 0; j < NG; ++j) acc[j] = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int k = 0; k < KM; ++k)
+#pragma unroll
+                for (int j = 0; j < NG; ++j) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(V[k], Wf[j][k], acc[j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < KV; ++i)
+#pragma unroll
+                for (int j = 0; j < NG; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[j][r] = __builtin_fma(Vv[i][r], Wv[j][i], acc[j][r]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int j = 0; j < NG; ++j) sq[j] = __builtin_fma(acc[j][r], acc[j][r], sq[j]);
+        };
+        double VA[KM], VB[KM];
+        if (ntile > 0) ldv(0, VA);
+        int t = 0;
+        for (; t + 1 < ntile; t += 2) {
+            ldv(t + 1, VB);
+            tile_step(t, VA);
+            ldv(t + 2, VA);
+            tile_step(t + 1, VB);
+        }
+        if (t < ntile) tile_step(t, VA);
+#pragma unroll
+        for (int j = 0; j < NG; ++j) {
+            const double s = row_sum4(sq[j]);
+            if (l < 16) pout[16 * (wv + BF_WAVES * j) + l] = s;
+        }
+    }
+}
+
 template <int NG, int TILES, bool PING>
 __device__ __forceinline__ void ws_stage2(const double *Vl, const double *__restrict__ Wp, int Gp, int wv, int l,
                                           int ntile, double *__restrict__ pout)
@@ -509,8 +591,8 @@ __device__ __forceinline__ void ws_stage2_y(const double *Vl, const double *__re
     }
 }
 
-template <int NGW, int NT, bool WANT_Y>
-__global__ __launch_bounds__(BF_THREADS, WANT_Y ? 2 : (NT == 2 ? 6 : 4)) void beamform_ws_kernel(
+template <int NGW, int NT, bool WANT_Y, int KM, int KV>
+__global__ __launch_bounds__(BF_THREADS, WANT_Y ? 2 : (KV ? 4 : (NT == 2 ? 6 : 4))) void beamform_ws_kernel(
     const int8_t *__restrict__ spikes, const double *__restrict__ ntab_g, int NK, const double *__restrict__ Wp, int GT, int C,
     int T, double *__restrict__ partial, int G, double *__restrict__ y)
 {
@@ -650,6 +732,13 @@ __global__ __launch_bounds__(BF_THREADS, WANT_Y ? 2 : (NT == 2 ? 6 : 4)) void be
         return;
     }
     // NGW = ceil(GT / 8): every wave owns NGW or NGW - 1 DoA tiles (wave-uniform choice of the instantiation)
+    if constexpr (KM < 4) {
+        if (wv + BF_WAVES * (NGW - 1) < GT)
+            ws_stage2_kv<NGW, TILES, KM, KV>(Vl, Wp, Gp, wv, l, ntile, pout);
+        else
+            ws_stage2_kv<NGW - 1, TILES, KM, KV>(Vl, Wp, Gp, wv, l, ntile, pout);
+        return;
+    }
     if (wv + BF_WAVES * (NGW - 1) < GT)
         ws_stage2<NGW, TILES, NT != 2>(Vl, Wp, Gp, wv, l, ntile, pout);
     else
@@ -663,13 +752,30 @@ static size_t ws_lds_bytes(const NeuronTab &nt, int NT, int Gy = 0)
     return ((tile > vfrag ? tile : vfrag) + (Gy ? ((tab + 1) & ~(size_t)1) + (size_t)16 * Gy : tab)) * sizeof(double);
 }
 
-template <int NGW, int NT, bool WANT_Y>
+template <int NGW, int NT, bool WANT_Y, int KM = 4, int KV = 0>
 static hipError_t launch_ws_n(const BeamformW &W, const NeuronTab &nt, const int8_t *spikes, int B, int T,
                               double *partial, double *y, hipStream_t stream)
 {
+    if constexpr (!WANT_Y && KM == 4) {
+        // only the k-steps that hold channels; 6 / 10 / 14 channels: the last two on the vector ALU instead of a half-empty
+        // k-step (MICLOC_WS_K4=1 keeps four k-steps: ablation only, same results)
+        if (!getenv("MICLOC_WS_K4")) {
+#define WS_K(KM_, KV_) return launch_ws_n<NGW, NT, false, KM_, KV_>(W, nt, spikes, B, T, partial, y, stream)
+            switch (W.C) {  // (the plan's channel count is 2 x microphones: always even)
+                case 1: case 2: case 3: case 4: WS_K(1, 0);
+                case 6: WS_K(1, 2);
+                case 5: case 7: case 8: WS_K(2, 0);
+                case 10: WS_K(2, 2);
+                case 9: case 11: case 12: WS_K(3, 0);
+                case 14: WS_K(3, 2);
+                default: break;
+            }
+#undef WS_K
+        }
+    }
     const size_t lds = ws_lds_bytes(nt, NT, WANT_Y ? W.G : 0);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    auto k = &beamform_ws_kernel<NGW, NT, WANT_Y>;
+    auto k = &beamform_ws_kernel<NGW, NT, WANT_Y, KM, KV>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        160 * 1024);
     if (e != hipSuccess) return e;

@@ -435,7 +435,11 @@ def test_f32_mfma_beamform_variant(plan2, cfg2):
         (14, 1, 300, 35),     # a single DoA column
         (14, 17, 256, 35),    # one column into the second DoA tile; exactly one workgroup
         (14, 512, 700, 71),   # 32 DoA tiles (largest bf_mat-stationary shape), long kernel
-        (2, 24, 1100, 35),    # single microphone
+        (2, 24, 1100, 35),    # single microphone (one k-step)
+        (6, 225, 600, 35),    # one k-step + two channels on the vector ALU
+        (8, 130, 300, 35),    # two full k-steps
+        (10, 64, 300, 35),    # two k-steps + two channels on the vector ALU
+        (12, 300, 520, 35),   # three full k-steps
         (16, 100, 600, 35),   # C = 16: no channel padding
         (14, 520, 600, 35),   # 33 DoA tiles: falls back to the time-stationary kernel
     ],
@@ -449,11 +453,12 @@ def test_lif_beamform_stage_shapes_vs_oracle(torch, C, G, T, n_nir):
     from haghighatshoarmuir2024_amd.runtime import Plan
 
     rng = np.random.default_rng(C * 1000 + G + T)
+    bipolar = True
     M = C // 2
     B = 3
     nir = rng.standard_normal(n_nir)
     W = rng.standard_normal((C, G))
-    p = Plan(M, np.array([0.0, 1.0, 0.0, -1.0]), np.array([1.0]), np.array([1.0]), 2, True)
+    p = Plan(M, np.array([0.0, 1.0, 0.0, -1.0]), np.array([1.0]), np.array([1.0]), 2, bipolar)
     p.set_neuron_kernel(nir)
     p.set_bf_mat(W)
     spikes = (rng.integers(-1, 2, size=(B, T, C)) * (rng.random((B, T, C)) < 0.3)).astype(np.int8)
