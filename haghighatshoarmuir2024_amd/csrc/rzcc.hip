@@ -91,13 +91,25 @@ __device__ __forceinline__ void resolve_cluster(int s, int e, int stride, int w,
     while (remaining > 0) {
         int best = -1;
         double bv = 0.0;
-        for (int k = s; k < e; k += stride) {
-            const int wk = *word_at(k);
-            if (wk < 0) continue;
-            const double vk = *val_at(k) * sgn;
-            if (best < 0 || vk >= bv) {  // >= : equal priority -> the later peak wins (stable sort order)
-                best = k;
-                bv = vk;
+        // four list entries per trip: the LDS reads of a trip do not depend on each other, so their latencies overlap
+        // (one read at a time left this loop latency bound on dense candidate trains: order-1 band-pass, config 4)
+        for (int k = s; k < e; k += 4 * stride) {
+            int wk[4];
+            double vk[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int kk = k + u * stride;
+                const int kc = kk < e ? kk : s;
+                wk[u] = *word_at(kc);
+                vk[u] = *val_at(kc) * sgn;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int kk = k + u * stride;
+                if (kk < e && wk[u] >= 0 && (best < 0 || vk[u] >= bv)) {  // >= : equal priority -> the later peak wins (stable sort order)
+                    best = kk;
+                    bv = vk[u];
+                }
             }
         }
         const int wb = *word_at(best);

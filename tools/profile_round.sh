@@ -16,7 +16,23 @@ python3 bench.py --config xylo --steps 3 --warmup 1 > $OUT/bench_n1_xylo.json 2>
 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace -o run -- python3 bench.py --steps 40 --warmup 4 --no-cpu-baseline --streams 1 > $OUT/trace.log 2>&1
 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace_speech -o run -- python3 bench.py --config speech --steps 3 --warmup 1 --streams 1 > $OUT/trace_speech.log 2>&1
 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace_stress -o run -- python3 bench.py --config stress --steps 3 --warmup 1 --streams 1 > $OUT/trace_stress.log 2>&1
-rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace_xylo -o run -- python3 bench.py --config xylo --steps 2 --warmup 1 > $OUT/trace_xylo.log 2>&1
+rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace_xylo -o run -- python3 bench.py --config xylo --steps 2 --warmup 1 --streams 1 > $OUT/trace_xylo.log 2>&1
+# API-faithful mode (y stored) and the store-pattern microbenchmark behind its design
+(python3 tools/k3_time.py 360 1100 1; python3 tools/k3_time.py 449 1100 1; python3 tools/k3_time.py 360 1100 0; python3 tools/k3_time.py 449 1100 0) > $OUT/y_store.txt 2>/dev/null
+hipcc -O3 --offload-arch=gfx950 -o /tmp/store_bw tools/store_bw.hip > /dev/null 2>&1 && /tmp/store_bw > $OUT/store_bw.txt 2>&1
+# ablation: four MFMA k-steps for 14 channels instead of 3 + 2 channels on the vector ALU (same box, alternating)
+for i in 1 2; do
+  python3 bench.py --steps 40 --warmup 4 --no-cpu-baseline | tail -1 > $OUT/ab_kv_$i.json 2>/dev/null
+  MICLOC_WS_K4=1 python3 bench.py --steps 40 --warmup 4 --no-cpu-baseline | tail -1 > $OUT/ab_k4_$i.json 2>/dev/null
+done
+python3 - <<PY > $OUT/ablation_kstep.txt
+import json
+for tag in ("kv", "k4"):
+    for i in (1, 2):
+        d = json.load(open("$OUT/ab_%s_%d.json" % (tag, i)))
+        print(tag, i, "ms_per_step %.4f" % d["ms_per_step"], "value %.4g" % d["value"], "beamform launch %.4f ms" % d["roofline"]["avg_launch_ms"], "frac %.3f" % d["roofline"]["frac"])
+PY
+rm -f $OUT/ab_kv_*.json $OUT/ab_k4_*.json
 # counters: separate passes, nothing but --pmc (+ kernel trace)
 for cfg in noisy stress speech; do
   steps=6; [ $cfg = speech ] && steps=2
