@@ -34,8 +34,8 @@ for tag in ("kv", "k4"):
 PY
 rm -f $OUT/ab_kv_*.json $OUT/ab_k4_*.json
 # counters: separate passes, nothing but --pmc (+ kernel trace)
-for cfg in noisy stress speech; do
-  steps=6; [ $cfg = speech ] && steps=2
+for cfg in noisy stress speech xylo; do
+  steps=6; [ $cfg = speech ] && steps=2; [ $cfg = xylo ] && steps=2
   extra="--config $cfg --steps $steps --warmup 1 --no-cpu-baseline --streams 1"
   rocprofv3 --output-format csv --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch_$cfg -o run -- python3 bench.py $extra > $OUT/pmc_fetch_$cfg.log 2>&1
   rocprofv3 --output-format csv --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write_$cfg -o run -- python3 bench.py $extra > $OUT/pmc_write_$cfg.log 2>&1
@@ -48,6 +48,7 @@ python3 tools/summarize_profiles.py trace $OUT/trace_xylo $OUT/kernel_trace_summ
 python3 tools/summarize_profiles.py pmc $OUT/pmc_summary.csv pmc_fetch=$OUT/pmc_fetch_noisy pmc_write=$OUT/pmc_write_noisy pmc_sq=$OUT/pmc_sq_noisy
 python3 tools/summarize_profiles.py pmc $OUT/pmc_summary_stress.csv pmc_fetch=$OUT/pmc_fetch_stress pmc_write=$OUT/pmc_write_stress pmc_sq=$OUT/pmc_sq_stress
 python3 tools/summarize_profiles.py pmc $OUT/pmc_summary_speech.csv pmc_fetch=$OUT/pmc_fetch_speech pmc_write=$OUT/pmc_write_speech pmc_sq=$OUT/pmc_sq_speech
+python3 tools/summarize_profiles.py pmc $OUT/pmc_summary_xylo.csv pmc_fetch=$OUT/pmc_fetch_xylo pmc_write=$OUT/pmc_write_xylo pmc_sq=$OUT/pmc_sq_xylo
 find $OUT/trace -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats_bench_steps40_streams1.csv \;
 # keep the merge-back small: drop the raw per-dispatch traces
 rm -rf $OUT/trace $OUT/trace_speech $OUT/trace_stress $OUT/trace_xylo $OUT/pmc_fetch_* $OUT/pmc_write_* $OUT/pmc_sq_*
