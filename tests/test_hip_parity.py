@@ -143,7 +143,10 @@ def test_rzcc_random_batches_vs_oracle(torch):
 
     rng = np.random.RandomState(0)
     for (B, T, C, w, bip, kind) in [(5, 1000, 14, 12, 1, "walk"), (3, 777, 3, 1, 1, "noise"), (2, 2048, 130, 24, 0, "noise"),
-                                    (4, 500, 7, 5, 1, "int"), (1, 3000, 2, 400, 1, "noise"), (70, 64, 1, 3, 1, "int")]:
+                                    (4, 500, 7, 5, 1, "int"), (1, 3000, 2, 400, 1, "noise"), (70, 64, 1, 3, 1, "int"),
+                                    # cluster sizes around the register-resident widths (4 / 8 / 16) and beyond (list walk)
+                                    (3, 1500, 14, 4, 1, "noise"), (3, 1500, 14, 8, 1, "noise"), (3, 1500, 14, 16, 1, "noise"),
+                                    (3, 1500, 14, 40, 1, "noise"), (2, 1500, 5, 9, 0, "noise"), (2, 900, 6, 7, 1, "int")]:
         if kind == "int":
             x = rng.randint(-2, 3, size=(B, T, C)).astype(np.float64)
         elif kind == "walk":
