@@ -286,7 +286,9 @@ int micloc_xylo_lif_i16(const uint8_t *spikes_in, int B, int T, int Cin, const i
  * be captured into a HIP graph.  ternary_channels > 0: `spikes_in` is the encoder's int8 raster [B][T][ternary_channels]
  * in {-1, 0, +1} and Cin = 2 * ternary_channels: input channel c carries the +1 events of raster channel c, channel
  * ternary_channels + c its -1 events -- Demo.spike_encoding's split (xylo_snn_localization.py:350-354) folded into the
- * kernel's staging loop.  ternary_channels == 0: spikes_in is uint8 [B][T][Cin] as above. */
+ * kernel's staging loop.  ternary_channels == 0: spikes_in is uint8 [B][T][Cin] as above.
+ * With a ternary raster, w_rec == 0 and a 16-byte aligned `spikes_in` the launch takes the sweep kernel (two neurons per
+ * lane in packed 16-bit arithmetic, input currents on the int8 matrix cores); anything else the general one.  Same results. */
 int micloc_xylo_upload(int Cin, const int8_t *W_in, int N, const uint8_t *dash_syn, const uint8_t *dash_mem, const int16_t *thr,
                        void *ws, size_t ws_bytes, void *stream);
 int micloc_xylo_lif_resident_i16(const void *spikes_in, int ternary_channels, int B, int T, int Cin, int N, int w_rec,
