@@ -564,10 +564,10 @@ def run_xylo(args, rank, local_rank, world):
             torch.cuda.synchronize()
             return float(np.mean([a.elapsed_time(b) for a, b in zip(e0, e1)]))
 
-        h = plan.stht(x)
-        _, raster = plan.bandpass_rzcc(h, T, want_pre=False, want_spikes=True)
-        st = {"stht_kernel": timed(lambda: plan.stht(x)),
-              "bandpass_rzcc_kernel": timed(lambda: plan.bandpass_rzcc(h, T, want_pre=False, want_spikes=True)),
+        stage_out = plan.snn_pipeline(x, want_spikes=True, want_power=False, stages=3)
+        raster = stage_out["spikes"]
+        st = {"stht_kernel": timed(lambda: plan.snn_pipeline(x, want_spikes=True, want_power=False, stages=1, out=stage_out)),
+              "bandpass_rzcc_kernel": timed(lambda: plan.snn_pipeline(x, want_spikes=True, want_power=False, stages=2, out=stage_out)),
               "xylo_lif_kernel": timed(lambda: net.run(raster, ternary=True)),
               "peak_location_kernel": timed(lambda: runtime.peak_location(counts, G, win))}
         dom = max(st, key=st.get)

@@ -197,9 +197,9 @@ class Demo:
         per_band = []
         for plan in self._plans():
             x = plan.to_device(sig_batch)
-            h = plan.stht(x)
-            _, spikes = plan.bandpass_rzcc(h, x.shape[1], want_pre=False, want_spikes=True)
-            per_band.append(spikes)
+            # STHT + band-pass + RZCC of the fused pipeline: only the quadrature channels go through HBM, the encoder reads
+            # the in-phase ones (rolled input frames) from x itself
+            per_band.append(plan.snn_pipeline(x, want_spikes=True, want_power=False, stages=3)["spikes"])
         s = torch.cat(per_band, dim=2)
         if self.bipolar_spikes:
             s = torch.cat([(s > 0), (s < 0)], dim=2)
@@ -227,9 +227,9 @@ class Demo:
         per_band = []
         for plan in self._plans():
             x = plan.to_device(sig_batch)
-            h = plan.stht(x)
-            _, spikes = plan.bandpass_rzcc(h, x.shape[1], want_pre=False, want_spikes=True)
-            per_band.append(spikes)
+            # STHT + band-pass + RZCC of the fused pipeline: only the quadrature channels go through HBM, the encoder reads
+            # the in-phase ones (rolled input frames) from x itself
+            per_band.append(plan.snn_pipeline(x, want_spikes=True, want_power=False, stages=3)["spikes"])
         return per_band[0] if len(per_band) == 1 else torch.cat(per_band, dim=2).contiguous()
 
     def counts_batch(self, sig_batch):
