@@ -346,7 +346,7 @@ __global__ __launch_bounds__(BF_THREADS) void beamform_kernel(const int8_t *__re
 // the sum is unchanged -- channels 0..11 inside the MFMAs, then 12, 13 -- so y and the power stay bit-identical.
 // KM = k-steps on the matrix cores, KV = channels 4 KM .. 4 KM + KV - 1 on the vector ALU (fewer than 13 channels: only the
 // k-steps that hold channels at all).
-template <int NG, int TILES, int KM, int KV>
+template <int NG, int TILES, int KM, int KV, bool LEAN = false>
 __device__ __forceinline__ void ws_stage2_kv(const double *Vl, const double *__restrict__ Wp, int Gp, int wv, int l, int ntile,
                                              double *__restrict__ pout)
 {
@@ -382,7 +382,7 @@ __device__ __forceinline__ void ws_stage2_kv(const double *Vl, const double *__r
         };
         auto tile_step = [&](int tile, const double (&V)[KM]) {
             double Vv[KVD][4];
-            ldvv(tile, Vv);
+            if (!LEAN) ldvv(tile, Vv);
             double4_t acc[NG];
 #pragma unroll
             for (int j = 0; j < NG; ++j) acc[j] = double4_t{0.0, 0.0, 0.0, 0.0};
@@ -391,26 +391,42 @@ __device__ __forceinline__ void ws_stage2_kv(const double *Vl, const double *__r
 #pragma unroll
                 for (int j = 0; j < NG; ++j) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(V[k], Wf[j][k], acc[j], 0, 0, 0);
 #pragma unroll
-            for (int i = 0; i < KV; ++i)
+            for (int i = 0; i < KV; ++i) {
+                if (LEAN) {  // one channel's four rows at a time: 8 registers instead of 8 KV
+                    const double *p = Vl + (size_t)tile * 256 + 64 * KM + q + 16 * i;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Vv[0][r] = p[4 * r];
+                }
 #pragma unroll
                 for (int j = 0; j < NG; ++j)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[j][r] = __builtin_fma(Vv[i][r], Wv[j][i], acc[j][r]);
+                    for (int r = 0; r < 4; ++r) acc[j][r] = __builtin_fma(Vv[LEAN ? 0 : i][r], Wv[j][i], acc[j][r]);
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int j = 0; j < NG; ++j) sq[j] = __builtin_fma(acc[j][r], acc[j][r], sq[j]);
         };
-        double VA[KM], VB[KM];
-        if (ntile > 0) ldv(0, VA);
-        int t = 0;
-        for (; t + 1 < ntile; t += 2) {
-            ldv(t + 1, VB);
-            tile_step(t, VA);
-            ldv(t + 2, VA);
-            tile_step(t + 1, VB);
+        if (LEAN) {
+            // register-lean form (three workgroups per CU): fragments fetched per tile, the other waves of the SIMD cover the
+            // LDS latency
+            for (int t = 0; t < ntile; ++t) {
+                double V[KM];
+                ldv(t, V);
+                tile_step(t, V);
+            }
+        } else {
+            double VA[KM], VB[KM];
+            if (ntile > 0) ldv(0, VA);
+            int t = 0;
+            for (; t + 1 < ntile; t += 2) {
+                ldv(t + 1, VB);
+                tile_step(t, VA);
+                ldv(t + 2, VA);
+                tile_step(t + 1, VB);
+            }
+            if (t < ntile) tile_step(t, VA);
         }
-        if (t < ntile) tile_step(t, VA);
 #pragma unroll
         for (int j = 0; j < NG; ++j) {
             const double s = row_sum4(sq[j]);
@@ -591,8 +607,13 @@ __device__ __forceinline__ void ws_stage2_y(const double *Vl, const double *__re
     }
 }
 
+// Waves per SIMD the 6 / 10 / 14-channel instantiations are compiled for.  6 = three workgroups per CU, which needs the
+// register-lean stage 2 (fragments fetched per tile, one tail channel's rows at a time: 70 VGPRs for three DoA tiles per
+// wave; the double-buffered form takes 100 and runs two per CU: 1.13 against 1.07 ms per launch, step 1.63 against 1.59 ms).
+// Four DoA tiles per wave (G > 384) do not fit 80 registers either way and stay at two workgroups per CU.
+constexpr int WS_KV_WAVES = 6;
 template <int NGW, int NT, bool WANT_Y, int KM, int KV>
-__global__ __launch_bounds__(BF_THREADS, WANT_Y ? 2 : (KV ? 4 : (NT == 2 ? 6 : 4))) void beamform_ws_kernel(
+__global__ __launch_bounds__(BF_THREADS, WANT_Y ? 2 : (KV ? (NGW <= 3 ? WS_KV_WAVES : 4) : (NT == 2 ? 6 : 4))) void beamform_ws_kernel(
     const int8_t *__restrict__ spikes, const double *__restrict__ ntab_g, int NK, const double *__restrict__ Wp, int GT, int C,
     int T, double *__restrict__ partial, int G, double *__restrict__ y)
 {
@@ -733,10 +754,11 @@ __global__ __launch_bounds__(BF_THREADS, WANT_Y ? 2 : (KV ? 4 : (NT == 2 ? 6 : 4
     }
     // NGW = ceil(GT / 8): every wave owns NGW or NGW - 1 DoA tiles (wave-uniform choice of the instantiation)
     if constexpr (KM < 4) {
+        constexpr bool LEAN = KV > 0 && WS_KV_WAVES >= 6 && NGW <= 3;
         if (wv + BF_WAVES * (NGW - 1) < GT)
-            ws_stage2_kv<NGW, TILES, KM, KV>(Vl, Wp, Gp, wv, l, ntile, pout);
+            ws_stage2_kv<NGW, TILES, KM, KV, LEAN>(Vl, Wp, Gp, wv, l, ntile, pout);
         else
-            ws_stage2_kv<NGW - 1, TILES, KM, KV>(Vl, Wp, Gp, wv, l, ntile, pout);
+            ws_stage2_kv<NGW - 1, TILES, KM, KV, LEAN>(Vl, Wp, Gp, wv, l, ntile, pout);
         return;
     }
     if (wv + BF_WAVES * (NGW - 1) < GT)
