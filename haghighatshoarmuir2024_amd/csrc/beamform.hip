@@ -348,7 +348,7 @@ __global__ __launch_bounds__(BF_THREADS) void beamform_kernel(const int8_t *__re
 // k-steps that hold channels at all).
 template <int NG, int TILES, int KM, int KV, bool LEAN = false>
 __device__ __forceinline__ void ws_stage2_kv(const double *Vl, const double *__restrict__ Wp, int Gp, int wv, int l, int ntile,
-                                             double *__restrict__ pout)
+                                             double *__restrict__ pout, int j0 = 0)
 {
     if constexpr (NG > 0) {
         const int lc = l & 15;
@@ -357,7 +357,7 @@ __device__ __forceinline__ void ws_stage2_kv(const double *Vl, const double *__r
         double Wf[NG][KM], Wv[NG][KVD];
 #pragma unroll
         for (int j = 0; j < NG; ++j) {
-            const double *wp = Wp + 16 * (wv + BF_WAVES * j) + lc;
+            const double *wp = Wp + 16 * (wv + BF_WAVES * (j0 + j)) + lc;
 #pragma unroll
             for (int k = 0; k < KM; ++k) Wf[j][k] = wp[(size_t)(4 * k + q) * Gp];
 #pragma unroll
@@ -430,7 +430,7 @@ __device__ __forceinline__ void ws_stage2_kv(const double *Vl, const double *__r
 #pragma unroll
         for (int j = 0; j < NG; ++j) {
             const double s = row_sum4(sq[j]);
-            if (l < 16) pout[16 * (wv + BF_WAVES * j) + l] = s;
+            if (l < 16) pout[16 * (wv + BF_WAVES * (j0 + j)) + l] = s;
         }
     }
 }
@@ -610,10 +610,10 @@ __device__ __forceinline__ void ws_stage2_y(const double *Vl, const double *__re
 // Waves per SIMD the 6 / 10 / 14-channel instantiations are compiled for.  6 = three workgroups per CU, which needs the
 // register-lean stage 2 (fragments fetched per tile, one tail channel's rows at a time: 70 VGPRs for three DoA tiles per
 // wave; the double-buffered form takes 100 and runs two per CU: 1.13 against 1.07 ms per launch, step 1.63 against 1.59 ms).
-// Four DoA tiles per wave (G > 384) do not fit 80 registers either way and stay at two workgroups per CU.
+// Four DoA tiles per wave (G > 384) do not fit 80 registers and run as two passes of two.
 constexpr int WS_KV_WAVES = 6;
 template <int NGW, int NT, bool WANT_Y, int KM, int KV>
-__global__ __launch_bounds__(BF_THREADS, WANT_Y ? 2 : (KV ? (NGW <= 3 ? WS_KV_WAVES : 4) : (NT == 2 ? 6 : 4))) void beamform_ws_kernel(
+__global__ __launch_bounds__(BF_THREADS, WANT_Y ? 2 : (KV ? WS_KV_WAVES : (NT == 2 ? 6 : 4))) void beamform_ws_kernel(
     const int8_t *__restrict__ spikes, const double *__restrict__ ntab_g, int NK, const double *__restrict__ Wp, int GT, int C,
     int T, double *__restrict__ partial, int G, double *__restrict__ y)
 {
@@ -754,7 +754,17 @@ __global__ __launch_bounds__(BF_THREADS, WANT_Y ? 2 : (KV ? (NGW <= 3 ? WS_KV_WA
     }
     // NGW = ceil(GT / 8): every wave owns NGW or NGW - 1 DoA tiles (wave-uniform choice of the instantiation)
     if constexpr (KM < 4) {
-        constexpr bool LEAN = KV > 0 && WS_KV_WAVES >= 6 && NGW <= 3;
+        constexpr bool LEAN = KV > 0 && WS_KV_WAVES >= 6;
+        if constexpr (LEAN && NGW == 4) {
+            // four DoA tiles per wave do not fit 80 registers: two passes of two over the parked fragments (the LDS reads
+            // double, the MFMAs do not) keep three workgroups per CU
+            ws_stage2_kv<2, TILES, KM, KV, true>(Vl, Wp, Gp, wv, l, ntile, pout, 0);
+            if (wv + BF_WAVES * 3 < GT)
+                ws_stage2_kv<2, TILES, KM, KV, true>(Vl, Wp, Gp, wv, l, ntile, pout, 2);
+            else
+                ws_stage2_kv<1, TILES, KM, KV, true>(Vl, Wp, Gp, wv, l, ntile, pout, 2);
+            return;
+        }
         if (wv + BF_WAVES * (NGW - 1) < GT)
             ws_stage2_kv<NGW, TILES, KM, KV, LEAN>(Vl, Wp, Gp, wv, l, ntile, pout);
         else
