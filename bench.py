@@ -517,6 +517,9 @@ def run_xylo(args, rank, local_rank, world):
     nstreams = max(1, args.streams)
     # consecutive steps are independent batches: the latency-bound encoder of one overlaps the issue-bound LIF of another
     plans = [plan] + [runtime.Plan(M, demo.beamfs[0].kernel, bb, aa, enc.robust_width, enc.bipolar, device=device) for _ in range(nstreams - 1)]
+    if args.encoder_chunk is not None:
+        for pl in plans:
+            pl.set_encoder_chunk(args.encoder_chunk)
     pipe = runtime.StreamPipeline(plans)
 
     def body(pl):

@@ -33,6 +33,8 @@
 //     cheap serial scan stored at its boundary (see "Time chunking" below): bit-exact by construction.
 #include "micloc_internal.h"
 
+#include <stdlib.h>
+
 #include <type_traits>
 
 // (the instantiations that also store the filtered signal are limited by LDS, not by the waves-per-SIMD hint below)
@@ -253,22 +255,23 @@ constexpr int RZ_DIR_NONE = 0, RZ_DIR_RISE = 1, RZ_DIR_FALL = 2, RZ_DIR_UNKNOWN 
 // ---- loader wave (shared by the scan and the encoder kernel) ----------------------------------------------------
 // 16-step x 64-stream input tiles from the planar [stream][Ts] layout (in-phase channels straight from the rolled
 // input frames) into a transposed LDS tile; two register sets keep the loads of two tiles in flight.
-template <bool WANT_PRE, typename XT, typename YT>
+template <bool WANT_PRE, int SW, typename XT, typename YT>
 __device__ __forceinline__ void rz_loader(XT &X, YT &Y, const double *__restrict__ h, double *__restrict__ pre,
                                           const double *__restrict__ xin, int base, int nlanes, int C, int T, int Ts, int M,
                                           int shift, int m_lo, int m_hi, int nstep, int lane)
 {
     const int tl = lane & 15;  // time offset inside the tile
     const int sq = lane >> 4;  // stream slot 0..3 of each group of four
-    const bool full_block = base + 64 <= nlanes;
-    double v[2][16];  // two register sets: the loads of tile m are issued two tiles before they are written to LDS
+    constexpr int NJ = SW / 4;  // streams per lane: stream slot 4 j + sq
+    const bool full_block = base + SW <= nlanes;
+    double v[2][NJ];  // two register sets: the loads of tile m are issued two tiles before they are written to LDS
     // Per-stream source.  Quadrature channels (and everything when xin == nullptr) come from the planar STHT
     // buffer h; with xin != nullptr the in-phase channels c < M are read straight from the input frames,
     // x[b][(t - L/2) mod T][c]  (np.roll, snn_beamformer.py:325), so the STHT kernel need not write them.
-    const double *pb[16];
-    bool rolled[16];
+    const double *pb[NJ];
+    bool rolled[NJ];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
+    for (int j = 0; j < NJ; ++j) {
         int g = base + 4 * j + sq;
         g = g < nlanes ? g : nlanes - 1;
         const int bb = g / C, cc = g - bb * C;
@@ -283,12 +286,12 @@ __device__ __forceinline__ void rz_loader(XT &X, YT &Y, const double *__restrict
         int tr = (t < T ? t : T - 1) - sh;
         tr = tr < 0 ? tr + T : tr;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) v[S][j] = rolled[j] ? pb[j][(size_t)tr * M] : pb[j][tc];
+        for (int j = 0; j < NJ; ++j) v[S][j] = rolled[j] ? pb[j][(size_t)tr * M] : pb[j][tc];
     };
     auto write_tile = [&](int buf, auto set) {
         constexpr int S = decltype(set)::value;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) X[buf][tl][4 * j + sq] = v[S][j];
+        for (int j = 0; j < NJ; ++j) X[buf][tl][4 * j + sq] = v[S][j];
     };
     auto store_tile = [&](int m) {  // (WANT_PRE launches are never chunked: m is also the buffer parity)
         const int t = m * RZ_MT + tl;
@@ -296,10 +299,10 @@ __device__ __forceinline__ void rz_loader(XT &X, YT &Y, const double *__restrict
         if (full_block && (m + 1) * RZ_MT <= Ts) {
             double *p = pre + (size_t)(base + sq) * Ts + t;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) p[(size_t)(4 * j) * Ts] = Y[WANT_PRE ? yb : 0][WANT_PRE ? tl : 0][WANT_PRE ? 4 * j + sq : 0];
+            for (int j = 0; j < NJ; ++j) p[(size_t)(4 * j) * Ts] = Y[WANT_PRE ? yb : 0][WANT_PRE ? tl : 0][WANT_PRE ? 4 * j + sq : 0];
         } else {
 #pragma unroll 4
-            for (int j = 0; j < 16; ++j) {
+            for (int j = 0; j < NJ; ++j) {
                 const int g = base + 4 * j + sq;
                 if (g < nlanes && t < Ts) pre[(size_t)g * Ts + t] = Y[WANT_PRE ? yb : 0][WANT_PRE ? tl : 0][WANT_PRE ? 4 * j + sq : 0];
             }
@@ -344,7 +347,7 @@ __device__ __forceinline__ void rz_loader(XT &X, YT &Y, const double *__restrict
 // ---------------------------------------------------------------------------------------------------
 // loader wave `phase` of NP: owns the tiles m_lo + phase, m_lo + phase + NP, ...; tile m is written to X[m % 3] during
 // iteration m - 1 (tile 0 before the first barrier); `nstep` barriers after the first one.
-template <int NP, int PHASE, typename XT>
+template <int NP, int PHASE, int SW, typename XT>
 __device__ __forceinline__ void rz_loader_np(XT &X, const double *__restrict__ h, const double *__restrict__ xin, int base,
                                              int nlanes, int C, int T, int Ts, int M, int shift, int m_lo, int m_hi, int nstep,
                                              int lane)
@@ -353,11 +356,12 @@ __device__ __forceinline__ void rz_loader_np(XT &X, const double *__restrict__ h
                                   // the younger register set's loads in flight, which needs straight-line knowledge
     const int tl = lane & 15;  // time offset inside the tile
     const int sq = lane >> 4;  // stream slot 0..3 of each group of four
-    double v[2][16];
-    const double *pb[16];
-    bool rolled[16];
+    constexpr int NJ = SW / 4;  // streams per lane: stream slot 4 j + sq
+    double v[2][NJ];
+    const double *pb[NJ];
+    bool rolled[NJ];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
+    for (int j = 0; j < NJ; ++j) {
         int g = base + 4 * j + sq;
         g = g < nlanes ? g : nlanes - 1;
         const int bb = g / C, cc = g - bb * C;
@@ -375,12 +379,12 @@ __device__ __forceinline__ void rz_loader_np(XT &X, const double *__restrict__ h
         int tr = (t < T ? t : T - 1) - sh;
         tr = tr < 0 ? tr + T : tr;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) v[S][j] = rolled[j] ? pb[j][(size_t)tr * M] : pb[j][tc];
+        for (int j = 0; j < NJ; ++j) v[S][j] = rolled[j] ? pb[j][(size_t)tr * M] : pb[j][tc];
     };
     auto write_tile = [&](int buf, auto set) {
         constexpr int S = decltype(set)::value;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) X[buf][tl][4 * j + sq] = v[S][j];
+        for (int j = 0; j < NJ; ++j) X[buf][tl][4 * j + sq] = v[S][j];
     };
     using set0 = std::integral_constant<int, 0>;
     using set1 = std::integral_constant<int, 1>;
@@ -432,11 +436,11 @@ __global__ __launch_bounds__(192) void rzcc_scan_kernel(const double *__restrict
     const int m_end = (g.P - 1) * g.Lt - g.Vt;  // tile of the last checkpoint: nothing to do beyond it
     const int nstep = m_end + 2;                // the filter wave runs one tile behind the LDS ring
     if (wave == 0) {
-        rz_loader_np<2, 0>(X, h, xin, base, nlanes, C, T, Ts, M, shift, 0, m_end, nstep, lane);
+        rz_loader_np<2, 0, 64>(X, h, xin, base, nlanes, C, T, Ts, M, shift, 0, m_end, nstep, lane);
         return;
     }
     if (wave == 1) {
-        rz_loader_np<2, 1>(X, h, xin, base, nlanes, C, T, Ts, M, shift, 0, m_end, nstep, lane);
+        rz_loader_np<2, 1, 64>(X, h, xin, base, nlanes, C, T, Ts, M, shift, 0, m_end, nstep, lane);
         return;
     }
     // ------------------------------------ filter + checkpoints ----------------------------------------
@@ -587,8 +591,8 @@ struct RzStream {
 // WRITER: a seventh wave that stores the spikes (see spq below).  It pays off where the launch is occupancy bound (chunked
 // launches: speech 13.1 -> 12.2 ms for scan + chunks) and costs where one workgroup per CU runs at the pace of its slowest
 // wave (sweep shape: 0.417 -> 0.445 ms), so only chunked launches carry it.
-template <int N, bool WANT_PRE, bool WANT_SPIKES, int RING = RZ_RING, bool WRITER = false>
-__global__ __launch_bounds__(448, 4) void bandpass_rzcc_fast_kernel(const double *__restrict__ h,
+template <int N, bool WANT_PRE, bool WANT_SPIKES, int RING = RZ_RING, bool WRITER = false, int SW = 64>
+__global__ __launch_bounds__(448, SW == 64 ? 4 : 6) void bandpass_rzcc_fast_kernel(const double *__restrict__ h,
                                                                   double *__restrict__ pre,
                                                                   int8_t *__restrict__ spikes,
                                                                   int *__restrict__ flag_count,
@@ -598,23 +602,25 @@ __global__ __launch_bounds__(448, 4) void bandpass_rzcc_fast_kernel(const double
                                                                   RzGeom g, int nblk, const double *__restrict__ ckd,
                                                                   const int *__restrict__ cki, RzStream ss)
 {
-    __shared__ __attribute__((aligned(16))) double X[3][RZ_MT][RZ_ROW];
-    __shared__ double Y[WANT_PRE ? 2 : 1][WANT_PRE ? RZ_MT : 1][WANT_PRE ? RZ_ROW : 1];
-    __shared__ double ringV[WANT_SPIKES ? RING : 1][64];
-    __shared__ int ringP[WANT_SPIKES ? RING : 1][64];
-    __shared__ int nPub[64];
-    __shared__ int polPub[64];     // 1: the stream's first candidate is a minimum (candidates alternate from there)
-    __shared__ int deadPub[64];
-    __shared__ int ovPub[64];      // the detect wave found the ring full (or the checkpoint unusable): unit flagged
-    __shared__ int leftPub[64];    // time of the last strict change when the detect wave stopped
-    __shared__ int oldPub[2][64];  // per polarity: oldest ring entry the select wave still needs
+    static_assert(SW == 64 || SW == 32, "streams per workgroup");
+    constexpr int ROW = SW + 1;    // padded row of the transposed input tile (doubles)
+    __shared__ __attribute__((aligned(16))) double X[3][RZ_MT][ROW];
+    __shared__ double Y[WANT_PRE ? 2 : 1][WANT_PRE ? RZ_MT : 1][WANT_PRE ? ROW : 1];
+    __shared__ double ringV[WANT_SPIKES ? RING : 1][SW];
+    __shared__ int ringP[WANT_SPIKES ? RING : 1][SW];
+    __shared__ int nPub[SW];
+    __shared__ int polPub[SW];     // 1: the stream's first candidate is a minimum (candidates alternate from there)
+    __shared__ int deadPub[SW];
+    __shared__ int ovPub[SW];      // the detect wave found the ring full (or the checkpoint unusable): unit flagged
+    __shared__ int leftPub[SW];    // time of the last strict change when the detect wave stopped
+    __shared__ int oldPub[2][SW];  // per polarity: oldest ring entry the select wave still needs
     // Spike positions on their way to the raster.  A kept peak becomes one byte store into [B][T][C]: 64 lanes, 64 different
     // cache lines per instruction, in the middle of the select waves' dependent walk -- measured 0.13 of the kernel's 0.41 ms
     // on the sweep shape.  The select waves only queue the positions; a WRITER wave stores them one tile later, off the
     // critical path.  A lane that finds its queue full (a long cluster resolved at once) stores directly.
     constexpr int QN = 8;
-    __shared__ int spq[WRITER ? 2 : 1][WRITER ? QN : 1][64];
-    __shared__ int qwPub[2][64];
+    __shared__ int spq[WRITER ? 2 : 1][WRITER ? QN : 1][SW];
+    __shared__ int qwPub[2][SW];
 
     // 0: loader, 1: filter, 2: detect, 3: select maxima, 4: select minima.  Launches that do not store the filtered signal
     // have a second loader wave in front (even / odd tiles, four tiles of global loads in flight instead of two: with
@@ -626,29 +632,36 @@ __global__ __launch_bounds__(448, 4) void bandpass_rzcc_fast_kernel(const double
     const int lane = threadIdx.x & 63;
     const int blk = blockIdx.x % nblk;
     const int p = blockIdx.x / nblk;
-    const int base = blk * 64;
+    const int base = blk * SW;
     const RzSpan sp_ = rz_span(g, p, (T + RZ_MT - 1) / RZ_MT);
     const int m_lo = sp_.m_lo;
     const int NM = sp_.m_hi - sp_.m_lo;  // tiles of this chunk
     const int NSTEP = WANT_SPIKES ? NM + 2 : NM + 1;
     const int lane_g = base + lane;
-    const bool active = lane_g < nlanes;
+    const bool active = lane_g < nlanes;              // (lanes >= SW of the compute waves leave right after the loaders' branch)
     const int lane_c = active ? lane_g : nlanes - 1;  // clamped: inactive lanes shadow the last stream, results unused
     const size_t nl = (size_t)nlanes;
+    const int sblk = lane_g >> 6, sl = lane_g & 63;  // streaming state: blocks of 64 streams, whatever SW is
 
     if (LD2) {
         if (wave_hw == 0) {
-            rz_loader_np<2, 0>(X, h, xin, base, nlanes, C, T, Ts, M, shift, m_lo, sp_.m_hi, NSTEP, lane);
+            rz_loader_np<2, 0, SW>(X, h, xin, base, nlanes, C, T, Ts, M, shift, m_lo, sp_.m_hi, NSTEP, lane);
             return;
         }
         if (wave_hw == 1) {
-            rz_loader_np<2, 1>(X, h, xin, base, nlanes, C, T, Ts, M, shift, m_lo, sp_.m_hi, NSTEP, lane);
+            rz_loader_np<2, 1, SW>(X, h, xin, base, nlanes, C, T, Ts, M, shift, m_lo, sp_.m_hi, NSTEP, lane);
             return;
         }
     } else if (wave == 0) {
-        rz_loader<WANT_PRE>(X, Y, h, pre, xin, base, nlanes, C, T, Ts, M, shift, m_lo, sp_.m_hi, NSTEP, lane);
+        rz_loader<WANT_PRE, SW>(X, Y, h, pre, xin, base, nlanes, C, T, Ts, M, shift, m_lo, sp_.m_hi, NSTEP, lane);
         return;
     }
+
+    // Fewer than 64 streams per workgroup: a wave's step time does not depend on its live lanes (the chain is latency
+    // bound), so a launch with too few 64-stream workgroups to give every CU two runs 32 or 16 streams per workgroup
+    // instead -- twice / four times the workgroups, the same serial chain per stream, hence the same bits.  The upper lanes
+    // of the compute waves have nothing to do; they still arrive at every barrier (a barrier counts waves).
+    if (SW < 64 && lane >= SW) return;
 
     if (wave == 1) {
         // ------------------------------------ filter ---------------------------------------------------
@@ -660,11 +673,11 @@ __global__ __launch_bounds__(448, 4) void bandpass_rzcc_fast_kernel(const double
             for (int i = 0; i < N - 1; ++i) iir.z[i] = ckd[((size_t)(p - 1) * N + i) * nl + lane_c];
             cs = ckd[((size_t)(p - 1) * N + (N - 1)) * nl + lane_c];
         }
-        double *const sdb = ss.on ? ss.sd + (size_t)blk * (N + 1) * 64 : nullptr;
+        double *const sdb = ss.on ? ss.sd + (size_t)sblk * (N + 1) * 64 : nullptr;
         if (ss.on && ss.resume) {
 #pragma unroll
-            for (int i = 0; i < N - 1; ++i) iir.z[i] = sdb[i * 64 + lane];
-            cs = sdb[(N - 1) * 64 + lane];
+            for (int i = 0; i < N - 1; ++i) iir.z[i] = sdb[i * 64 + sl];
+            cs = sdb[(N - 1) * 64 + sl];
         }
         pin_coef<N>(coef);
         __syncthreads();
@@ -688,7 +701,7 @@ __global__ __launch_bounds__(448, 4) void bandpass_rzcc_fast_kernel(const double
                     const unsigned addr = (unsigned)(size_t)(&X[buf][0][lane]);
 #pragma unroll
                     for (int j = 0; j < RZ_MT; ++j)
-                        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(xr[j]) : "v"(addr), "n"(j * RZ_ROW * 8));
+                        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(xr[j]) : "v"(addr), "n"(j * ROW * 8));
                     asm volatile("s_waitcnt lgkmcnt(0)"
                                  : "+v"(xr[0]), "+v"(xr[1]), "+v"(xr[2]), "+v"(xr[3]), "+v"(xr[4]), "+v"(xr[5]), "+v"(xr[6]), "+v"(xr[7]),
                                    "+v"(xr[8]), "+v"(xr[9]), "+v"(xr[10]), "+v"(xr[11]), "+v"(xr[12]), "+v"(xr[13]), "+v"(xr[14]),
@@ -711,14 +724,14 @@ __global__ __launch_bounds__(448, 4) void bandpass_rzcc_fast_kernel(const double
         }
         if (ss.on) {
 #pragma unroll
-            for (int i = 0; i < N - 1; ++i) sdb[i * 64 + lane] = iir.z[i];
-            sdb[(N - 1) * 64 + lane] = cs;
+            for (int i = 0; i < N - 1; ++i) sdb[i * 64 + sl] = iir.z[i];
+            sdb[(N - 1) * 64 + sl] = cs;
         }
         return;
     }
 
     if (!WANT_SPIKES) return;  // (band-pass-only launches have just the two waves above)
-    int *const sib = ss.on ? ss.si + (size_t)blk * 12 * 64 : nullptr;
+    int *const sib = ss.on ? ss.si + (size_t)sblk * 12 * 64 : nullptr;
     const int tb0 = ss.on ? ss.t_base : 0;  // absolute time of local frame 0
 
     if (WRITER && wave == 5) {
@@ -781,20 +794,20 @@ __global__ __launch_bounds__(448, 4) void bandpass_rzcc_fast_kernel(const double
             livel = dcode != RZ_DIR_UNKNOWN;
         }
         if (ss.on && ss.resume) {
-            double *const sdb = ss.sd + (size_t)blk * (N + 1) * 64;
-            prev = sdb[N * 64 + lane];
-            left = sib[0 * 64 + lane];
-            n = sib[1 * 64 + lane];
-            const int bits = sib[2 * 64 + lane];
+            double *const sdb = ss.sd + (size_t)sblk * (N + 1) * 64;
+            prev = sdb[N * 64 + sl];
+            left = sib[0 * 64 + sl];
+            n = sib[1 * 64 + sl];
+            const int bits = sib[2 * 64 + sl];
             dir = (bits & 1) ? 1 : ((bits & 2) ? 2 : 0);
             ffall = (bits >> 2) & 1;
             livel = (bits >> 3) & 1;
             // the candidate ring with the clusters that were still open
-            const double *rv = ss.ringV + (size_t)blk * RZ_RING * 64;
-            const int *rp = ss.ringP + (size_t)blk * RZ_RING * 64;
+            const double *rv = ss.ringV + (size_t)sblk * RZ_RING * 64;
+            const int *rp = ss.ringP + (size_t)sblk * RZ_RING * 64;
             for (int e = 0; e < RING; ++e) {
-                ringV[e][lane] = rv[e * 64 + lane];
-                ringP[e][lane] = rp[e * 64 + lane];
+                ringV[e][lane] = rv[e * 64 + sl];
+                ringP[e][lane] = rp[e * 64 + sl];
             }
         }
         nPub[lane] = n;
@@ -848,7 +861,7 @@ __global__ __launch_bounds__(448, 4) void bandpass_rzcc_fast_kernel(const double
                         const int lf = below ? tbase + (31 - __builtin_clz(below)) : left;
                         // plateau value: the sum just before the step that completes the candidate
                         const double val = je ? *reinterpret_cast<const double *>(reinterpret_cast<const char *>(&X[m % 3][0][lane]) +
-                                                                                 (size_t)(je - 1) * RZ_ROW * 8)
+                                                                                 (size_t)(je - 1) * ROW * 8)
                                               : prev;
                         const int slot = n & (RING - 1);
                         ringP[slot][lane] = lf + tbase + je - 1;  // left + t - 1; position = word >> 1 (plateau midpoint)
@@ -868,11 +881,11 @@ __global__ __launch_bounds__(448, 4) void bandpass_rzcc_fast_kernel(const double
                     leftPub[lane] = dir != 0 ? left : tbase + RZ_MT + 1;
                 }
                 if (k == NM && ss.on) {
-                    double *const sdb = ss.sd + (size_t)blk * (N + 1) * 64;
-                    sdb[N * 64 + lane] = prev;
-                    sib[0 * 64 + lane] = left;  // absolute time of the last strict change
-                    sib[1 * 64 + lane] = n;
-                    sib[2 * 64 + lane] = (dir == 1 ? 1 : 0) | (dir == 2 ? 2 : 0) | (ffall << 2) | ((livel ? 1 : 0) << 3);
+                    double *const sdb = ss.sd + (size_t)sblk * (N + 1) * 64;
+                    sdb[N * 64 + sl] = prev;
+                    sib[0 * 64 + sl] = left;  // absolute time of the last strict change
+                    sib[1 * 64 + sl] = n;
+                    sib[2 * 64 + sl] = (dir == 1 ? 1 : 0) | (dir == 2 ? 2 : 0) | (ffall << 2) | ((livel ? 1 : 0) << 3);
                 }
                 nPub[lane] = n;
                 polPub[lane] = ffall;
@@ -921,10 +934,10 @@ __global__ __launch_bounds__(448, 4) void bandpass_rzcc_fast_kernel(const double
     if (mypol == 0) deadPub[lane] = 0;
     oldPub[mypol][lane] = 0;
     if (ss.on && ss.resume && mine) {
-        i_next = sib[(3 + 4 * mypol) * 64 + lane];
-        s_open = sib[(4 + 4 * mypol) * 64 + lane];
-        l_last = sib[(5 + 4 * mypol) * 64 + lane];
-        was_dead = sib[(6 + 4 * mypol) * 64 + lane] != 0;
+        i_next = sib[(3 + 4 * mypol) * 64 + sl];
+        s_open = sib[(4 + 4 * mypol) * 64 + sl];
+        l_last = sib[(5 + 4 * mypol) * 64 + sl];
+        was_dead = sib[(6 + 4 * mypol) * 64 + sl] != 0;
         dead = dead || was_dead;
         oldPub[mypol][lane] = dead ? 0x7fffffff : (s_open >= 0 ? s_open : (i_next >= 0 ? i_next : 0));
     }
@@ -963,20 +976,20 @@ __global__ __launch_bounds__(448, 4) void bandpass_rzcc_fast_kernel(const double
     if (ss.on) {
         if (ovPub[lane]) dead = true;
         if (mine) {
-            sib[(3 + 4 * mypol) * 64 + lane] = i_next;
-            sib[(4 + 4 * mypol) * 64 + lane] = s_open;
-            sib[(5 + 4 * mypol) * 64 + lane] = l_last;
-            sib[(6 + 4 * mypol) * 64 + lane] = dead ? 1 : 0;
+            sib[(3 + 4 * mypol) * 64 + sl] = i_next;
+            sib[(4 + 4 * mypol) * 64 + sl] = s_open;
+            sib[(5 + 4 * mypol) * 64 + sl] = l_last;
+            sib[(6 + 4 * mypol) * 64 + sl] = dead ? 1 : 0;
         }
         // a stream that lost its ring cannot be redone from its start (the history is gone): count it once
         if (active && mine && dead && !was_dead && atomicExch(&deadPub[lane], 1) == 0) atomicAdd(ss.overflow, 1);
         __syncthreads();  // (both select waves: the ring is final)
         if (mypol == 0) {
-            double *rv = ss.ringV + (size_t)blk * RZ_RING * 64;
-            int *rp = ss.ringP + (size_t)blk * RZ_RING * 64;
+            double *rv = ss.ringV + (size_t)sblk * RZ_RING * 64;
+            int *rp = ss.ringP + (size_t)sblk * RZ_RING * 64;
             for (int e = 0; e < RING; ++e) {
-                rv[e * 64 + lane] = ringV[e][lane];
-                rp[e * 64 + lane] = ringP[e][lane];
+                rv[e * 64 + sl] = ringV[e][lane];
+                rp[e * 64 + sl] = ringP[e][lane];
             }
         }
         if (!ss.final_) return;
@@ -1097,8 +1110,8 @@ __global__ __launch_bounds__(64) void rzcc_unit_fallback_kernel(const double *__
         bool seen[2] = {false, false};
         bool done[2] = {false, !bipolar};
         const int t_lo = span.m_lo * RZ_MT;
-        for (int t = t_lo; t < T && !(done[0] && done[1]); ++t) {
-            const double y = iir.step(coef, sample(t));
+        auto walk = [&](int t, double xt) {
+            const double y = iir.step(coef, xt);
             c = c + y;
             const bool rise = c > prev;
             const bool fall = c < prev;
@@ -1123,6 +1136,18 @@ __global__ __launch_bounds__(64) void rzcc_unit_fallback_kernel(const double *__
                 if (!seen[0] || nextpos - lastpos[0] >= w) done[0] = true;
                 if (!seen[1] || nextpos - lastpos[1] >= w) done[1] = true;
             }
+        };
+        // The samples of FB_BLK steps are fetched together (independent loads, one wait).  With one load per step in front of
+        // the conditional list stores the walk ran at one memory round trip per step (0.7 us: 8.7 ms for ONE flagged unit of a
+        // 12 000-frame chunk -- more than the whole chunked pass of config 4).
+        constexpr int FB_BLK = 16;
+        for (int t0 = t_lo; t0 < T && !(done[0] && done[1]); t0 += FB_BLK) {
+            double xs[FB_BLK];
+#pragma unroll
+            for (int u = 0; u < FB_BLK; ++u) xs[u] = sample(t0 + u < T ? t0 + u : T - 1);
+#pragma unroll
+            for (int u = 0; u < FB_BLK; ++u)
+                if (t0 + u < T && !(done[0] && done[1])) walk(t0 + u, xs[u]);
         }
 
         // ---- clusters of each polarity; the owned ones are resolved and scattered -----------------------------
@@ -1199,15 +1224,22 @@ static RzGeom rz_geom(int nlanes, int T, int w, int chunk_frames)
     if (chunk_frames > 0) {
         Lt = (chunk_frames + RZ_MT - 1) / RZ_MT;
     } else if (chunk_frames == 0) {
-        // Few workgroups and long streams: split so that about 2048 workgroups exist (8 per CU), chunks of at least 2048
-        // frames (look-back + tail tiles cost 4 %).  Launches that already fill the chip stay one exact pass: the
-        // scan's serial walk would be pure overhead there.
-        if (nblk < 160 && NM >= 2 * 128) {
-            const int want = (2048 + nblk - 1) / nblk;
+        // A workgroup is a serial chain over its tiles and a CU holds two of them (LDS), so a launch runs in
+        // ceil(workgroups / 512) rounds of chain length.  Few workgroups (speech: 28) or long streams (config 4: 3000
+        // tiles) are split so that about 2048 workgroups exist -- four full rounds of chunk length, P = floor(2048 / nblk)
+        // so that the last round is full -- with chunks of at least 2048 frames (look-back + tail tiles cost 4 %).  The
+        // scan's serial walk costs 0.1 - 0.5 of the single pass (it has no detector / selection), so short streams on a
+        // full chip (config 2: 300 tiles, 241 workgroups) stay one exact pass.
+        if (nblk < 512 && ((nblk < 160 && NM >= 2 * 128) || NM >= 1024)) {
+            int want = 2048 / nblk;
+            if (want < 2) want = 2;
             Lt = (NM + want - 1) / want;
             if (Lt < 128) Lt = 128;
         }
     }
+    // tail tiles: a cluster still open at the end of the tail sends its unit to the serial fallback, which walks the whole
+    // chunk -- for a 12 000-frame chunk longer than the whole chunked pass takes.  Long chunks can afford a long tail (3 %).
+    if (Lt / 32 > g.V2t) g.V2t = Lt / 32 > 24 ? 24 : Lt / 32;
     if (Lt < g.Vt + 1) Lt = g.Vt + 1;
     int P = (NM + Lt - 1) / Lt;
     // unit ids p * nlanes + lane must fit an int; keep the checkpoint tables small
@@ -1260,6 +1292,37 @@ size_t rzcc_scratch_bytes(int nlanes, int T, int w, int chunk_frames)
 
 int rzcc_chunks(int nlanes, int T, int w, int chunk_frames) { return rz_geom(nlanes, T, w, chunk_frames).P; }
 
+// Streams per workgroup of the spikes-only launches: 64, or 32 with MICLOC_RZ_SW=32 (measurement only; identical spikes).
+// A workgroup is a serial chain whose pace does not depend on its live lanes, so halving the streams per workgroup doubles
+// the workgroups but not the speed of a launch that is resident in one round anyway (config 2 / config 4: 241 -> 482
+// workgroups, 0.32 -> 0.31-0.36 ms / 9.0 -> 8.5 ms, profiles/r3/rz_sw_sweep.txt); what a CU can hold is bounded by
+// registers and LDS per stream, which do not shrink.  The lever for long streams is time chunking (rz_geom).
+static int rz_pick_sw()
+{
+    static const int forced = [] {
+        const char *e = getenv("MICLOC_RZ_SW");
+        return (e && atoi(e) == 32) ? 32 : 64;
+    }();
+    return forced;
+}
+
+template <int N, int SW>
+static void launch_rz_spikes(const IirCoef &coef, const double *h, int nlanes, int C, int T, int Ts, int w, int bipolar,
+                             int8_t *spikes, int *flag_count, int *flag_list, const RzGeom &g, const double *ckd, const int *cki,
+                             const double *xin, int M, int shift, hipStream_t stream)
+{
+    const int nblk = (nlanes + SW - 1) / SW;
+    dim3 grid(nblk * g.P);
+    if (g.P > 1)
+        hipLaunchKernelGGL((bandpass_rzcc_fast_kernel<N, false, true, RZ_RING, true, SW>), grid, dim3(448), 0, stream, h, nullptr,
+                           spikes, flag_count, flag_list, coef, nlanes, C, T, Ts, w, bipolar, xin, M, shift, g, nblk, ckd, cki,
+                           RzStream{});
+    else
+        hipLaunchKernelGGL((bandpass_rzcc_fast_kernel<N, false, true, RZ_RING, false, SW>), grid, dim3(384), 0, stream, h, nullptr,
+                           spikes, flag_count, flag_list, coef, nlanes, C, T, Ts, w, bipolar, xin, M, shift, g, nblk, ckd, cki,
+                           RzStream{});
+}
+
 template <int N>
 static void launch_rz(const IirCoef &coef, const double *h, int nlanes, int C, int T, int Ts, int w, int bipolar,
                       double *pre, int8_t *spikes, unsigned char *scratch, const RzGeom &g, const RzScratch &sc,
@@ -1273,17 +1336,18 @@ static void launch_rz(const IirCoef &coef, const double *h, int nlanes, int C, i
     if (g.P > 1)
         hipLaunchKernelGGL((rzcc_scan_kernel<N>), dim3(nblk), dim3(192), 0, stream, h, coef, nlanes, C, T, Ts, xin, M, shift,
                            g, ckd, cki);
-    dim3 grid(nblk * g.P), block(spikes ? (pre ? 320 : (g.P > 1 ? 448 : 384)) : 128);
+    dim3 grid(nblk * g.P), block(spikes ? 320 : 128);
     if (pre && spikes)
         hipLaunchKernelGGL((bandpass_rzcc_fast_kernel<N, true, true>), grid, block, 0, stream, h, pre, spikes,
                            flag_count, flag_list, coef, nlanes, C, T, Ts, w, bipolar, xin, M, shift, g, nblk, ckd, cki, RzStream{});
-    else if (spikes && g.P > 1)
-        hipLaunchKernelGGL((bandpass_rzcc_fast_kernel<N, false, true, RZ_RING, true>), grid, block, 0, stream, h, pre, spikes,
-                           flag_count, flag_list, coef, nlanes, C, T, Ts, w, bipolar, xin, M, shift, g, nblk, ckd, cki, RzStream{});
-    else if (spikes)
-        hipLaunchKernelGGL((bandpass_rzcc_fast_kernel<N, false, true>), grid, block, 0, stream, h, pre, spikes,
-                           flag_count, flag_list, coef, nlanes, C, T, Ts, w, bipolar, xin, M, shift, g, nblk, ckd, cki, RzStream{});
-    else
+    else if (spikes) {
+        if (rz_pick_sw() == 32)
+            launch_rz_spikes<N, 32>(coef, h, nlanes, C, T, Ts, w, bipolar, spikes, flag_count, flag_list, g, ckd, cki, xin, M,
+                                    shift, stream);
+        else
+            launch_rz_spikes<N, 64>(coef, h, nlanes, C, T, Ts, w, bipolar, spikes, flag_count, flag_list, g, ckd, cki, xin, M,
+                                    shift, stream);
+    } else
         hipLaunchKernelGGL((bandpass_rzcc_fast_kernel<N, true, false>), grid, block, 0, stream, h, pre, spikes,
                            flag_count, flag_list, coef, nlanes, C, T, Ts, w, bipolar, xin, M, shift, g, nblk, ckd, cki, RzStream{});
     if (spikes)
