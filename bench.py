@@ -260,7 +260,7 @@ def make_step(wl, nstreams, variants=True):
     def body_e2e(plan):
         st = e2e_state[id(plan)]
         runtime.counter_add_(st["epoch"], 1)
-        runtime.uniform(B, 77, substream=0x40000000, lo=0.0, hi=2 * np.pi, out=st["doa"], epoch=st["epoch"])
+        runtime.uniform(B, 77, substream=0, lo=0.0, hi=2 * np.pi, out=st["doa"], epoch=st["epoch"])
         runtime.delay_min(st["doa"].view(B, 1), geo, out=st["shift"])
         runtime.synth_targets(tpl, "apply_to_template", doa=st["doa"].view(B, 1), geometry=geo, shift=st["shift"], out=st["x"])
         runtime.awgn_(st["x"], snr_db=snr_dev, seed=77, substream=0, epoch=st["epoch"], ws=st["ws"])

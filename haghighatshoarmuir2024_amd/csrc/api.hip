@@ -41,7 +41,9 @@ struct micloc_plan {
     BeamformW W{};
     int W_is_complex = 0;
     int G_out = 0;  // DoA grid size seen by the caller
-    // bumped whenever a device table is re-allocated (captured hipGraphs holding the old pointers become stale)
+    // bumped whenever a captured hipGraph of this plan becomes stale: a device table was re-allocated (the graph holds the
+    // old pointer) or replaced by one of another shape (the graph holds the old dimensions BY VALUE: W.GT / W.G / W.CT,
+    // ntab.n / NK are kernel arguments, and the packed bf_mat layout depends on Gp)
     int generation = 0;
     int chunk_frames = 0;  // encoder time chunking: 0 automatic, < 0 off, > 0 owned frames per chunk
     size_t taps_cap = 0, ntab_cap = 0, W_cap = 0;  // allocated doubles
@@ -64,8 +66,21 @@ struct DeviceGuard {
     }
 };
 
+// Device that owns a device pointer (plan-less entry points: their launches belong to the device of their buffers and
+// stream, whatever the caller's current device is).  Falls back to the current device for pointers HIP does not know.
+int device_of(const void *ptr)
+{
+    hipPointerAttribute_t at;
+    int dev = 0;
+    if (ptr && hipPointerGetAttributes(&at, ptr) == hipSuccess) return at.device;
+    (void)hipGetLastError();
+    (void)hipGetDevice(&dev);
+    return dev;
+}
+
 // Uploads a host table.  A table that fits the existing allocation is overwritten in place (device pointer unchanged:
-// hipGraphs captured against this plan stay valid); otherwise the buffer is re-allocated and *generation is bumped.
+// hipGraphs captured against this plan stay valid IF the caller keeps the table's shape -- set_W / set_neuron_kernel bump
+// the generation themselves when the shape changes); otherwise the buffer is re-allocated and *generation is bumped.
 int upload(double **dptr, size_t *cap, int *generation, const std::vector<double> &host)
 {
     const size_t n = host.empty() ? 1 : host.size();
@@ -255,6 +270,7 @@ int micloc_plan_set_neuron_kernel(micloc_plan *p, const double *nir, int n)
     HIP_TRY(hipDeviceSynchronize());
     int rc = upload(&p->d_ntab, &p->ntab_cap, &p->generation, tab);
     if (rc != MICLOC_OK) return rc;
+    if (p->ntab.tab && (p->ntab.n != n || p->ntab.NK != NK)) ++p->generation;  // captured graphs hold n / NK by value
     p->ntab.tab = p->d_ntab;
     p->ntab.n = n;
     p->ntab.NK = NK;
@@ -268,6 +284,9 @@ static int set_W(micloc_plan *p, const std::vector<double> &Wp, int CT, int GT, 
     HIP_TRY(hipDeviceSynchronize());
     int rc = upload(&p->d_W, &p->W_cap, &p->generation, Wp);
     if (rc != MICLOC_OK) return rc;
+    // same allocation, other shape: a captured graph would read the new table with the old stride and dimensions
+    if (p->W.Wp && (p->W.CT != CT || p->W.GT != GT || p->W.C != C || p->W.G != Gcols || p->W_is_complex != is_complex || p->G_out != G_out))
+        ++p->generation;
     p->W.Wp = p->d_W;
     p->W.CT = CT;
     p->W.GT = GT;
@@ -520,6 +539,7 @@ int micloc_rzcc_encode_ex_f64(const double *sig, int B, int T, int C, int robust
     if (!sig || !spikes || bad_batch(B) || T < 1 || C < 1 || robust_width < 1) return MICLOC_ERR_INVALID;
     // (the automatic choice does not depend on robust_width: micloc_rzcc_workspace_bytes(B, T, C) covers chunk_frames 0)
     if (bad_ws(ws, ws_bytes, micloc_rzcc_workspace_bytes_ex(B, T, C, robust_width, chunk_frames))) return MICLOC_ERR_WORKSPACE;
+    DeviceGuard guard(device_of(spikes));
     const int Ts = micloc_padded_T(T);
     unsigned char *base = reinterpret_cast<unsigned char *>(ws);
     double *planar = reinterpret_cast<double *>(base);
@@ -547,6 +567,7 @@ int micloc_lfilter_f64(const double *b, const double *a, int n, const double *x,
     if (!b || !a || !x || !y || n < 1 || n > MICLOC_MAX_IIR || bad_batch(B) || T < 1 || C < 1 || a[0] == 0.0)
         return MICLOC_ERR_INVALID;
     if (bad_ws(ws, ws_bytes, micloc_lfilter_workspace_bytes(B, T, C))) return MICLOC_ERR_WORKSPACE;
+    DeviceGuard guard(device_of(y));
     const int Ts = micloc_padded_T(T);
     const size_t planar_bytes = align256((size_t)B * C * Ts * sizeof(double));
     unsigned char *base = reinterpret_cast<unsigned char *>(ws);
@@ -637,6 +658,7 @@ int micloc_synth_delay_f64(const double *time, const double *sig, const double *
                            int B, int M, double fs, double *x, void *stream)
 {
     if (!time || !sig || !slopes || !delays || !x || T < 2 || bad_batch(B) || M < 1 || !(fs > 0.0)) return MICLOC_ERR_INVALID;
+    DeviceGuard guard(device_of(x));
     HIP_TRY(launch_synth(time, sig, slopes, T, delays, B, M, fs, x, (hipStream_t)stream));
     return MICLOC_OK;
 }
@@ -647,6 +669,7 @@ int micloc_synth_targets_f64(const micloc_synth_args *a, void *stream)
         return MICLOC_ERR_INVALID;
     if (a->mode != MICLOC_SYNTH_APPLY_TO_TEMPLATE && a->mode != MICLOC_SYNTH_SIGNAL_FROM_TEMPLATE) return MICLOC_ERR_INVALID;
     if (!a->delays && (!a->doa || !a->r_vec || !a->theta_vec || !(a->speed > 0.0))) return MICLOC_ERR_INVALID;
+    DeviceGuard guard(device_of(a->x));
     SynthArgs k{};
     k.time = a->time;
     k.sig = a->sig;
@@ -674,6 +697,7 @@ int micloc_delay_min_f64(const double *doa, int B, int K, int moving_T, const do
                          double speed, double *shift, void *stream)
 {
     if (!doa || !r_vec || !theta_vec || !shift || bad_batch(B) || K < 1 || moving_T < 1 || M < 1 || !(speed > 0.0)) return MICLOC_ERR_INVALID;
+    DeviceGuard guard(device_of(shift));
     HIP_TRY(launch_delay_min(doa, B, K, moving_T, r_vec, theta_vec, M, speed, shift, (hipStream_t)stream));
     return MICLOC_OK;
 }
@@ -682,7 +706,8 @@ int micloc_delay_min_f64(const double *doa, int B, int K, int moving_T, const do
 int micloc_uniform_f64(double *out, size_t n, uint64_t seed, uint32_t substream, const uint32_t *epoch, double lo, double hi,
                        void *stream)
 {
-    if (!out || n < 1) return MICLOC_ERR_INVALID;
+    if (!out || n < 1 || (n + 1) / 2 > 0xFFFFFFFFull) return MICLOC_ERR_INVALID;  // the pair index is one counter word
+    DeviceGuard guard(device_of(out));
     HIP_TRY(launch_uniform(out, n, seed, substream, epoch, lo, hi, (hipStream_t)stream));
     return MICLOC_OK;
 }
@@ -690,6 +715,7 @@ int micloc_uniform_f64(double *out, size_t n, uint64_t seed, uint32_t substream,
 int micloc_counter_add_u32(uint32_t *counter, uint32_t inc, void *stream)
 {
     if (!counter) return MICLOC_ERR_INVALID;
+    DeviceGuard guard(device_of(counter));
     HIP_TRY(launch_counter_add(counter, inc, (hipStream_t)stream));
     return MICLOC_OK;
 }
@@ -704,7 +730,10 @@ int micloc_awgn_f64(double *x, int B, int T, int M, const double *snr_db, const 
                     const uint32_t *epoch, uint32_t first_trial, void *ws, size_t ws_bytes, void *stream)
 {
     if (!x || bad_batch(B) || T < 1 || M < 1 || (!snr_db && !sigma)) return MICLOC_ERR_INVALID;
+    // counter words: pair index < 2^32; trial ids stay below the uniform generator's reserved word 0xFFFFFFFF
+    if (((size_t)T * M + 1) / 2 > 0xFFFFFFFFull || (uint64_t)first_trial + (uint64_t)B > 0xFFFFFFFFull) return MICLOC_ERR_INVALID;
     if (!sigma && bad_ws(ws, ws_bytes, awgn_ws_bytes(B, (size_t)T * M))) return MICLOC_ERR_WORKSPACE;
+    DeviceGuard guard(device_of(x));
     HIP_TRY(launch_awgn(x, B, (size_t)T * M, snr_db, sigma, seed, substream, epoch, first_trial, ws, (hipStream_t)stream));
     return MICLOC_OK;
 }
@@ -715,6 +744,7 @@ int micloc_doa_error_f64(const int32_t *argmax, const double *doa_list, int G, c
 {
     if (!argmax || !doa_list || !doa_true || G < 1 || bad_batch(B) || groups < 1 || B % groups != 0 || (!err && !mae))
         return MICLOC_ERR_INVALID;
+    DeviceGuard guard(device_of(argmax));
     HIP_TRY(launch_doa_error(argmax, doa_list, G, doa_true, B, groups, err, mae, (hipStream_t)stream));
     return MICLOC_OK;
 }
@@ -737,6 +767,7 @@ int micloc_xylo_lif_i16(const uint8_t *spikes_in, int B, int T, int Cin, const i
     for (int g = 0; g < N; ++g)
         if (thr[g] <= 0 || dash_syn[g] > 15 || dash_mem[g] > 15) return MICLOC_ERR_INVALID;
     if (bad_ws(ws, ws_bytes, xylo_ws_bytes(Cin, N))) return MICLOC_ERR_WORKSPACE;
+    DeviceGuard guard(device_of(ws));
     HIP_TRY(launch_xylo(spikes_in, B, T, Cin, W_in, N, w_rec, dash_syn, dash_mem, thr, max_spikes, spikes_out, rate, ws,
                         (hipStream_t)stream));
     return MICLOC_OK;
@@ -752,6 +783,7 @@ int micloc_xylo_upload(int Cin, const int8_t *W_in, int N, const uint8_t *dash_s
     for (int g = 0; g < N; ++g)
         if (thr[g] <= 0 || dash_syn[g] > 15 || dash_mem[g] > 15) return MICLOC_ERR_INVALID;
     if (bad_ws(ws, ws_bytes, xylo_ws_bytes(Cin, N))) return MICLOC_ERR_WORKSPACE;
+    DeviceGuard guard(device_of(ws));
     HIP_TRY(xylo_upload(Cin, W_in, N, dash_syn, dash_mem, thr, ws, (hipStream_t)stream));
     return MICLOC_OK;
 }
@@ -763,6 +795,7 @@ int micloc_xylo_lif_resident_i16(const void *spikes_in, int ternary_channels, in
     if (Cin > 64 || (w_rec != 0 && N > 1024)) return MICLOC_ERR_SHAPE;
     if (ternary_channels < 0 || (ternary_channels > 0 && Cin != 2 * ternary_channels)) return MICLOC_ERR_SHAPE;
     if (bad_ws(ws, ws_bytes, xylo_ws_bytes(Cin, N))) return MICLOC_ERR_WORKSPACE;
+    DeviceGuard guard(device_of(ws));
     HIP_TRY(launch_xylo_resident(spikes_in, ternary_channels, B, T, Cin, N, w_rec, max_spikes, spikes_out, rate, ws, (hipStream_t)stream));
     return MICLOC_OK;
 }
@@ -772,6 +805,7 @@ int micloc_design_vectors_f64(const double *cov, int n_doa, int C, int bipolar, 
 {
     if (!cov || !bf_mat || n_doa < 1 || C < 2 || G < 1 || g0 < 0 || g0 + n_doa > G || !(rel_prec > 0.0)) return MICLOC_ERR_INVALID;
     if (C > 32 || (bipolar && (C & 1))) return MICLOC_ERR_SHAPE;
+    DeviceGuard guard(device_of(bf_mat));
     HIP_TRY(launch_design_vec(cov, n_doa, C, bipolar ? 1 : 0, rel_prec, bf_mat, G, g0, (hipStream_t)stream));
     return MICLOC_OK;
 }
@@ -780,6 +814,7 @@ int micloc_peak_location_i32(const int32_t *rate, int B, int G, int bands, int w
 {
     if (!rate || !index || bad_batch(B) || G < 1 || bands < 1) return MICLOC_ERR_INVALID;
     if (win_size < 1 || win_size % 2 != 1 || win_size > G / 2 || G > 16384) return MICLOC_ERR_INVALID;  // utils.py:96-107
+    DeviceGuard guard(device_of(index));
     HIP_TRY(launch_peak_location(rate, B, G, bands, win_size, index, (hipStream_t)stream));
     return MICLOC_OK;
 }

@@ -9,11 +9,17 @@
 // oracle/micloc_oracle.c's restatement of the same generator (integers and uniforms exact, normals to ~1e-15: libm
 // vs. device log / sin / cos).
 //
-// Stream layout: key = seed (64 bit); counter = (index lo, index hi, trial, substream).  The normals of trial b are
-// numbered by element pair: pair i covers elements 2i, 2i+1 of the flat [T][M] frame block (z0 = r cos, z1 = r sin).
+// Stream layout: key = seed (64 bit); counter = (pair index, epoch, trial, substream) -- four independent words, so two
+// draws share a Philox block only if they agree in all of them.  The uniforms carry the reserved trial word 0xFFFFFFFF
+// (PHILOX_UNIFORM_DOMAIN): for one seed they are disjoint from the normals of every trial, substream and epoch.  (Round 2
+// added the epoch to the substream word, which made (substream s, epoch e) and (s + e, 0) the same stream and let the DoA
+// draws of substream 0 coincide with trial 0's noise.)  The normals of trial b are numbered by element pair: pair i covers
+// elements 2i, 2i+1 of the flat [T][M] frame block (z0 = r cos, z1 = r sin); a call covers fewer than 2^32 pairs.
 #include "micloc_internal.h"
 
 namespace micloc {
+
+constexpr uint32_t PHILOX_UNIFORM_DOMAIN = 0xFFFFFFFFu;  // trial word of the uniform generator (no trial carries it)
 
 struct Philox4 {
     uint32_t v[4];
@@ -53,8 +59,8 @@ __global__ __launch_bounds__(256) void uniform_kernel(double *__restrict__ out, 
 {
     const size_t pair = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (2 * pair >= n) return;
-    if (epoch) sub += *epoch;
-    const Philox4 r = philox4x32_10((uint32_t)pair, (uint32_t)(pair >> 32), 0u, sub, k0, k1);
+    const uint32_t ep = epoch ? *epoch : 0u;
+    const Philox4 r = philox4x32_10((uint32_t)pair, ep, PHILOX_UNIFORM_DOMAIN, sub, k0, k1);
     out[2 * pair] = lo + span * u53_co(r.v[0], r.v[1]);
     if (2 * pair + 1 < n) out[2 * pair + 1] = lo + span * u53_co(r.v[2], r.v[3]);
 }
@@ -125,7 +131,7 @@ __global__ __launch_bounds__(256) void awgn_kernel(double *__restrict__ x, size_
                                                     uint32_t k1, uint32_t sub, const uint32_t *__restrict__ epoch, uint32_t trial0)
 {
     const int b = blockIdx.y;
-    if (epoch) sub += *epoch;
+    const uint32_t ep = epoch ? *epoch : 0u;
     double *xb = x + (size_t)b * n;
     const double sg = sigma[b];
     const size_t pair0 = (size_t)blockIdx.x * (AWGN_BLOCK / 2);
@@ -134,7 +140,7 @@ __global__ __launch_bounds__(256) void awgn_kernel(double *__restrict__ x, size_
         const size_t pair = pair0 + i;
         const size_t e = 2 * pair;
         if (e >= n) break;
-        const Philox4 r = philox4x32_10((uint32_t)pair, (uint32_t)(pair >> 32), trial0 + (uint32_t)b, sub, k0, k1);
+        const Philox4 r = philox4x32_10((uint32_t)pair, ep, trial0 + (uint32_t)b, sub, k0, k1);
         const double u1 = u53_oc(r.v[0], r.v[1]);
         const double u2 = u53_co(r.v[2], r.v[3]);
         const double rad = sqrt(-2.0 * log(u1));

@@ -853,18 +853,48 @@ __global__ __launch_bounds__(448, SW == 64 ? 4 : 6) void bandpass_rzcc_fast_kern
                 Ew = livel ? Ew : 0u;
                 if (dir == 0 && Sw) ffall = (Fw & low) ? 1 : 0;
                 // ---- C: append the events (time order; maxima and minima alternate) ----
+                // The plateau value of an event is read from the LDS tile at an index only the event knows.  One event per
+                // trip with that read in the middle cost a full LDS latency per event, and a wave makes as many trips as its
+                // busiest lane has events: the first DET_PF events of every lane are located with integer operations, their
+                // values fetched together, then appended; a lane with more events finishes in the loop below.
+                constexpr int DET_PF = 3;
+                {
+                    int jev[DET_PF], lfv[DET_PF];
+                    double vev[DET_PF];
+                    const char *xt = reinterpret_cast<const char *>(&X[m % 3][0][lane]);
+#pragma unroll
+                    for (int u = 0; u < DET_PF; ++u) {
+                        const bool has = Ew != 0u;
+                        const int je = has ? __builtin_ctz(Ew) : 0;
+                        Ew &= Ew - 1u;  // (0 stays 0)
+                        const unsigned below = Sw & ((1u << je) - 1u);
+                        lfv[u] = below ? tbase + (31 - __builtin_clz(below)) : left;
+                        jev[u] = has ? je : -1;
+                        // plateau value: the sum just before the step that completes the candidate
+                        const double v = *reinterpret_cast<const double *>(xt + (size_t)(je > 0 ? je - 1 : 0) * ROW * 8);
+                        vev[u] = je > 0 ? v : prev;
+                    }
+#pragma unroll
+                    for (int u = 0; u < DET_PF; ++u) {
+                        if (jev[u] >= 0) {
+                            const int slot = n & (RING - 1);
+                            ringP[slot][lane] = lfv[u] + tbase + jev[u] - 1;  // left + t - 1; position = word >> 1 (plateau midpoint)
+                            ringV[slot][lane] = vev[u];
+                            ++n;
+                        }
+                    }
+                }
                 while (__any(Ew != 0u)) {
                     if (Ew) {
                         const int je = __builtin_ctz(Ew);
                         Ew &= Ew - 1u;
                         const unsigned below = Sw & ((1u << je) - 1u);
                         const int lf = below ? tbase + (31 - __builtin_clz(below)) : left;
-                        // plateau value: the sum just before the step that completes the candidate
                         const double val = je ? *reinterpret_cast<const double *>(reinterpret_cast<const char *>(&X[m % 3][0][lane]) +
                                                                                  (size_t)(je - 1) * ROW * 8)
                                               : prev;
                         const int slot = n & (RING - 1);
-                        ringP[slot][lane] = lf + tbase + je - 1;  // left + t - 1; position = word >> 1 (plateau midpoint)
+                        ringP[slot][lane] = lf + tbase + je - 1;
                         ringV[slot][lane] = val;
                         ++n;
                     }
@@ -904,6 +934,7 @@ __global__ __launch_bounds__(448, SW == 64 ? 4 : 6) void bandpass_rzcc_fast_kern
     int i_next = -1;      // next own list index to examine (-1: the stream has no candidate yet)
     int s_open = -1;      // first list index of the open cluster (-1: none)
     int l_last = 0;       // position of the last own candidate
+    int s_first = 0;      // position of the open cluster's first candidate (kept in a register: no LDS read when it closes)
     bool dead = !active;  // ring overflow (or lane out of range): stop selecting; redone by the fallback kernel
     bool was_dead = false;  // (streaming: already lost in an earlier tile)
     const int b = lane_c / C;
@@ -923,8 +954,7 @@ __global__ __launch_bounds__(448, SW == 64 ? 4 : 6) void bandpass_rzcc_fast_kern
             sp[(size_t)pos * C] = mark;
         }
     };
-    auto close_cluster = [&](int s, int e, int lastpos) {
-        const int first = *word_at(s) >> 1;
+    auto close_cluster = [&](int s, int e, int lastpos, int first) {
         if (first < own_lo || first >= own_hi) return;  // the cluster belongs to a neighbouring chunk
         if (e - s <= stride)
             emit(lastpos);
@@ -939,6 +969,7 @@ __global__ __launch_bounds__(448, SW == 64 ? 4 : 6) void bandpass_rzcc_fast_kern
         l_last = sib[(5 + 4 * mypol) * 64 + sl];
         was_dead = sib[(6 + 4 * mypol) * 64 + sl] != 0;
         dead = dead || was_dead;
+        s_first = s_open >= 0 ? ss.ringP[(size_t)sblk * RZ_RING * 64 + (s_open & (RING - 1)) * 64 + sl] >> 1 : 0;
         oldPub[mypol][lane] = dead ? 0x7fffffff : (s_open >= 0 ? s_open : (i_next >= 0 ? i_next : 0));
     }
     if (!mine) oldPub[mypol][lane] = 0x7fffffff;
@@ -948,15 +979,21 @@ __global__ __launch_bounds__(448, SW == 64 ? 4 : 6) void bandpass_rzcc_fast_kern
             const int n = nPub[lane];  // candidates published by the detect wave before the last barrier
             if (ovPub[lane]) dead = true;
             if (i_next < 0 && n > 0) i_next = bipolar ? (polPub[lane] ^ mypol) : 0;
+            // one candidate per lane and trip.  (Fetching the words of the next four candidates up front was measured and
+            // rejected: most tiles bring one new candidate per lane, the three extra reads and selects cost more than the
+            // latency they hide -- select waves 1450 -> 1720 cycles per tile on config 2.)
             while (__any(!dead && i_next >= 0 && i_next < n)) {
                 if (!dead && i_next >= 0 && i_next < n) {
                     const int i = i_next;
                     const int pos = *word_at(i) >> 1;
                     if (s_open >= 0 && pos - l_last >= w) {
-                        close_cluster(s_open, i, l_last);
-                        s_open = i;
+                        close_cluster(s_open, i, l_last, s_first);
+                        s_open = -1;
                     }
-                    if (s_open < 0) s_open = i;
+                    if (s_open < 0) {
+                        s_open = i;
+                        s_first = pos;
+                    }
                     l_last = pos;
                     i_next = i + stride;
                 }
@@ -993,7 +1030,7 @@ __global__ __launch_bounds__(448, SW == 64 ? 4 : 6) void bandpass_rzcc_fast_kern
             }
         }
         if (!ss.final_) return;
-        if (active && mine && !dead && s_open >= 0) close_cluster(s_open, nPub[lane], l_last);  // end of the stream
+        if (active && mine && !dead && s_open >= 0) close_cluster(s_open, nPub[lane], l_last, s_first);  // end of the stream
         return;
     }
     if (active && mine) {
@@ -1006,11 +1043,11 @@ __global__ __launch_bounds__(448, SW == 64 ? 4 : 6) void bandpass_rzcc_fast_kern
         // range (its position is the plateau midpoint) -- nobody else would claim it.
         if (!sp_.at_end && nextpos < own_hi) dead = true;
         if (!dead && s_open >= 0) {
-            const int first = *word_at(s_open) >> 1;
+            const int first = s_first;
             if (first >= own_lo && first < own_hi) {
                 // the open cluster is closed iff the next candidate is >= w away (or the stream ends here)
                 if (sp_.at_end || nextpos - l_last >= w)
-                    close_cluster(s_open, nPub[lane], l_last);
+                    close_cluster(s_open, nPub[lane], l_last, s_first);
                 else
                     dead = true;
             }

@@ -95,7 +95,14 @@ __global__ __launch_bounds__(256) void peak_location_kernel(const int32_t *__res
 
 hipError_t launch_peak_location(const int32_t *rate, int B, int G, int F, int win, int32_t *index, hipStream_t stream)
 {
-    hipLaunchKernelGGL(peak_location_kernel, dim3(B), dim3(256), (size_t)G * sizeof(long long), stream, rate, G, F, win, index);
+    const size_t dyn = (size_t)G * sizeof(long long);
+    if (dyn > 48 * 1024) {
+        // beyond the default dynamic-LDS limit (the API accepts G <= 16384 = 128 KB + 3 KB static of the CU's 160 KB)
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(peak_location_kernel),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(peak_location_kernel, dim3(B), dim3(256), dyn, stream, rate, G, F, win, index);
     return hipGetLastError();
 }
 

@@ -598,8 +598,9 @@ class StreamPipeline:
             state["next"] += 1
             if plans[i].generation != graphs[i][2]:
                 # the graph holds raw device pointers of tables / workspace that have been re-allocated since
-                raise _lib.MiclocError("stale HIP graph: the plan's tables or workspace were re-allocated after capture "
-                                       "(set_bf_mat / set_neuron_kernel with a larger table, or a larger batch); capture again")
+                raise _lib.MiclocError("stale HIP graph: the plan's tables or workspace were re-allocated, or a table changed its "
+                                       "shape, after capture (set_bf_mat / set_neuron_kernel with another size, or a larger batch); "
+                                       "capture again")
             with torch.cuda.stream(self.streams[i]):
                 graphs[i][0].replay()
             return graphs[i][1]

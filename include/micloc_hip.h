@@ -15,6 +15,10 @@
  *     scratch comes from the caller (`ws`, sized by micloc_workspace_bytes).
  *   - All stage calls are asynchronous on `stream`, re-entrant per plan+stream, and safe to capture
  *     in a hipGraph.  Return value: MICLOC_OK (0) or a negative micloc_status.
+ *   - A plan's calls launch on the plan's device; the entry points without a plan (synthesis, random
+ *     numbers, DoA error, design vectors, peak location, Xylo LIF, stand-alone operators) launch on the
+ *     device that OWNS their output / workspace buffer -- in both cases whatever the caller's current
+ *     device is (the previous current device is restored before the call returns).
  *   - All arithmetic is IEEE binary64 unless a name says otherwise (float32 before the
  *     encoder flips spikes).
  *
@@ -77,10 +81,12 @@ int micloc_plan_set_bf_mat(micloc_plan *plan, const double *W, int C, int G);
  * sig @ bf_mat.conj() (beamformer.py:290) */
 int micloc_plan_set_bf_mat_c128(micloc_plan *plan, const double *Wre, const double *Wim, int M, int G);
 
-/* Counter that changes whenever a device table of the plan was RE-ALLOCATED (set_neuron_kernel / set_bf_mat with a
- * table larger than any before).  A hipGraph captured from stage calls holds the raw table pointers: re-capture (or
- * refuse to replay) when the value differs from the one read at capture time.  Tables that fit the existing allocation
- * are overwritten in place after a device synchronisation and leave the counter -- and captured graphs -- valid. */
+/* Counter that changes whenever a hipGraph captured from this plan's stage calls has become stale: a device table was
+ * RE-ALLOCATED (set_neuron_kernel / set_bf_mat with a table larger than any before: the graph holds the raw pointer) or
+ * replaced by a table of ANOTHER SHAPE (other channel / DoA count, real vs complex, other neuron-kernel length: the graph
+ * holds those dimensions by value).  Re-capture (or refuse to replay) when the value differs from the one read at capture
+ * time.  A table of the same shape is overwritten in place after a device synchronisation and leaves the counter -- and
+ * captured graphs -- valid. */
 int micloc_plan_generation(const micloc_plan *plan);
 
 /* Time chunking of the band-pass / RZCC stage.  The stage is serial in time per (trial, channel) stream; with few, long
@@ -165,7 +171,7 @@ int micloc_lif_beamform_f32(const micloc_plan *plan, const int8_t *spikes, int B
  * power[b][g] = w_g^T (V^T V / T') w_g  ==  mean_t (V @ bf_mat)^2  without forming T x G.  An algebraically
  * identical VARIANT of micloc_lif_beamform_f64's power (2 C^2 instead of 2 C G flops per frame); it agrees to
  * ~1e-15 relative but is reported separately.  cov [B][C][C], power [B][G], argmax [B] may each be NULL.
- * Supports C <= 64 channels. */
+ * Supports C <= 128 channels (lif_cov_kernel up to 64, lif_cov_wide_kernel beyond). */
 int micloc_lif_covariance_f64(const micloc_plan *plan, const int8_t *spikes, int B, int T, int t_start, double *cov,
                               double *power, int32_t *argmax, void *ws, size_t ws_bytes, void *stream);
 /* whole chain (STHT, band-pass, RZCC, LIF) with the covariance-form tail */
@@ -246,14 +252,15 @@ int micloc_delay_min_f64(const double *doa, int B, int K, int moving_T, const do
                          double speed, double *shift, void *stream);
 
 /* ---- counter-based random numbers (throughput-mode sweeps) --------------------------------------- */
-/* Philox-4x32-10 keyed by `seed`; counter = (index, trial, substream).  The reference draws from NumPy's sequential
+/* Philox-4x32-10 keyed by `seed`; counter = (pair index, epoch, trial, substream); the uniforms use the reserved trial word
+ * 0xFFFFFFFF, so for one seed no two draws of any (generator, trial, substream, epoch) share a block.  The reference draws from NumPy's sequential
  * global MT19937 stream (target_snn_localization.py:452, snn_beamformer.py:273); parity runs replay that on the host,
  * throughput runs use these: out[i] = lo + (hi - lo) * u_i, u in [0, 1) with 53 bits (np.random.rand's range), and
  * x[b] += sigma_b * N(0, 1) (Box-Muller, fp64) with sigma_b = sqrt(mean(x[b]^2)) / sqrt(10^(snr_db[b] / 10))
  * (snn_beamformer.py:270-275) computed on the device from snr_db [B], or taken from `sigma` [B] when it is not NULL.
  * Trial b of the call uses counter word `first_trial + b`, so a sweep sharded over ranks draws the same noise for a
- * given global trial whatever the world size.  `epoch` (device uint32, may be NULL) is added to `substream` when the kernel
- * runs: a HIP graph that contains the generators draws fresh numbers on every replay once micloc_counter_add_u32 (also in
+ * given global trial whatever the world size (first_trial + B <= 0xFFFFFFFF).  `epoch` (device uint32, may be NULL: 0) is read when
+ * the kernel runs and is a counter word of its own: a HIP graph that contains the generators draws fresh numbers on every replay once micloc_counter_add_u32 (also in
  * the graph) advances it.  Device buffers; ws from micloc_awgn_workspace_bytes (256-B aligned). */
 int micloc_uniform_f64(double *out, size_t n, uint64_t seed, uint32_t substream, const uint32_t *epoch, double lo, double hi,
                        void *stream);

@@ -444,7 +444,8 @@ void oracle_xylo_lif(const unsigned char *spikes_in, int T, int Cin, const signe
  * 0xBB67AE85), pinned by the known-answer vectors of its kat_vectors file (tests/test_rng_cpu.py).
  * The reference itself draws from NumPy's sequential MT19937 (paper_plots/target_snn_localization.py:452,
  * micloc/snn_beamformer.py:270-275); this stream replaces it only where bit parity of the noise is not
- * asked for.  Same counter layout as the device: key = seed, counter = (index lo, index hi, trial, substream).
+ * asked for.  Same counter layout as the device: key = seed, counter = (pair index, epoch, trial, substream); the uniforms
+ * carry the reserved trial word 0xFFFFFFFF (disjoint from every trial's normals for any substream and epoch).
  * ---------------------------------------------------------------------------------------------- */
 void oracle_philox4x32_10(const unsigned int ctr[4], const unsigned int key[2], unsigned int out[4])
 {
@@ -467,12 +468,12 @@ static double u53_co(unsigned int lo, unsigned int hi) { return (double)((((unsi
 static double u53_oc(unsigned int lo, unsigned int hi) { return (double)(((((unsigned long long)hi << 32) | lo) >> 11) + 1) * 0x1.0p-53; }
 
 /* out[i] = lo + (hi - lo) * u_i, u in [0, 1): two per Philox call */
-void oracle_uniform(double *out, long long n, unsigned long long seed, unsigned int substream, double lo, double hi)
+void oracle_uniform(double *out, long long n, unsigned long long seed, unsigned int substream, unsigned int epoch, double lo, double hi)
 {
     const unsigned int key[2] = {(unsigned int)seed, (unsigned int)(seed >> 32)};
     const double span = hi - lo;
     for (long long pair = 0; 2 * pair < n; ++pair) {
-        const unsigned int ctr[4] = {(unsigned int)pair, (unsigned int)((unsigned long long)pair >> 32), 0u, substream};
+        const unsigned int ctr[4] = {(unsigned int)pair, epoch, 0xFFFFFFFFu, substream};
         unsigned int r[4];
         oracle_philox4x32_10(ctr, key, r);
         out[2 * pair] = lo + span * u53_co(r[0], r[1]);
@@ -481,11 +482,11 @@ void oracle_uniform(double *out, long long n, unsigned long long seed, unsigned 
 }
 
 /* z[e] for the flat [T][M] block of trial `trial`: Box-Muller, pair i -> elements 2i (cos), 2i+1 (sin) */
-void oracle_normals(double *z, long long n, unsigned long long seed, unsigned int substream, unsigned int trial)
+void oracle_normals(double *z, long long n, unsigned long long seed, unsigned int substream, unsigned int epoch, unsigned int trial)
 {
     const unsigned int key[2] = {(unsigned int)seed, (unsigned int)(seed >> 32)};
     for (long long pair = 0; 2 * pair < n; ++pair) {
-        const unsigned int ctr[4] = {(unsigned int)pair, (unsigned int)((unsigned long long)pair >> 32), trial, substream};
+        const unsigned int ctr[4] = {(unsigned int)pair, epoch, trial, substream};
         unsigned int r[4];
         oracle_philox4x32_10(ctr, key, r);
         const double u1 = u53_oc(r[0], r[1]);

@@ -40,8 +40,8 @@ void oracle_xylo_lif(const unsigned char *spikes_in, int T, int Cin, const signe
                      unsigned char *spikes_out, int *rate);
 
 void oracle_philox4x32_10(const unsigned int ctr[4], const unsigned int key[2], unsigned int out[4]);
-void oracle_uniform(double *out, long long n, unsigned long long seed, unsigned int substream, double lo, double hi);
-void oracle_normals(double *z, long long n, unsigned long long seed, unsigned int substream, unsigned int trial);
+void oracle_uniform(double *out, long long n, unsigned long long seed, unsigned int substream, unsigned int epoch, double lo, double hi);
+void oracle_normals(double *z, long long n, unsigned long long seed, unsigned int substream, unsigned int epoch, unsigned int trial);
 
 #ifdef __cplusplus
 }

@@ -66,8 +66,8 @@ def lib():
                                       ctypes.POINTER(ctypes.c_short), ctypes.c_int, _ubp, _ip]
         _up = ctypes.POINTER(ctypes.c_uint)
         L.oracle_philox4x32_10.argtypes = [_up, _up, _up]
-        L.oracle_uniform.argtypes = [_dp, ctypes.c_longlong, ctypes.c_ulonglong, ctypes.c_uint, ctypes.c_double, ctypes.c_double]
-        L.oracle_normals.argtypes = [_dp, ctypes.c_longlong, ctypes.c_ulonglong, ctypes.c_uint, ctypes.c_uint]
+        L.oracle_uniform.argtypes = [_dp, ctypes.c_longlong, ctypes.c_ulonglong, ctypes.c_uint, ctypes.c_uint, ctypes.c_double, ctypes.c_double]
+        L.oracle_normals.argtypes = [_dp, ctypes.c_longlong, ctypes.c_ulonglong, ctypes.c_uint, ctypes.c_uint, ctypes.c_uint]
         _lib = L
     return _lib
 
@@ -362,19 +362,19 @@ def philox4x32_10(ctr, key):
     return [int(v) for v in o]
 
 
-def uniform(n, seed, substream=0, lo=0.0, hi=1.0):
+def uniform(n, seed, substream=0, lo=0.0, hi=1.0, epoch=0):
     out = np.empty(int(n))
-    lib().oracle_uniform(out.ctypes.data_as(_dp), int(n), int(seed), int(substream), float(lo), float(hi))
+    lib().oracle_uniform(out.ctypes.data_as(_dp), int(n), int(seed), int(substream), int(epoch), float(lo), float(hi))
     return out
 
 
-def normals(n, seed, substream, trial):
+def normals(n, seed, substream, trial, epoch=0):
     z = np.empty(int(n))
-    lib().oracle_normals(z.ctypes.data_as(_dp), int(n), int(seed), int(substream), int(trial))
+    lib().oracle_normals(z.ctypes.data_as(_dp), int(n), int(seed), int(substream), int(epoch), int(trial))
     return z
 
 
-def awgn(x, snr_db, seed, substream=0, first_trial=0):
+def awgn(x, snr_db, seed, substream=0, first_trial=0, epoch=0):
     """x [B, T, M] + sigma_b * N(0, 1), sigma_b = sqrt(mean(x_b^2)) / sqrt(10^(snr_db_b / 10)) (snn_beamformer.py:270-275)
     with the device's Philox stream.  Returns (noisy, sigma)."""
     x = np.asarray(x, dtype=np.float64)
@@ -383,7 +383,7 @@ def awgn(x, snr_db, seed, substream=0, first_trial=0):
     sigma = np.sqrt(np.mean(x.reshape(B, -1) ** 2, axis=1)) / np.sqrt(10 ** (snr_db / 10))
     out = x.copy()
     for b in range(B):
-        out[b] += sigma[b] * normals(x[b].size, seed, substream, first_trial + b).reshape(x[b].shape)
+        out[b] += sigma[b] * normals(x[b].size, seed, substream, first_trial + b, epoch).reshape(x[b].shape)
     return out, sigma
 
 

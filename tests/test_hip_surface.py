@@ -377,3 +377,45 @@ def test_integration_md_ctypes_stub_runs(cfg2):
     np.testing.assert_array_equal(y, want)
     with pytest.raises(ValueError):
         ns["apply_to_signal"](plan, sig, cfg2["nir"], cfg2["bf_mat"][:10])
+
+
+def test_captured_graph_goes_stale_when_a_table_changes_shape(cfg2):
+    """A captured hipGraph holds the tables' dimensions by value.  A bf_mat with fewer DoAs (or a shorter neuron kernel)
+    fits the old allocation and is written in place: the plan's generation must change all the same and replay() must
+    refuse, instead of reading the new table with the old stride.  Same-shape replacements keep the graph."""
+    import torch
+
+    from haghighatshoarmuir2024_amd import _lib, runtime
+
+    z = golden("trials_cfg2.npz")
+    plan = runtime.Plan(7, cfg2["kernel"], cfg2["b"], cfg2["a"], cfg2["robust_width"], True)
+    plan.set_neuron_kernel(cfg2["nir"])
+    W = cfg2["bf_mat"]
+    plan.set_bf_mat(W)
+    x = plan.to_device(z["sig_in"])
+    pipe = runtime.StreamPipeline([plan])
+    replay = pipe.capture(lambda p: p.snn_pipeline(x, want_power=True))
+    ref = {k: v.clone() for k, v in replay().items() if v is not None}
+    pipe.synchronize()
+    # same shape, other values: in place, the graph stays valid and sees the new table
+    gen0 = plan.generation
+    plan.set_bf_mat(2.0 * W)
+    assert plan.generation == gen0
+    out = replay()
+    pipe.synchronize()
+    torch.testing.assert_close(out["power"], 4.0 * ref["power"], rtol=1e-12, atol=0)
+    # fewer DoAs: fits the allocation, changes the layout
+    plan.set_bf_mat(W[:, :200])
+    assert plan.generation != gen0
+    with pytest.raises(_lib.MiclocError, match="stale HIP graph"):
+        replay()
+    # a shorter neuron kernel likewise
+    plan.set_bf_mat(W)
+    replay2 = pipe.capture(lambda p: p.snn_pipeline(x, want_power=True))
+    replay2()
+    pipe.synchronize()
+    gen1 = plan.generation
+    plan.set_neuron_kernel(cfg2["nir"][:20])
+    assert plan.generation != gen1
+    with pytest.raises(_lib.MiclocError, match="stale HIP graph"):
+        replay2()

@@ -75,6 +75,11 @@ def test_uniform_bit_exact_and_awgn_against_oracle():
     for n in (1, 2, 7, 1000, 100_001):
         u = runtime.uniform(n, seed, substream=2, lo=0.0, hi=2 * np.pi).cpu().numpy()
         np.testing.assert_array_equal(u, O.uniform(n, seed, 2, 0.0, 2 * np.pi))
+    # the epoch word (a device counter a captured graph advances): its own counter word, equal to the oracle's
+    ep = torch.full((1,), 5, dtype=torch.int32, device="cuda")
+    u5 = runtime.uniform(1000, seed, substream=2, lo=0.0, hi=1.0, epoch=ep).cpu().numpy()
+    np.testing.assert_array_equal(u5, O.uniform(1000, seed, 2, 0.0, 1.0, epoch=5))
+    assert not np.array_equal(u5, O.uniform(1000, seed, 7, 0.0, 1.0))
     rng = np.random.RandomState(1)
     for shape in ((3, 4799, 7), (2, 33, 3), (1, 1, 1), (2, 8192 // 7 + 5, 7)):
         x = rng.randn(*shape) * np.linspace(0.5, 3.0, shape[0])[:, None, None]
@@ -90,6 +95,11 @@ def test_uniform_bit_exact_and_awgn_against_oracle():
             xs = torch.from_numpy(x[1:]).cuda()
             runtime.awgn_(xs, snr_db=snr[1:], seed=seed, substream=1, first_trial=41)
             np.testing.assert_array_equal(xs.cpu().numpy(), got[1:])
+    x1 = rng.randn(2, 501, 3)
+    want1, sg1 = O.awgn(x1, [3.0, 4.0], seed=seed, substream=1, first_trial=9, epoch=6)
+    xd1 = torch.from_numpy(x1).cuda()
+    runtime.awgn_(xd1, snr_db=np.array([3.0, 4.0]), seed=seed, substream=1, first_trial=9, epoch=torch.full((1,), 6, dtype=torch.int32, device="cuda"))
+    np.testing.assert_allclose(xd1.cpu().numpy() - x1, want1 - x1, rtol=0, atol=1e-12 * sg1.max())
     # explicit sigma, statistics of a large draw
     xz = torch.zeros((4, 100_000, 7), dtype=torch.float64, device="cuda")
     runtime.awgn_(xz, sigma=np.array([1.0, 2.0, 0.5, 1.0]), seed=7)

@@ -18,13 +18,34 @@ def test_philox_known_answers():
 def test_uniform_mapping_and_layout():
     u = O.uniform(1001, seed=(5 << 32) | 9, substream=3, lo=0.0, hi=1.0)
     assert u.min() >= 0.0 and u.max() < 1.0
-    # element 2i / 2i+1 come from words (0,1) / (2,3) of counter (i, 0, 0, substream), key (seed lo, seed hi)
-    r = O.philox4x32_10([7, 0, 0, 3], [9, 5])
+    # element 2i / 2i+1 come from words (0,1) / (2,3) of counter (i, epoch, 0xFFFFFFFF, substream), key (seed lo, seed hi)
+    r = O.philox4x32_10([7, 0, 0xFFFFFFFF, 3], [9, 5])
     assert u[14] == ((r[1] << 32 | r[0]) >> 11) * 2.0**-53
     assert u[15] == ((r[3] << 32 | r[2]) >> 11) * 2.0**-53
     v = O.uniform(1001, seed=(5 << 32) | 9, substream=3, lo=0.0, hi=2 * np.pi)
     np.testing.assert_array_equal(v, 0.0 + (2 * np.pi - 0.0) * u)
     assert not np.array_equal(u, O.uniform(1001, seed=(5 << 32) | 9, substream=4))
+    # the epoch is a counter word of its own: (substream s, epoch e) is not (s + e, 0)
+    ue = O.uniform(1001, seed=(5 << 32) | 9, substream=3, epoch=1)
+    assert not np.array_equal(ue, O.uniform(1001, seed=(5 << 32) | 9, substream=4))
+    r = O.philox4x32_10([7, 1, 0xFFFFFFFF, 3], [9, 5])
+    assert ue[14] == ((r[1] << 32 | r[0]) >> 11) * 2.0**-53
+
+
+def test_generators_do_not_share_blocks():
+    """Same seed, default substream / epoch: the uniforms (DoA draws) and trial 0's normals come from different Philox
+    blocks (round 2 drew both from counter (i, 0, 0, 0))."""
+    seed = 77
+    r_uni = O.philox4x32_10([5, 0, 0xFFFFFFFF, 0], [seed, 0])
+    r_nrm = O.philox4x32_10([5, 0, 0, 0], [seed, 0])
+    assert r_uni != r_nrm
+    u = O.uniform(12, seed)
+    assert u[10] == ((r_uni[1] << 32 | r_uni[0]) >> 11) * 2.0**-53
+    z = O.normals(12, seed, 0, 0)
+    u1 = (((r_nrm[1] << 32 | r_nrm[0]) >> 11) + 1) * 2.0**-53
+    assert np.isclose(z[10] ** 2 + z[11] ** 2, -2 * np.log(u1), rtol=1e-12)
+    # epochs of the normals are disjoint from neighbouring substreams
+    assert not np.array_equal(O.normals(64, seed, 0, 3, epoch=1), O.normals(64, seed, 1, 3, epoch=0))
 
 
 def test_normals_statistics_and_trial_independence():

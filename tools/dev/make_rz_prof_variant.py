@@ -56,15 +56,24 @@ extern "C" int micloc_debug_rz_prof(unsigned long long *out24, int reset)
     return 0;
 }
 ''')
-tmp = os.path.join(CS, "rzcc_prof_tmp.hip")
+# ablations (wrong results, timing attribution only): --ablate nostore | noresolve | nodetectloop
+abl = sys.argv[sys.argv.index("--ablate") + 1] if "--ablate" in sys.argv else ""
+if "nostore" in abl:
+    s = s.replace("            sp[(size_t)pos * C] = mark;\n", "            asm volatile(\"\" ::\"v\"(pos));\n")
+if "noresolve" in abl:
+    s = s.replace("            resolve_cluster(s, e, stride, w, emit, word_at, val_at, sgn);", "            emit(lastpos);")
+if "nodetectloop" in abl:
+    s = s.replace("                while (__any(Ew != 0u)) {\n                    if (Ew) {", "                while (false) {\n                    if (Ew) {")
+tmp = os.path.join(CS, "rzcc_prof_tmp_%s.hip" % (abl or "plain"))
+obj = "/tmp/rzcc_prof_%s.o" % (abl or "plain")
 open(tmp, "w").write(s)
 try:
     flags = "-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -Wno-unused-result".split()
-    subprocess.check_call(["/opt/rocm/bin/hipcc"] + flags + ["-c", "-o", "/tmp/rzcc_prof.o", tmp])
+    subprocess.check_call(["/opt/rocm/bin/hipcc"] + flags + ["-c", "-o", obj, tmp])
 finally:
     if "--keep" not in sys.argv:
         os.remove(tmp)
 objs = [os.path.join(CS, o) for o in "api.o stht.o beamform.o xylo.o synth.o covariance.o beamform_f32.o sweep.o rng.o design.o".split()]
 os.makedirs(os.path.join(ROOT, "tools", "_variants"), exist_ok=True)
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", os.path.join(ROOT, "tools", "_variants", "libmicloc_hip_prof.so"), "/tmp/rzcc_prof.o"] + objs)
-print("built tools/_variants/libmicloc_hip_prof.so")
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", os.path.join(ROOT, "tools", "_variants", "libmicloc_hip_prof%s.so" % (("_" + abl) if abl else "")), obj] + objs)
+print("built variant", abl or "(plain)")

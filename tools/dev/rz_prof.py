@@ -5,7 +5,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from haghighatshoarmuir2024_amd import _lib
-_lib.LIB_PATH = os.path.join(ROOT, "tools", "_variants", "libmicloc_hip_prof.so")
+_lib.LIB_PATH = os.path.join(ROOT, "tools", "_variants", "libmicloc_hip_prof%s.so" % os.environ.get("RZ_VARIANT", ""))
 import torch
 from haghighatshoarmuir2024_amd import runtime, synthesis
 from haghighatshoarmuir2024_amd.array_geometry import CenterCircularArray
