@@ -53,6 +53,8 @@ def parse(argv=None):
     ap.add_argument("--trials", type=int, default=None, help="trials per rank per step (default: 1100 = 11 SNRs x 100; speech 125; stress 256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of each cpu_baseline leg")
+    ap.add_argument("--repeats", type=int, default=5, help="the K-step timed region is run this many times; ms_per_step / value are the median")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the speech / xylo / stress child runs and the reference-MAE / per-call blocks")
     ap.add_argument("--streams", type=int, default=3, help="HIP streams consecutive steps are pipelined over (1 = serial)")
     ap.add_argument("--encoder-chunk", type=int, default=None, help="frames per time chunk of the band-pass / RZCC stage (default: the library's automatic choice; < 0: never chunk)")
     ap.add_argument("--traffic-bytes", type=float, default=None, help="override roofline.traffic (HBM bytes per dominant-kernel launch)")
@@ -465,6 +467,105 @@ def run_stub(args, rank, world):
     return 0
 
 
+
+# ----------------------------------------------------------------------------------------------------------------
+# blocks of the default (noisy, one GPU) line that are not the timed region
+# ----------------------------------------------------------------------------------------------------------------
+def reference_mae_block(device):
+    """'DoA MAE vs ref' of the metric: ONE un-timed pass of the reference's own accuracy sweep
+    (paper_plots/target_snn_localization.py:435-467 prints the MAE per SNR at :519-520) in parity mode -- the reference's bf_mat
+    (its LAPACK phases, tests/golden/bf_mat_chirp449_bipolar.npz), its global MT19937 stream (np.random.seed(0): rand(1) then
+    randn(T, M) per trial), its script-exact grid of 449 DoAs, 11 SNRs x 100 trials -- against the MAE curve the reference
+    itself produced on those draws (tests/golden/sweep_full_seed0.npz, generated by tests/golden/make_golden.py)."""
+    from haghighatshoarmuir2024_amd.array_geometry import CenterCircularArray
+    from haghighatshoarmuir2024_amd.snn_beamformer import SNNBeamformer
+    from haghighatshoarmuir2024_amd.sweep import noisy_target_sweep
+
+    gold = os.path.join(ROOT, "tests", "golden")
+    z = np.load(os.path.join(gold, "sweep_full_seed0.npz"))
+    bfz = np.load(os.path.join(gold, "bf_mat_chirp449_bipolar.npz"))
+    tau = 1.0 / (2 * np.pi * 2000.0)
+    beamf = SNNBeamformer(geometry=CenterCircularArray(radius=4.5e-2, num_mic=7), kernel_duration=10.0e-3, tau_vec=np.asarray([tau, tau]),
+                          freq_range=[1000.0, 2000.0], fs=48_000, bipolar_spikes=True, device=device)
+    t0 = time.perf_counter()
+    res = noisy_target_sweep(beamf, bfz["bf_mat"], bfz["doa_list"], num_sim=100, seed=int(z["seed"]), mode="parity")
+    dt = time.perf_counter() - t0
+    return {"mae_ref_deg_per_snr": [float(v) for v in z["mae_deg"]], "mae_deg_per_snr": [float(v) for v in res["mae_deg"]],
+            "snr_db": [float(v) for v in z["snr_db_vec"]],
+            "max_abs_diff_vs_ref_deg": float(np.max(np.abs(res["mae_deg"] - z["mae_deg"]))),
+            "argmax_equal_to_ref": int(np.sum(res["argmax"] == z["argmax"])), "trials": int(z["argmax"].size),
+            "max_rel_pmax_diff_vs_ref": float(np.max(np.abs(res["pmax"] / z["pmax"] - 1))),
+            "num_doa": int(len(bfz["doa_list"])), "seconds": dt,
+            "note": "parity mode, un-timed: the reference's bf_mat fixture, np.random.seed(0) MT19937 stream replayed on the host in the "
+                    "reference's draw order, 449-DoA script grid, 11 SNRs x 100 trials; `mae_ref_deg_per_snr` is the reference's own output on "
+                    "the same draws (tests/golden/sweep_full_seed0.npz); the timed headline uses Philox noise and a device-designed bf_mat"}
+
+
+def api_per_call_block(device, calls=40):
+    """The unchanged-script path: SNNBeamformer.apply_to_template once per trial, B = 1, the T x G array returned to the
+    host (paper_plots/target_snn_localization.py:455; the reference takes 24.7-27.5 ms per trial on 8 vCPUs)."""
+    import torch
+
+    from haghighatshoarmuir2024_amd.array_geometry import CenterCircularArray
+    from haghighatshoarmuir2024_amd.snn_beamformer import SNNBeamformer
+
+    bfz = np.load(os.path.join(ROOT, "tests", "golden", "bf_mat_chirp449_bipolar.npz"))
+    tau = 1.0 / (2 * np.pi * 2000.0)
+    beamf = SNNBeamformer(geometry=CenterCircularArray(radius=4.5e-2, num_mic=7), kernel_duration=10.0e-3, tau_vec=np.asarray([tau, tau]),
+                          freq_range=[1000.0, 2000.0], fs=48_000, bipolar_spikes=True, device=device)
+    time_test = np.arange(0, 100e-3, step=1 / 48_000)
+    sig_test = np.sin(2 * np.pi * 2000.0 * time_test)
+    np.random.seed(0)
+    bf_mat = bfz["bf_mat"]
+    snr_db = 5.0 - 10 * np.log10(24.0)
+
+    def one():
+        doa = np.random.rand(1)[0] * 2 * np.pi
+        y = beamf.apply_to_template(bf_mat=bf_mat, template=(time_test, sig_test, doa), snr_db=snr_db)
+        power = np.mean(np.abs(y) ** 2, axis=0)
+        return y, int(np.argmax(power))
+
+    for _ in range(3):
+        y, _ = one()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(calls):
+        t0 = time.perf_counter()
+        one()
+        ts.append(time.perf_counter() - t0)
+    ts = np.asarray(ts) * 1e3
+    return {"apply_to_template_ms": float(np.median(ts)), "min_ms": float(ts.min()), "max_ms": float(ts.max()), "calls": calls,
+            "returns": f"numpy float64 [{y.shape[0]} x {y.shape[1]}] on the host ({y.nbytes / 1e6:.1f} MB D2H per call)",
+            "frames_per_s": float(y.shape[0] / (np.median(ts) * 1e-3)),
+            "reference_ms_per_trial": "24.7-27.5 (8 vCPU Xeon 2.1 GHz, SURVEY 6)",
+            "note": "one trial per call exactly as the script's loop does it: host synthesis + host MT19937 noise (reference draw order), H2D, "
+                    "STHT -> RZCC -> LIF -> beamforming with y stored, D2H of T x G, power / arg-max in NumPy; PCIe- and host-bound, never `value`"}
+
+
+def other_configs_block(args):
+    """The other BASELINE configs on the same box, a few steps each, as CHILD processes of this (GPU-initialised) process --
+    started, never exec'ed; one at a time."""
+    out = {}
+    for cfg, steps in (("speech", 3), ("xylo", 3), ("stress", 3)):
+        cmd = [sys.executable, os.path.abspath(__file__), "--config", cfg, "--steps", str(steps), "--warmup", "1", "--repeats", "3",
+               "--no-cpu-baseline", "--no-other-configs", "--streams", str(args.streams)]
+        t0 = time.perf_counter()
+        try:
+            p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
+            lines = [ln for ln in p.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
+            d = json.loads(lines[-1])
+            r = d["roofline"]
+            out[cfg] = {"ms_per_step": d["ms_per_step"], "value": d["value"], "unit": "frames/s", "workload": d["config"]["workload"],
+                        "roofline": {k: r.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_ms")},
+                        "stages_ms": r.get("stages_ms"), "steps": d["steps"], "wall_s": time.perf_counter() - t0}
+            if "parity" in d:
+                out[cfg]["parity"] = "unpinned"
+                out[cfg]["parity_note"] = d["parity"]
+        except Exception as e:  # a failed child run is reported, it does not take the headline line down
+            out[cfg] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    return out
+
+
 XYLO_VALU_PER_WAVE_STEP = 20  # vector instructions per wave (128 neurons, two per lane) and time step: 18 of the packed update +
 #                               2 v_perm that pair the matrix-core currents (ISA of xylo_lif_pk_kernel<1, false>, see DESIGN.md)
 
@@ -541,18 +642,22 @@ def run_xylo(args, rank, local_rank, world):
 
     for _ in range(args.warmup):
         replay()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        counts, idx, mae = replay()
-    barrier()
-    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+    dt_all = []
+    for _ in range(max(1, args.repeats)):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            counts, idx, mae = replay()
+        barrier()
+        dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+        if use_dist:
+            dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        dt_all.append(float(dt.item()))
     if use_dist:
-        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
         gathered = [torch.empty_like(mae) for _ in range(world)]
         dist.all_gather(gathered, mae)
         mae = torch.stack(gathered).mean(dim=0)
-    dt = float(dt.item())
+    dt = float(np.median(dt_all))
     frames = group_size * B * T * args.steps
     result = None
     if rank == 0:
@@ -603,7 +708,8 @@ def run_xylo(args, rank, local_rank, world):
             "metric": "audio samples/sec through STHT+RZCC+SNN beamform, 7-mic 48kHz 360-DoA; DoA MAE vs ref",
             "value": value, "unit": "frames/s (one frame = one audio sample instant across all mics)",
             "n_gpus": group_size, "rccl_ranks": group_size if use_dist else 0, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": dt / args.steps * 1e3, "ms_per_step_repeats": [t / args.steps * 1e3 for t in dt_all],
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64 encoder + int16 LIF state / int8 weights", "data": "synthetic",
             "parity": "UNPINNED for the integer-LIF stage (rockpool / XyloSim absent); spike encoding and peak finding pinned",
             "config": {"workload": f"target_xylo_localization sweep (Xylo-A2 integer LIF, bipolar RZCC): {M}-mic, {fs // 1000} kHz, T={T} (1 s chirp), "
@@ -665,20 +771,26 @@ def run(args):
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed_steps(fn):
+    def timed_steps(fn, repeats=1):
+        """W warm-up steps, then `repeats` timed regions of EXACTLY K steps, each bracketed by barrier + synchronize on both
+        sides and reduced with MAX over ranks.  Returns (median seconds per region, all regions, last result)."""
         for _ in range(args.warmup):
             fn()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            res = fn()
-        barrier()
-        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
-        if use_dist:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item()), res
+        times = []
+        res = None
+        for _ in range(max(1, repeats)):
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                res = fn()
+            barrier()
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+            if use_dist:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            times.append(float(t.item()))
+        return float(np.median(times)), times, res
 
-    dt, (out, mae) = timed_steps(step)
+    dt, dt_all, (out, mae) = timed_steps(step, args.repeats)
     if use_dist:
         # the sweep's one exchange step: gather the per-rank MAE curves (RCCL)
         gathered = [torch.empty_like(mae) for _ in range(world)]
@@ -690,7 +802,7 @@ def run(args):
     power_direct = out["power"].clone()
 
     # the same K steps with the input side inside the graph (synthesis + noise regenerated every step)
-    dte, (out_e, mae_e) = timed_steps(lambda: step(cov="e2e"))
+    dte, _, (out_e, mae_e) = timed_steps(lambda: step(cov="e2e"), min(args.repeats, 3))
     if use_dist:
         gathered = [torch.empty_like(mae_e) for _ in range(world)]
         dist.all_gather(gathered, mae_e)
@@ -703,14 +815,14 @@ def run(args):
     cov_variant = f32_variant = None
     if M * 2 <= 128:
         # separately reported algorithmic variant: covariance-form power, same K steps, same inputs
-        dtc, (out_c, _) = timed_steps(lambda: step(cov=True))
+        dtc, _, (out_c, _) = timed_steps(lambda: step(cov=True))
         cov_variant = {"value": frames / dtc, "unit": "frames/s", "ms_per_step": dtc / args.steps * 1e3,
                        "argmax_equal_to_direct": bool(torch.equal(out_c["argmax"], argmax_direct)),
                        "max_rel_power_diff_vs_direct": float((out_c["power"] / power_direct - 1).abs().max().item()),
                        "note": "power = w^T (V^T V / T) w instead of mean_t (V w)^2: algebraically identical, 2C^2 instead of 2CG flops per frame; not the headline"}
     if noisy and M * 2 <= 64:
         # second separately reported variant: fp32-MFMA beamforming tail (fp64 up to the spikes)
-        dtf, (out_f, _) = timed_steps(lambda: step(cov="f32"))
+        dtf, _, (out_f, _) = timed_steps(lambda: step(cov="f32"))
         relerr = float((out_f["power"] / power_direct - 1).abs().max().item())
         f32_variant = {"value": frames / dtf, "unit": "frames/s", "ms_per_step": dtf / args.steps * 1e3,
                        "argmax_equal_to_f64": int((out_f["argmax"] == argmax_direct).sum().item()), "trials": int(B),
@@ -731,26 +843,30 @@ def run(args):
         dom = max(st, key=st.get)
         frames_launch = B * T
         traffic_src = None
+        serial_stage = None
         if dom == "bandpass_rzcc_kernel":
-            # latency-bound sequential stage: price it against HBM with its algorithmic bytes (8 B in per channel sample + 1 B spike out)
-            achieved = frames_launch * (8 * C + C) / (st[dom] * 1e-3) / 1e9
-            roof = dict(kernel=KERNEL_SYMBOL[dom], bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
-                        traffic=args.traffic_bytes,
-                        note="bit-exactness makes the time axis of every (trial, channel) stream a serial dependency chain (DF2T + running "
-                             "sum): this stage is bound by single-wave instruction issue x stream length, not by HBM; long streams are "
-                             "cut into chunks behind a serial scan (rzcc_scan_kernel, ~72 cycles per step on a handful of CUs) that "
-                             "overlaps the neighbouring steps' STHT / beamforming -- see DESIGN.md 4.2")
-        else:
-            achieved = frames_launch * flops[dom] / (st[dom] * 1e-3) / 1e12
-            traffic = args.traffic_bytes
-            if traffic is None and dom == "beamform_kernel" and C <= 16:
-                # launch size of beamform_ws_kernel: 256-frame chunks x 512 work-items per trial
-                traffic, traffic_src = traffic_from_profiles(KERNEL_SYMBOL[dom], -(-T // 256) * 512 * B, args.pmc_summary)
-            sym = KERNEL_SYMBOL.get(dom, dom)
-            if dom == "beamform_kernel" and C > 64:
-                sym = "beamform_slab_kernel"
-            roof = dict(kernel=sym, bound="mfma", achieved=achieved, peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
-                        frac=achieved / FP64_MFMA_PEAK_TFLOPS, traffic=traffic)
+            # The longest BRACKET is the band-pass / RZCC stage: a serial dependency chain per (trial, channel) stream (DF2T +
+            # running sum; long streams are cut into chunks behind a serial scan, rzcc_scan_kernel, on a handful of CUs).  It is
+            # latency, not throughput, and in the pipelined step it runs beside the neighbouring steps' kernels -- it sits on no
+            # roof.  The roofline object therefore prices the dominant THROUGHPUT kernel; the stage is reported beside it.
+            serial_stage = {"stage": "bandpass_rzcc", "ms": st[dom], "algorithmic_GBs": frames_launch * (8 * C + C) / (st[dom] * 1e-3) / 1e9,
+                            "encoder_chunks": int(wl["plan"].encoder_chunks(B, T)),
+                            "note": "serial-latency stage (scan + chunked encoder), overlapped with the other kernels of neighbouring steps; see DESIGN.md 4.2"}
+            dom = max((k for k in st if k != "bandpass_rzcc_kernel"), key=st.get)
+        achieved = frames_launch * flops[dom] / (st[dom] * 1e-3) / 1e12
+        traffic = args.traffic_bytes
+        if traffic is None and dom == "beamform_kernel" and C <= 16:
+            # launch size of beamform_ws_kernel: 256-frame chunks x 512 work-items per trial
+            traffic, traffic_src = traffic_from_profiles(KERNEL_SYMBOL[dom], -(-T // 256) * 512 * B, args.pmc_summary)
+        sym = KERNEL_SYMBOL.get(dom, dom)
+        if dom == "beamform_kernel" and C > 64:
+            sym = "beamform_slab_kernel"
+        roof = dict(kernel=sym, bound="mfma", achieved=achieved, peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                    frac=achieved / FP64_MFMA_PEAK_TFLOPS, traffic=traffic)
+        if dom == "stht_kernel":
+            roof["note"] = "fp64 vector FMAs (the fp64 vector and matrix peaks of gfx950 are the same 78.6 TF); dense-tap flops as the reference computes them"
+        if serial_stage:
+            roof["serial_stage"] = serial_stage
         roof["traffic_source"] = traffic_src
         roof["avg_launch_ms"] = st[dom]
         roof["stages_ms"] = st
@@ -765,6 +881,8 @@ def run(args):
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
+            "ms_per_step_repeats": [t / args.steps * 1e3 for t in dt_all],
+            "timing_note": f"median of {len(dt_all)} timed regions of exactly {args.steps} steps each (barrier + synchronize on both sides, max over ranks)",
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -787,6 +905,11 @@ def run(args):
                              "note": "compute-bound path (about 300 flop/B): small by construction, the binding roof is in `roofline`"},
             "variants": {"covariance_power": cov_variant, "f32_mfma_beamform": f32_variant},
         }
+        if noisy and group_size == 1 and not args.no_other_configs:
+            torch.cuda.synchronize()
+            result["mae_ref"] = reference_mae_block(device)
+            result["api_per_call_ms"] = api_per_call_block(device)
+            result["other_configs"] = other_configs_block(args)
         if not args.no_cpu_baseline and group_size == 1 and noisy:
             cb, am = cpu_baseline(wl, args.cpu_seconds)
             am_gpu = argmax_direct.cpu().numpy()

@@ -395,8 +395,9 @@ def test_captured_graph_goes_stale_when_a_table_changes_shape(cfg2):
     x = plan.to_device(z["sig_in"])
     pipe = runtime.StreamPipeline([plan])
     replay = pipe.capture(lambda p: p.snn_pipeline(x, want_power=True))
-    ref = {k: v.clone() for k, v in replay().items() if v is not None}
-    pipe.synchronize()
+    out = replay()
+    pipe.synchronize()  # (the outputs belong to the pipeline's stream)
+    ref = {k: v.clone() for k, v in out.items() if v is not None}
     # same shape, other values: in place, the graph stays valid and sees the new table
     gen0 = plan.generation
     plan.set_bf_mat(2.0 * W)
