@@ -81,6 +81,8 @@ SYMBOLS = {
     "micloc_lfilter_f64": (c_int, [c_double_p, c_double_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "micloc_lif_beamform_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "micloc_lif_covariance_f64": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "micloc_planar_gram_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "micloc_planar_gram_f64": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "micloc_snn_pipeline_cov_f64": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "micloc_synth_delay_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, ctypes.c_double, c_void_p, c_void_p]),
     "micloc_synth_targets_f64": (c_int, [c_void_p, c_void_p]),

@@ -5,8 +5,8 @@ reference method                      -> what runs here
   apply_to_signal      :260-292       -> micloc_beamformer_pipeline_f64: STHT, band-pass, (T x 2M) @ stacked real
                                          form of conj(bf_mat) on the fp64 matrix cores
   apply_to_template    :194-258       -> host synthesis (same np.random draws) + the above
-  design_from_template :73-192        -> STHT on the GPU per DoA, complex covariance + SVD / generalised eigh on the
-                                         host (LAPACK, like the reference)
+  design_from_template :73-192        -> STHT and the complex covariance (micloc_planar_gram_f64) on the GPU per DoA; the M x M
+                                         SVD / generalised eigh on the host (LAPACK, like the reference: its phases)
   localize_batch (new)                -> power [B,G], arg-max [B] for a batch of trials, no T x G temporary
 """
 from numbers import Number
@@ -102,13 +102,11 @@ class Beamformer:
             sig = np.ascontiguousarray(np.transpose(sig, (0, 2, 1)))  # [n, T, M]
             T = sig.shape[1]
             # NOTE (reference :137-150): the covariance uses the STHT output *before* band-pass filtering
-            h = plan.stht(plan.to_device(sig))[:, :, :T]  # planar [n, 2M, T]
-            import torch
-
-            hc = torch.complex(h[:, :M, :], h[:, M:, :])  # [n, M, T]
+            h = plan.stht(plan.to_device(sig))  # planar [n, 2M, Ts]: rows re_0..re_{M-1}, im_0..im_{M-1}
             stable = min(len(self.kernel), T // 2)
-            hs = hc[:, :, stable:]
-            cov = (hs.conj() @ hs.transpose(1, 2) / hs.shape[2]).cpu().numpy()  # conj(h)^T h -> [n, M, M]
+            # conj(h)^T h / T' over the stable part = a fold of the real 2M x 2M Gram matrix (fp64 MFMA kernel, csrc/covariance.hip)
+            R = runtime.planar_gram(h, T, t_start=stable, normalise=True).cpu().numpy()
+            cov = (R[:, :M, :M] + R[:, M:, M:]) + 1j * (R[:, :M, M:] - R[:, M:, :M])  # [n, M, M]
             cov_mat_list.extend(list(cov))
 
         bf_mat = []

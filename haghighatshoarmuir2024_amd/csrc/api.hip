@@ -653,6 +653,24 @@ int micloc_snn_pipeline_cov_f64(const micloc_plan *p, const double *x, int B, in
     return MICLOC_OK;
 }
 
+// ---- Gram matrix of a planar signal (complex covariance of Beamformer.design_from_template) ------------------------------
+size_t micloc_planar_gram_workspace_bytes(int B, int T, int C, int t_start)
+{
+    if (B < 1 || T < 1 || C < 1 || t_start < 0 || t_start >= T) return 0;
+    return align256(planar_gram_partial_bytes(B, T, C, t_start));
+}
+
+int micloc_planar_gram_f64(const double *planar, int B, int C, int T, int Ts, int t_start, int normalise, double *gram, void *ws,
+                           size_t ws_bytes, void *stream)
+{
+    if (!planar || !gram || bad_batch(B) || C < 1 || C > 128 || T < 1 || t_start < 0 || t_start >= T) return MICLOC_ERR_INVALID;
+    if (Ts < T) return MICLOC_ERR_SHAPE;
+    if (bad_ws(ws, ws_bytes, planar_gram_partial_bytes(B, T, C, t_start))) return MICLOC_ERR_WORKSPACE;
+    DeviceGuard guard(device_of(gram));
+    HIP_TRY(launch_planar_gram(planar, B, C, T, Ts, t_start, normalise, gram, reinterpret_cast<double *>(ws), (hipStream_t)stream));
+    return MICLOC_OK;
+}
+
 // ---- array-signal synthesis (noise-free part of apply_to_template) -------------------------------------------
 int micloc_synth_delay_f64(const double *time, const double *sig, const double *slopes, int T, const double *delays,
                            int B, int M, double fs, double *x, void *stream)

@@ -411,4 +411,85 @@ hipError_t launch_cov_power(const double *partial, int B, int T, int CT, int C, 
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Gram matrix of a planar signal:  R[b] = sum_{t >= t_start} x[b][:, t] x[b][:, t]^T  (/ (T - t_start)),  x planar [B][C][Ts].
+//
+// Beamformer.design_from_template (micloc/beamformer.py:142-150) needs the complex covariance conj(h)^T h / T' of the STHT
+// output h = re + j im over the stable part of each delayed template; with the planar rows [re_0.. re_{M-1}, im_0.. im_{M-1}]
+// it is a fold of the REAL 2M x 2M Gram matrix:  cov = (R_rr + R_ii) + j (R_ri - R_ir).
+//
+// One wave per (trial, time chunk, 16 x 16 tile pair).  In v_mfma_f64_16x16x4_f64 the A fragment of lane l is A[i = l & 15][k = l >> 4]
+// and the B fragment B[k = l >> 4][j = l & 15]: for a Gram product both are x[channel = l & 15][time k], so a diagonal tile needs
+// ONE register per step.  Which four time steps share an instruction only fixes the (deterministic) order of the sum, so lane
+// group q = l >> 4 streams its own contiguous quarter of the chunk.  Chunk sums are combined in a fixed order by the second kernel.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int PG_CHUNK = 2048;  // time steps per wave: 4 lane groups x 512
+
+__global__ __launch_bounds__(64) void planar_gram_kernel(const double *__restrict__ x, int C, int CT, int T, int Ts, int t_start,
+                                                          double *__restrict__ partial)
+{
+    const int l = threadIdx.x, lc = l & 15, q = l >> 4;
+    const int chunk = blockIdx.x, pair = blockIdx.y, b = blockIdx.z;
+    // pair -> (ti <= tj), row-major over the upper triangle
+    int ti = 0, rem = pair;
+    while (rem >= CT - ti) {
+        rem -= CT - ti;
+        ++ti;
+    }
+    const int tj = ti + rem;
+    const int ca = 16 * ti + lc, cb = 16 * tj + lc;
+    const double *xa = x + ((size_t)b * C + (ca < C ? ca : 0)) * Ts;
+    const double *xb = x + ((size_t)b * C + (cb < C ? cb : 0)) * Ts;
+    const bool va = ca < C, vb = cb < C;
+    const int t0 = t_start + chunk * PG_CHUNK + q * (PG_CHUNK / 4);
+    double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+    for (int s = 0; s < PG_CHUNK / 4; ++s) {
+        const int t = t0 + s;
+        const bool in = t < T;
+        const double a = (in && va) ? xa[t] : 0.0;
+        const double bb = ti == tj ? a : ((in && vb) ? xb[t] : 0.0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, acc, 0, 0, 0);
+    }
+    // accumulator layout of the fp64 16 x 16 tile: lane l, register r -> R[i = (l >> 4) + 4 r][j = l & 15]
+    double *out = partial + (((size_t)b * gridDim.x + chunk) * gridDim.y + pair) * 256;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[(q + 4 * r) * 16 + lc] = acc[r];
+}
+
+__global__ __launch_bounds__(256) void planar_gram_reduce_kernel(const double *__restrict__ partial, int nchunks, int C, int CT, double inv_n,
+                                                                  double *__restrict__ gram)
+{
+    const int b = blockIdx.y;
+    const int np = CT * (CT + 1) / 2;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < C * C; e += gridDim.x * 256) {
+        const int i = e / C, j = e % C;
+        const int lo = i < j ? i : j, hi = i < j ? j : i;  // symmetric: read the upper triangle
+        const int ti = lo >> 4, tj = hi >> 4;
+        const int pair = ti * CT - ti * (ti - 1) / 2 + (tj - ti);
+        double acc = 0.0;
+        for (int c = 0; c < nchunks; ++c) acc += partial[(((size_t)b * nchunks + c) * np + pair) * 256 + (lo & 15) * 16 + (hi & 15)];
+        gram[((size_t)b * C + i) * C + j] = acc * inv_n;
+    }
+}
+
+size_t planar_gram_partial_bytes(int B, int T, int C, int t_start)
+{
+    const int CT = (C + 15) / 16;
+    const int nchunks = (T - t_start + PG_CHUNK - 1) / PG_CHUNK;
+    return (size_t)B * nchunks * (CT * (CT + 1) / 2) * 256 * sizeof(double);
+}
+
+hipError_t launch_planar_gram(const double *x, int B, int C, int T, int Ts, int t_start, int normalise, double *gram, double *partial,
+                              hipStream_t stream)
+{
+    const int CT = (C + 15) / 16;
+    const int nchunks = (T - t_start + PG_CHUNK - 1) / PG_CHUNK;
+    const int np = CT * (CT + 1) / 2;
+    hipLaunchKernelGGL(planar_gram_kernel, dim3(nchunks, np, B), dim3(64), 0, stream, x, C, CT, T, Ts, t_start, partial);
+    hipLaunchKernelGGL(planar_gram_reduce_kernel, dim3((C * C + 255) / 256, B), dim3(256), 0, stream, partial, nchunks, C, CT,
+                       normalise ? 1.0 / (double)(T - t_start) : 1.0, gram);
+    return hipGetLastError();
+}
+
 }  // namespace micloc

@@ -92,6 +92,11 @@ hipError_t launch_lif_cov(const NeuronTab &nt, const int8_t *spikes, int B, int 
 hipError_t launch_cov_power(const double *partial, int B, int T, int CT, int C, int Tn, const double *Wp, int Gp, int G,
                             double *cov_out, double *power, int32_t *argmax, hipStream_t stream);
 
+// Gram matrix of a planar signal [B][C][Ts] over frames t >= t_start (complex covariance of Beamformer.design_from_template)
+size_t planar_gram_partial_bytes(int B, int T, int C, int t_start);
+hipError_t launch_planar_gram(const double *x, int B, int C, int T, int Ts, int t_start, int normalise, double *gram, double *partial,
+                              hipStream_t stream);
+
 // ---- Xylo integer LIF (parity unpinned) ------------------------------------------------------------------
 size_t xylo_ws_bytes(int Cin, int N);
 hipError_t launch_xylo(const uint8_t *spikes_in, int B, int T, int Cin, const int8_t *W_in_host, int N, int w_rec,

@@ -507,6 +507,22 @@ def design_vectors(cov, bipolar, bf_mat, g0, rel_prec=1e-8):
     return bf_mat
 
 
+def planar_gram(planar, T, t_start=0, normalise=True):
+    """micloc_planar_gram_f64: planar [B, C, Ts] device tensor -> gram [B, C, C] = sum over frames t_start <= t < T of
+    x[:, t] x[:, t]^T (/ (T - t_start)).  The complex covariance of Beamformer.design_from_template is a fold of it."""
+    torch = _torch()
+    B, C, Ts = planar.shape
+    lib = _lib.load()
+    nbytes = lib.micloc_planar_gram_workspace_bytes(B, int(T), C, int(t_start))
+    if nbytes == 0:
+        raise ValueError("planar_gram: bad shape or t_start")
+    ws = torch.empty(int(nbytes), dtype=torch.uint8, device=planar.device)
+    gram = torch.empty((B, C, C), dtype=torch.float64, device=planar.device)
+    _lib.check(lib.micloc_planar_gram_f64(_ptr(planar), B, C, int(T), Ts, int(t_start), int(bool(normalise)), _ptr(gram), _ptr(ws), nbytes,
+                                          _stream(planar.device)), "planar_gram")
+    return gram
+
+
 def peak_location(counts, G, win_size, out=None):
     """micloc_peak_location_i32: counts int32 [B, bands * G] -> index int32 [B] (find_peak_location of the per-DoA counts)."""
     torch = _torch()

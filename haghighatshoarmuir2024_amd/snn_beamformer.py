@@ -233,14 +233,9 @@ class SNNBeamformer:
                 cov_d = self.membrane_covariance_batch(sig, time_vec=time_temp, t_start=sig.shape[1] // 4)
                 runtime.design_vectors(cov_d, self.spk_encoder.bipolar, bf_dev, start, rel_prec=0.00000001)
                 continue
-            if sig.shape[2] * 2 <= 64:
-                # membrane covariance over the last 3/4 on the device (MFMA Gram kernel)
-                cov = self.membrane_covariance_batch(sig, time_vec=time_temp, t_start=sig.shape[1] // 4).cpu().numpy()
-            else:
-                vmem = self.membrane_batch(sig, time_vec=time_temp)
-                stable = vmem.shape[1] // 4
-                v = vmem[:, stable:, :]
-                cov = (v.transpose(1, 2) @ v / v.shape[1]).cpu().numpy()  # [n, 2M, 2M]
+            # membrane covariance over the last 3/4 on the device (MFMA Gram kernels: lif_cov_kernel up to 64 channels,
+            # lif_cov_wide_kernel up to 128 -- the plan's limit)
+            cov = self.membrane_covariance_batch(sig, time_vec=time_temp, t_start=sig.shape[1] // 4).cpu().numpy()
             for C in cov:
                 if not self.spk_encoder.bipolar:
                     bf_mat.append(self._find_dc_removed_sing_vec(C, rel_prec=0.00000001))

@@ -174,6 +174,14 @@ int micloc_lif_beamform_f32(const micloc_plan *plan, const int8_t *spikes, int B
  * Supports C <= 128 channels (lif_cov_kernel up to 64, lif_cov_wide_kernel beyond). */
 int micloc_lif_covariance_f64(const micloc_plan *plan, const int8_t *spikes, int B, int T, int t_start, double *cov,
                               double *power, int32_t *argmax, void *ws, size_t ws_bytes, void *stream);
+/* Gram matrix of a planar signal: gram[b] = sum_{t >= t_start} x[b][:, t] x[b][:, t]^T (divided by T - t_start when `normalise`),
+ * x planar [B][C][Ts] (C <= 128), gram [B][C][C].  Beamformer.design_from_template (beamformer.py:142-150) takes the complex
+ * covariance conj(h)^T h / T' of the STHT output over the stable part of each delayed template; with the planar rows
+ * [re_0..re_{M-1}, im_0..im_{M-1}] it is the fold (R_rr + R_ii) + j (R_ri - R_ir) of this real 2M x 2M matrix.  fp64 MFMA,
+ * deterministic (fixed-order chunk sums).  ws from micloc_planar_gram_workspace_bytes. */
+size_t micloc_planar_gram_workspace_bytes(int B, int T, int C, int t_start);
+int micloc_planar_gram_f64(const double *planar, int B, int C, int T, int Ts, int t_start, int normalise, double *gram, void *ws,
+                           size_t ws_bytes, void *stream);
 /* whole chain (STHT, band-pass, RZCC, LIF) with the covariance-form tail */
 int micloc_snn_pipeline_cov_f64(const micloc_plan *plan, const double *x, int B, int T, int t_start, int8_t *spikes,
                                 double *cov, double *power, int32_t *argmax, void *ws, size_t ws_bytes, void *stream);

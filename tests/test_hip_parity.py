@@ -547,3 +547,23 @@ def test_fused_pipeline_random_configurations_vs_oracle(torch, seed):
         out2 = p.snn_pipeline(p.to_device(x), want_spikes=True, want_power=True)
         np.testing.assert_array_equal(out2["spikes"].cpu().numpy(), out["spikes"].cpu().numpy(), err_msg=f"chunk={chunk} T={T} w={w}")
         np.testing.assert_array_equal(out2["power"].cpu().numpy(), out["power"].cpu().numpy())
+
+
+def test_planar_gram_against_numpy(torch):
+    """micloc_planar_gram_f64 (complex covariance of Beamformer.design_from_template, beamformer.py:142-150): the real Gram
+    matrix of a planar signal over frames >= t_start, every tile-pair shape incl. channel padding and ragged chunk ends;
+    fp64 tolerance 1e-14 relative to the largest entry (NumPy sums in another order)."""
+    from haghighatshoarmuir2024_amd import runtime
+
+    rng = np.random.RandomState(0)
+    for B, C, T, t0 in ((3, 14, 4799, 480), (2, 80, 5000, 17), (1, 128, 9599, 2400), (2, 5, 100, 0), (1, 16, 2048, 0), (1, 17, 2049, 1)):
+        Ts = (T + 7) // 8 * 8
+        x = rng.randn(B, C, Ts)
+        xd = torch.from_numpy(x).cuda()
+        for norm in (True, False):
+            g = runtime.planar_gram(xd, T, t_start=t0, normalise=norm).cpu().numpy()
+            ref = np.einsum("bct,bdt->bcd", x[:, :, t0:T], x[:, :, t0:T]) / ((T - t0) if norm else 1.0)
+            np.testing.assert_allclose(g, ref, rtol=0, atol=1e-14 * np.abs(ref).max() * (T - t0) ** 0.5)
+            np.testing.assert_array_equal(g, np.transpose(g, (0, 2, 1)))  # exactly symmetric: one tile serves both halves
+    with pytest.raises(ValueError):
+        runtime.planar_gram(xd, 2049, t_start=2049)

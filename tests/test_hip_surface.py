@@ -143,6 +143,35 @@ def test_beamformer_class_surface(cfg2):
     np.testing.assert_allclose(W * (phase / np.abs(phase)), z["bf_mat"][:, :5], rtol=0, atol=1e-8)
 
 
+def test_beamformer_design_interference_removal():
+    """Beamformer.design_from_template(interference_removal=True) (reference beamformer.py:152-190: generalised eigenvectors of
+    (cov_g, sum_g' cov_g' + offset - cov_g)) against the reference's own matrix: STHT + complex covariance on the device
+    (micloc_planar_gram_f64), scipy.linalg.eigh on the host like the reference.  A generalised eigenvector is defined up to a unit
+    phase: columns are compared after aligning it, and through the beam pattern |W^H W|."""
+    from micloc.array_geometry import CenterCircularArray
+    from micloc.beamformer import Beamformer
+
+    z = golden("beamformer_c128.npz")
+    fs = 48_000
+    bf = Beamformer(CenterCircularArray(4.5e-2, 7), 10e-3, [1000.0, 2000.0], fs=fs)
+    t = np.arange(0, 1.0, step=1 / fs)
+    period = t[-1]
+    s = np.sin(2 * np.pi * np.cumsum(1000 + 1000 * (t % period) / period) / fs)
+    doas = z["doa_list"][::4]
+    W, covs = bf.design_from_template((t[:9600], s[:9600]), doas, interference_removal=True)
+    ref = z["bf_mat_ir"]
+    assert W.shape == ref.shape == (7, len(doas)) and W.dtype == np.complex128
+    np.testing.assert_allclose(np.linalg.norm(W, axis=0), 1.0, rtol=0, atol=1e-12)
+    phase = np.sum(np.conj(W) * ref, axis=0)
+    assert np.all(np.abs(phase) > 1 - 1e-7)  # the same one-dimensional subspace
+    np.testing.assert_allclose(W * (phase / np.abs(phase)), ref, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(np.abs(W.conj().T @ W), np.abs(ref.conj().T @ ref), rtol=0, atol=1e-6)
+    # covariances are Hermitian PSD and equal to the NumPy form of the same STHT output
+    for c in covs:
+        np.testing.assert_allclose(c, c.conj().T, rtol=0, atol=1e-15)
+        assert np.linalg.eigvalsh(c).min() > -1e-12
+
+
 def test_device_synthesis_bit_exact(cfg2):
     """synthesize_batch (device) == synthesize_array_signal (host NumPy, itself == the reference's golden output)."""
     from haghighatshoarmuir2024_amd.snn_beamformer import synthesize_array_signal
