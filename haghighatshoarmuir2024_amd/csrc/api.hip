@@ -517,6 +517,106 @@ int micloc_stream_overflow(const void *state, int *count, void *stream)
     return MICLOC_OK;
 }
 
+// ---- streaming localisation: LIF + beamforming + power as the spikes become final ---------------------------------------------
+// loc_state: [256 B: 64 control ints][acc: B x 2 x G doubles]
+size_t micloc_stream_localize_state_bytes(const micloc_plan *p, int B)
+{
+    if (!p || bad_batch(B) || p->G_out < 1) return 0;
+    return 256 + align256((size_t)B * 2 * p->G_out * sizeof(double));
+}
+
+int micloc_stream_chunk_frames(const micloc_plan *p)
+{
+    if (!p || !p->d_ntab || !p->d_W) return MICLOC_ERR_NOT_SET;
+    return lif_beamform_chunk_frames(p->W, p->ntab);
+}
+
+size_t micloc_stream_localize_workspace_bytes(const micloc_plan *p, int B, int window_frames)
+{
+    if (!p || bad_batch(B) || window_frames < 1 || p->W.GT < 1) return 0;
+    return align256(beamform_partial_bytes(B, window_frames, 16 * p->W.GT));
+}
+
+int micloc_stream_encode_window_f64(const micloc_plan *p, const double *h, int B, int T_tile, int row_stride, long long t_base,
+                                    int first_tile, int final_tile, int8_t *window, int window_frames, long long window_base,
+                                    void *state, size_t state_bytes, void *stream)
+{
+    if (!p || !h || !window || bad_batch(B) || T_tile < 1 || window_frames < 1 || t_base < 0 || window_base < 0 || row_stride < T_tile)
+        return MICLOC_ERR_INVALID;
+    DeviceGuard guard(p->device);
+    if (t_base % 16 != 0 || (!final_tile && T_tile % 16 != 0) || t_base + T_tile > window_base + window_frames || window_base > t_base ||
+        (first_tile && t_base != 0) || t_base + T_tile > 0x7fffffffll)
+        return MICLOC_ERR_SHAPE;
+    if (bad_ws(state, state_bytes, rzcc_stream_state_bytes(B * p->C))) return MICLOC_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    if (first_tile) HIP_TRY(launch_zero_fill(window, (size_t)B * window_frames * p->C, st));
+    HIP_TRY(launch_stream_encode(p->iir, h, B * p->C, p->C, T_tile, row_stride, p->robust_width, p->bipolar, window, window_frames, t_base,
+                                 first_tile, final_tile, state, st, (int)window_base));
+    return MICLOC_OK;
+}
+
+int micloc_stream_localize_f64(const micloc_plan *p, const void *enc_state, void *loc_state, size_t loc_state_bytes, const int8_t *window,
+                               int B, int window_frames, long long window_base, long long t_end, int first_tile, int final_tile,
+                               double *power, int32_t *argmax, void *ws, size_t ws_bytes, void *stream)
+{
+    if (!p || !enc_state || !loc_state || !window || bad_batch(B) || window_frames < 1 || window_base < 0 || t_end < 1) return MICLOC_ERR_INVALID;
+    DeviceGuard guard(p->device);
+    if (!p->d_ntab || !p->d_W) return MICLOC_ERR_NOT_SET;
+    if (p->W_is_complex) return MICLOC_ERR_SHAPE;
+    const int CH = lif_beamform_chunk_frames(p->W, p->ntab);
+    if (window_base % CH != 0 || window_frames % CH != 0 || t_end > window_base + window_frames || t_end <= window_base ||
+        t_end > 0x7fffffffll)
+        return MICLOC_ERR_SHAPE;
+    const int G = p->G_out, Gp = 16 * p->W.GT;
+    if (bad_ws(loc_state, loc_state_bytes, micloc_stream_localize_state_bytes(p, B))) return MICLOC_ERR_WORKSPACE;
+    if (bad_ws(ws, ws_bytes, beamform_partial_bytes(B, window_frames, Gp))) return MICLOC_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    int *ctl = reinterpret_cast<int *>(loc_state);
+    double *acc = reinterpret_cast<double *>(reinterpret_cast<unsigned char *>(loc_state) + 256);
+    if (first_tile) HIP_TRY(launch_zero_fill(loc_state, 256 + (size_t)B * 2 * G * sizeof(double), st));
+    const int nwin = window_frames / CH;
+    HIP_TRY(launch_stream_horizon(enc_state, B * p->C, p->bipolar, (int)t_end, final_tile ? 1 : 0, CH, (int)(window_base / CH), nwin, ctl, st));
+    // the window as a recording of (t_end - window_base) frames: the chunks in ctl's range, everything else left alone
+    BeamformW W = p->W;
+    W.chunk_range = ctl + 4;
+    double *partial = reinterpret_cast<double *>(ws);
+    int nch = 0;
+    HIP_TRY(launch_lif_beamform(W, p->ntab, window, B, (int)(t_end - window_base), nullptr, partial, st, &nch));
+    HIP_TRY(launch_stream_accumulate(partial, B, nch, Gp, G, ctl + 4, ctl, acc, ctl + 8, power, argmax, st));
+    HIP_TRY(launch_stream_commit(ctl, STREAM_BLOCK_CHUNKS, st));
+    return MICLOC_OK;
+}
+
+int micloc_stream_window_shift(const micloc_plan *p, void *loc_state, const int8_t *src, int8_t *dst, int B, int window_frames,
+                               long long base_old, long long base_new, void *stream)
+{
+    if (!p || !loc_state || !src || !dst || src == dst || bad_batch(B) || window_frames < 1 || base_new < base_old || base_old < 0)
+        return MICLOC_ERR_INVALID;
+    DeviceGuard guard(p->device);
+    if (!p->d_ntab || !p->d_W) return MICLOC_ERR_NOT_SET;
+    const int CH = lif_beamform_chunk_frames(p->W, p->ntab);
+    if (base_new % CH != 0 || base_old % CH != 0 || base_new - base_old > window_frames) return MICLOC_ERR_SHAPE;
+    const size_t row = (size_t)window_frames * p->C;
+    HIP_TRY(launch_window_shift(src, dst, B, row, (size_t)(base_new - base_old) * p->C, reinterpret_cast<int *>(loc_state), (int)(base_new / CH),
+                                (hipStream_t)stream));
+    return MICLOC_OK;
+}
+
+/* status[0] = chunks beamformed, [1] = frames beamformed, [2] = window-lag failures, [3] = chunks in the open reduction block
+ * (synchronises the stream) */
+int micloc_stream_localize_status(const void *loc_state, int *status4, void *stream)
+{
+    if (!loc_state || !status4) return MICLOC_ERR_INVALID;
+    int ctl[16];
+    HIP_TRY(hipMemcpyAsync(ctl, loc_state, sizeof(ctl), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    status4[0] = ctl[0];
+    status4[1] = ctl[8];
+    status4[2] = ctl[13];
+    status4[3] = ctl[1];
+    return MICLOC_OK;
+}
+
 // ---- stand-alone operators -------------------------------------------------------------------------------
 size_t micloc_rzcc_workspace_bytes(int B, int T, int C) { return micloc_rzcc_workspace_bytes_ex(B, T, C, 1, 0); }
 

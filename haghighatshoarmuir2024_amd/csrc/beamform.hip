@@ -91,9 +91,10 @@ __global__ __launch_bounds__(BF_THREADS) void beamform_kernel(const int8_t *__re
                                                                const double *__restrict__ ntab_g, int NK,
                                                                const double *__restrict__ Wp, int GT, int C, int G,
                                                                int T, int Ts, double *__restrict__ y, int y_complex,
-                                                               double *__restrict__ partial)
+                                                               double *__restrict__ partial, const int *__restrict__ chunk_range)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (chunk_range && ((int)blockIdx.x < chunk_range[0] || (int)blockIdx.x >= chunk_range[1])) return;  // (workgroup-uniform)
     constexpr int Cs = 16 * CT;  // padded spike row (bytes)
     constexpr int KS = 4 * CT;   // beamforming k-steps
     const int Gp = 16 * GT;
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(BF_THREADS) void beamform_kernel(const int8_t *__re
     }
     if (SRC_SPIKES) {
         for (int e = tid; e < ntab_len; e += BF_THREADS) ntab[e] = ntab_g[e];
-        const int8_t *sb = spikes + (size_t)b * T * C;
+        const int8_t *sb = spikes + (size_t)b * (chunk_range ? chunk_range[3] : T) * C;  // ([3]: frames per trial of a raster window)
         const int tau0 = cs + 16 - 4 * NK;
         // all loads of a batch are issued (clamped addresses, hence unconditional) before the first LDS write, so
         // the workgroup pays the memory latency once per batch instead of once per element
@@ -615,7 +616,7 @@ constexpr int WS_KV_WAVES = 6;
 template <int NGW, int NT, bool WANT_Y, int KM, int KV>
 __global__ __launch_bounds__(BF_THREADS, WANT_Y ? 2 : (KV ? WS_KV_WAVES : (NT == 2 ? 6 : 4))) void beamform_ws_kernel(
     const int8_t *__restrict__ spikes, const double *__restrict__ ntab_g, int NK, const double *__restrict__ Wp, int GT, int C,
-    int T, double *__restrict__ partial, int G, double *__restrict__ y)
+    int T, double *__restrict__ partial, int G, double *__restrict__ y, const int *__restrict__ chunk_range)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int Gp = 16 * GT;
@@ -626,6 +627,7 @@ __global__ __launch_bounds__(BF_THREADS, WANT_Y ? 2 : (KV ? WS_KV_WAVES : (NT ==
     const int q = l >> 4;
     int chunk = blockIdx.x, b = blockIdx.y;
     xcd_chunk_order(chunk, b);
+    if (chunk_range && (chunk < chunk_range[0] || chunk >= chunk_range[1])) return;  // (workgroup-uniform)
     const int nchunks = gridDim.x;
     constexpr int CH = BF_WAVES * NT * 16;  // frames per workgroup
     constexpr int TILES = CH / 16;
@@ -643,7 +645,7 @@ __global__ __launch_bounds__(BF_THREADS, WANT_Y ? 2 : (KV ? WS_KV_WAVES : (NT ==
 
     for (int e = tid; e < ntab_len; e += BF_THREADS) ntab[e] = ntab_g[e];
     {
-        const int8_t *sb = spikes + (size_t)b * T * C;
+        const int8_t *sb = spikes + (size_t)b * (chunk_range ? chunk_range[3] : T) * C;  // ([3]: frames per trial of a raster window)
         const int tau0 = cs + 16 - 4 * NK;
         const int c = tid & 15;
         constexpr int RP = BF_THREADS / 16;  // rows per pass
@@ -813,7 +815,7 @@ static hipError_t launch_ws_n(const BeamformW &W, const NeuronTab &nt, const int
                                        160 * 1024);
     if (e != hipSuccess) return e;
     dim3 grid((T + BF_WAVES * NT * 16 - 1) / (BF_WAVES * NT * 16), B), block(BF_THREADS);
-    hipLaunchKernelGGL(k, grid, block, lds, stream, spikes, nt.tab, nt.NK, W.Wp, W.GT, W.C, T, partial, W.G, y);
+    hipLaunchKernelGGL(k, grid, block, lds, stream, spikes, nt.tab, nt.NK, W.Wp, W.GT, W.C, T, partial, W.G, y, W.chunk_range);
     return hipGetLastError();
 }
 
@@ -862,9 +864,10 @@ __global__ __launch_bounds__(BF_THREADS, 2) void beamform_slab_kernel(const int8
                                                                       const double *__restrict__ ntab_g, int NK,
                                                                       const double *__restrict__ Wp, int GT, int C, int G,
                                                                       int T, int Ts, double *__restrict__ y, int y_complex,
-                                                                      double *__restrict__ partial)
+                                                                      double *__restrict__ partial, const int *__restrict__ chunk_range)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (chunk_range && ((int)blockIdx.x < chunk_range[0] || (int)blockIdx.x >= chunk_range[1])) return;  // (workgroup-uniform)
     constexpr int Kp = 16 * CT;
     constexpr int Cs = 16 * CT;
     constexpr int KS = 4 * CT;
@@ -911,7 +914,7 @@ __global__ __launch_bounds__(BF_THREADS, 2) void beamform_slab_kernel(const int8
     issue_slab(0);
     if (SRC_SPIKES) {
         for (int e = tid; e < ntab_len; e += BF_THREADS) ntab[e] = ntab_g[e];
-        const int8_t *sb = spikes + (size_t)b * T * C;
+        const int8_t *sb = spikes + (size_t)b * (chunk_range ? chunk_range[3] : T) * C;  // ([3]: frames per trial of a raster window)
         const int tau0 = cs + 16 - 4 * NK;
         for (int e0 = tid; e0 < R * Cs; e0 += BF_THREADS * 8) {
             int8_t v[8];
@@ -1076,7 +1079,7 @@ static hipError_t launch_slab(const BeamformW &W, const NeuronTab *nt, const int
                                 160 * 1024);                                                                        \
         if (e != hipSuccess) return e;                                                                              \
         hipLaunchKernelGGL(k, grid, block, lds, stream, spikes, pre, tab, NK, W.Wp, W.GT, W.C, W.G, T, Ts, y,       \
-                           y_complex, partial);                                                                     \
+                           y_complex, partial, W.chunk_range);                                                      \
     } while (0)
     if (y)
         SL_LAUNCH(true);
@@ -1113,7 +1116,7 @@ static hipError_t launch_bf(const BeamformW &W, const NeuronTab *nt, const int8_
                                 160 * 1024);                                                                         \
         if (e != hipSuccess) return e;                                                                               \
         hipLaunchKernelGGL(k, grid, block, (LDSB), stream, spikes, pre, tab, NK, W.Wp, W.GT, W.C, W.G, T, Ts, y,      \
-                           y_complex, partial);                                                                      \
+                           y_complex, partial, W.chunk_range);                                                       \
     } while (0)
     if (w_lds) {
         if (y)
@@ -1152,6 +1155,12 @@ hipError_t launch_lif_beamform(const BeamformW &W, const NeuronTab &nt, const in
     return dispatch_ct<true>(W, &nt, spikes, nullptr, B, T, 0, y, 0, partial, stream);
 }
 
+int lif_beamform_chunk_frames(const BeamformW &W, const NeuronTab &nt)
+{
+    if (ws_eligible(W, nt, false)) return BF_WAVES * WS_NT * 16;
+    return W.CT > 4 ? SL_CHUNK : BF_CHUNK;
+}
+
 hipError_t launch_planar_beamform(const BeamformW &W, const double *pre, int B, int T, int Ts, double *y,
                                   int y_complex, double *partial, hipStream_t stream)
 {
@@ -1159,9 +1168,14 @@ hipError_t launch_planar_beamform(const BeamformW &W, const double *pre, int B, 
 }
 
 // ---- chunk reduction, mean over time, arg-max (first maximum, like np.argmax) --------------------------------
-// S = 1: one thread per DoA sums the chunks in ascending order.  Long recordings (speech: 1298 chunks, 125 trials) leave
-// that form latency bound on a few workgroups, so with S = 4 the chunk range is cut into 4 contiguous slices summed side
-// by side and combined as ((s0 + s1) + (s2 + s3)): still a fixed order, independent of the launch.
+// The order of the time reduction is fixed and STREAMABLE: chunk sums are added in ascending order inside blocks of
+// PA_BLOCK consecutive chunks, block sums in ascending order onto the total.  A recording that arrives tile by tile can
+// apply exactly this order with O(1) state (stream_accumulate_kernel below) and ends with the bits of the one-shot call.
+// Up to PA_BLOCK chunks (config 2: 19) that is the plain ascending sum.  Long recordings (speech: 1298 chunks, 125 trials)
+// would leave one thread per DoA latency bound, so with S = 4 four blocks are summed side by side and then added to the
+// total in their order -- the same additions, S of them in flight.
+constexpr int PA_BLOCK = STREAM_BLOCK_CHUNKS;
+
 template <int S>
 __global__ __launch_bounds__(256 * S) void power_argmax_kernel(const double *__restrict__ partial, int T, int nchunks,
                                                                 int Gp, int G, int complex_pairs, int Ghp,
@@ -1174,26 +1188,37 @@ __global__ __launch_bounds__(256 * S) void power_argmax_kernel(const double *__r
     const int col = threadIdx.x & 255;
     const int slice = threadIdx.x >> 8;
     const double *pb = partial + (size_t)b * nchunks * Gp;
-    const int c_lo = (int)((long long)slice * nchunks / S), c_hi = (int)((long long)(slice + 1) * nchunks / S);
+    const int nblocks = (nchunks + PA_BLOCK - 1) / PA_BLOCK;
     double best = -1.0;
     int bi = 0x7fffffff;
     for (int g0 = 0; g0 < G; g0 += 256) {
         const int g = g0 + col;
-        double s = 0.0;
-        if (g < G) {
-            for (int ch = c_lo; ch < c_hi; ++ch) {
-                s += pb[(size_t)ch * Gp + g];
-                if (complex_pairs) s += pb[(size_t)ch * Gp + Ghp + g];
+        double total = 0.0;
+        for (int blk0 = 0; blk0 < nblocks; blk0 += S) {
+            const int blk = blk0 + slice;
+            double s = 0.0;
+            if (g < G && blk < nblocks) {
+                const int c_hi = (blk + 1) * PA_BLOCK < nchunks ? (blk + 1) * PA_BLOCK : nchunks;
+                for (int ch = blk * PA_BLOCK; ch < c_hi; ++ch) {
+                    s += pb[(size_t)ch * Gp + g];
+                    if (complex_pairs) s += pb[(size_t)ch * Gp + Ghp + g];
+                }
+            }
+            if (S > 1) {
+                ps[slice][col] = s;
+                __syncthreads();
+                if (slice == 0) {
+#pragma unroll
+                    for (int u = 0; u < S; ++u)
+                        if (blk0 + u < nblocks) total += ps[u][col];
+                }
+                __syncthreads();
+            } else {
+                total += s;
             }
         }
-        if (S > 1) {
-            ps[slice][col] = s;
-            __syncthreads();
-            if (slice == 0) s = (ps[0][col] + ps[S > 1 ? 1 : 0][col]) + (ps[S > 2 ? 2 : 0][col] + ps[S > 3 ? 3 : 0][col]);
-            __syncthreads();
-        }
         if (slice == 0 && g < G) {
-            const double p = s / (double)T;
+            const double p = total / (double)T;
             if (power) power[(size_t)b * G + g] = p;
             if (p > best) {
                 best = p;
@@ -1218,6 +1243,74 @@ __global__ __launch_bounds__(256 * S) void power_argmax_kernel(const double *__r
         __syncthreads();
     }
     if (threadIdx.x == 0 && argmax) argmax[b] = si[0] == 0x7fffffff ? 0 : si[0];
+}
+
+// ---- streaming: the same reduction with O(1) state -----------------------------------------------------------------
+// acc [B][2][G]: running total and the sum of the open block; ctl: {chunks done, chunks of the open block}.  The chunk
+// range [lo, hi) of this call (window-relative, decided on the device by the caller's horizon kernel) is read from
+// `range`; rows lo .. hi - 1 of `partial` [B][nwin][Gp] are added in order.  power / argmax (may be NULL) = the mean over
+// the `frames` frames beamformed so far (frames_ptr[0]; the last chunk of a recording may be ragged).
+__global__ __launch_bounds__(256) void stream_accumulate_kernel(const double *__restrict__ partial, int nwin, int Gp, int G,
+                                                                 const int *__restrict__ range, const int *__restrict__ ctl,
+                                                                 double *__restrict__ acc, const int *__restrict__ frames_ptr,
+                                                                 double *__restrict__ power, int32_t *__restrict__ argmax)
+{
+    __shared__ double sv[256];
+    __shared__ int si[256];
+    const int b = blockIdx.x;
+    const int col = threadIdx.x;
+    const int lo = range[0], hi = range[1];
+    const int open0 = ctl[1];  // chunks already in the open block
+    const double *pb = partial + (size_t)b * nwin * Gp;
+    double *tot = acc + (size_t)b * 2 * G, *blk = tot + G;
+    const double frames = (double)frames_ptr[0];
+    double best = -1.0;
+    int bi = 0x7fffffff;
+    for (int g = col; g < G; g += 256) {
+        double total = tot[g], s = blk[g];
+        int open = open0;
+        for (int ch = lo; ch < hi; ++ch) {
+            s += pb[(size_t)ch * Gp + g];
+            if (++open == PA_BLOCK) {
+                total += s;
+                s = 0.0;
+                open = 0;
+            }
+        }
+        tot[g] = total;
+        blk[g] = s;
+        // the value the one-shot reduction would hold after these chunks: the open block is added last (if it holds any)
+        const double now = open > 0 ? total + s : total;
+        const double p = frames > 0.0 ? now / frames : 0.0;
+        if (power) power[(size_t)b * G + g] = p;
+        if (p > best) {
+            best = p;
+            bi = g;
+        }
+    }
+    sv[col] = best;
+    si[col] = bi;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (col < s) {
+            const double ov = sv[col + s];
+            const int oi = si[col + s];
+            if (ov > sv[col] || (ov == sv[col] && oi < si[col])) {
+                sv[col] = ov;
+                si[col] = oi;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && argmax) argmax[b] = si[0] == 0x7fffffff ? 0 : si[0];
+}
+
+hipError_t launch_stream_accumulate(const double *partial, int B, int nwin, int Gp, int G, const int *range, const int *ctl,
+                                    double *acc, const int *frames_ptr, double *power, int32_t *argmax, hipStream_t stream)
+{
+    hipLaunchKernelGGL(stream_accumulate_kernel, dim3(B), dim3(256), 0, stream, partial, nwin, Gp, G, range, ctl, acc, frames_ptr, power,
+                       argmax);
+    return hipGetLastError();
 }
 
 hipError_t launch_power_argmax(const double *partial, int B, int T, int nchunks, int Gp, int G, int complex_pairs,

@@ -45,7 +45,16 @@ hipError_t launch_bandpass_rzcc(const IirCoef &coef, const double *h, int nlanes
 size_t rzcc_stream_state_bytes(int nlanes);
 hipError_t launch_stream_encode(const IirCoef &coef, const double *h, int nlanes, int C, int T, int Ts, int robust_width,
                                 int bipolar, int8_t *spikes, int Ttot, long long t_base, int first_tile, int final_tile,
-                                void *state, hipStream_t stream);
+                                void *state, hipStream_t stream, int pos_lo = 0);
+// streaming localisation (rzcc.hip "which frames of the spike raster are final"); ctl: 64 device ints
+hipError_t launch_stream_horizon(const void *enc_state, int nlanes, int bipolar, int t_end, int final_, int chunk_frames, int base_chunk,
+                                 int nwin, int *ctl, hipStream_t stream);
+hipError_t launch_stream_commit(int *ctl, int block_chunks, hipStream_t stream);
+hipError_t launch_window_shift(const int8_t *src, int8_t *dst, int B, size_t row_bytes, size_t shift_bytes, int *ctl, int new_base_chunk,
+                               hipStream_t stream);
+hipError_t launch_stream_accumulate(const double *partial, int B, int nwin, int Gp, int G, const int *range, const int *ctl,
+                                    double *acc, const int *frames_ptr, double *power, int32_t *argmax, hipStream_t stream);
+constexpr int STREAM_BLOCK_CHUNKS = 32;  // == PA_BLOCK of the one-shot time reduction (beamform.hip)
 hipError_t launch_zero_fill(void *ptr, size_t bytes, hipStream_t stream);
 // row-major [B][T][C] <-> planar [B][C][Ts]
 hipError_t launch_pack_planar(const double *src, double *dst, int B, int T, int C, int Ts, hipStream_t stream);
@@ -61,6 +70,10 @@ struct BeamformW {
     int CT, GT;
     int C, G;          // logical sizes (G counts real columns: 2 * G_complex for the complex variant)
     int complex_pairs; // 0: real bf_mat; 1: columns [0,G/2) are Re, [Gp/2 ...) see api
+    // device {lo, hi, -, trial stride in frames} or nullptr: only the chunks lo <= chunk < hi of every trial are computed (the
+    // others leave their row of `partial` untouched), trial b starts at spikes + b * stride * C -- the streaming path beamforms the chunks whose spikes have become final, the range is decided on
+    // the device and the launch stays sync-free
+    const int *chunk_range = nullptr;
 };
 
 struct NeuronTab {
@@ -80,6 +93,7 @@ hipError_t launch_power_argmax(const double *partial, int B, int T, int nchunks,
                                int Ghalf_pad, double *power, int32_t *argmax, hipStream_t stream);
 int beamform_nchunks(int T);
 int beamform_nchunks_ct(int T, int CT);  // chunking of the kernel family that serves CT channel tiles
+int lif_beamform_chunk_frames(const BeamformW &W, const NeuronTab &nt);  // frames per chunk of the kernel launch_lif_beamform picks (power only)
 
 // fp32-MFMA variant of LIF + beamforming + power (up to 64 channels, bf_mat must fit in LDS)
 hipError_t launch_lif_beamform_f32(const BeamformW &W, const NeuronTab &nt, const int8_t *spikes, int B, int T,

@@ -583,6 +583,7 @@ struct RzStream {
     int t_base;      // absolute time of this launch's first frame
     int Ttot;        // frames per trial of the spike raster (row stride of the scatter)
     int on;
+    int pos_lo;      // the raster starts at this absolute frame (a sliding window over the recording; 0: the whole recording)
 };
 
 // RING: candidate ring entries per stream (power of two).  A whole tile of appends (RZ_MT) is reserved before every tile, so
@@ -950,8 +951,16 @@ __global__ __launch_bounds__(448, SW == 64 ? 4 : 6) void bandpass_rzcc_fast_kern
         if (WRITER && widx - w2 < QN) {
             spq[WRITER ? mypol : 0][WRITER ? (widx & (QN - 1)) : 0][lane] = pos;
             ++widx;
-        } else {
+        } else if (!ss.on) {
             sp[(size_t)pos * C] = mark;
+        } else {
+            // streaming: the raster may be a window [pos_lo, pos_lo + Ttot) over the recording; a spike that lies outside it
+            // cannot be stored (the window slid past a cluster that was still open): counted, never written out of bounds
+            const int rel = pos - ss.pos_lo;
+            if (rel >= 0 && rel < ss.Ttot)
+                sp[(size_t)rel * C] = mark;
+            else
+                atomicAdd(ss.overflow, 1);
         }
     };
     auto close_cluster = [&](int s, int e, int lastpos, int first) {
@@ -1459,9 +1468,9 @@ static void launch_rz_stream(const IirCoef &coef, const double *h, int nlanes, i
 // start t_base; spikes = the full-length raster [B][Ttot][C] (zeroed by the caller before the first tile).
 hipError_t launch_stream_encode(const IirCoef &coef, const double *h, int nlanes, int C, int T, int Ts, int robust_width,
                                 int bipolar, int8_t *spikes, int Ttot, long long t_base, int first_tile, int final_tile,
-                                void *state, hipStream_t stream)
+                                void *state, hipStream_t stream, int pos_lo)
 {
-    if (t_base % RZ_MT != 0 || (!final_tile && T % RZ_MT != 0) || t_base + T > Ttot) return hipErrorInvalidValue;
+    if (t_base % RZ_MT != 0 || (!final_tile && T % RZ_MT != 0) || t_base + T > (long long)pos_lo + Ttot) return hipErrorInvalidValue;
     const size_t nblk = (nlanes + 63) / 64;
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
     unsigned char *base = reinterpret_cast<unsigned char *>(state);
@@ -1480,6 +1489,7 @@ hipError_t launch_stream_encode(const IirCoef &coef, const double *h, int nlanes
     ss.t_base = (int)t_base;
     ss.Ttot = Ttot;
     ss.on = 1;
+    ss.pos_lo = pos_lo;
     if (first_tile) {
         hipError_t e = zero_fill(base, 256, stream);
         if (e != hipSuccess) return e;
@@ -1502,6 +1512,123 @@ hipError_t launch_stream_encode(const IirCoef &coef, const double *h, int nlanes
             return hipErrorInvalidValue;
     }
 #undef RZ_CASE
+    return hipGetLastError();
+}
+
+// ---- streaming localisation: which frames of the spike raster are final? ------------------------------------------------
+// After a tile every stage of the encoder has drained, and a stream can still emit spikes only at positions
+//   >= the first candidate of its open cluster (per polarity), or, without one,
+//   >= (left + t_end - 1) >> 1, the earliest position of a candidate that has not completed yet (left: last strict change).
+// F = the minimum over all streams: every frame below F has its final spikes, so the chunks below F / chunk_frames can be
+// filtered and beamformed now (LIF and beamforming are causal).  One workgroup; writes, for the launches that follow,
+//   range  = {lo, hi}: window-relative chunk range to compute (lo = chunks done so far, hi = chunks final now),
+//   frames = frames covered once they are added (t_end when the recording ends: its last chunk may be ragged),
+// and flags a window that no longer holds the rows the next chunk needs (status[1]).
+// ctl: {chunks done (absolute), chunks in the open reduction block}; committed by rz_stream_commit_kernel afterwards.
+__global__ __launch_bounds__(256) void rz_stream_horizon_kernel(const int *__restrict__ si, const int *__restrict__ ringP, int nlanes,
+                                                                 int bipolar, int t_end, int final_, int chunk_frames, int base_chunk,
+                                                                 int nwin, const int *__restrict__ ctl, int *__restrict__ range,
+                                                                 int *__restrict__ frames, int *__restrict__ status)
+{
+    __shared__ int red[256];
+    int f = 0x7fffffff;
+    for (int g = threadIdx.x; g < nlanes; g += 256) {
+        const int blk = g >> 6, l = g & 63;
+        const int *sib = si + (size_t)blk * 12 * 64;
+        const int left = sib[0 * 64 + l];
+        const int bits = sib[2 * 64 + l];
+        const bool moved = (bits & 3) != 0;
+        const int nextpos = moved ? (left + t_end - 1) >> 1 : t_end;
+        for (int pol = 0; pol < (bipolar ? 2 : 1); ++pol) {
+            if (sib[(6 + 4 * pol) * 64 + l]) continue;  // lost to a ring overflow: reported by the encoder's counter
+            const int s_open = sib[(4 + 4 * pol) * 64 + l];
+            const int fp = s_open >= 0 ? ringP[((size_t)blk * RZ_RING + (s_open & (RZ_RING - 1))) * 64 + l] >> 1 : nextpos;
+            f = fp < f ? fp : f;
+        }
+    }
+    red[threadIdx.x] = f;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) {
+        if ((int)threadIdx.x < h) red[threadIdx.x] = red[threadIdx.x + h] < red[threadIdx.x] ? red[threadIdx.x + h] : red[threadIdx.x];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const int F = red[0] < t_end ? red[0] : t_end;
+        const int done = ctl[0];
+        int ready = final_ ? (t_end + chunk_frames - 1) / chunk_frames : F / chunk_frames;
+        ready = ready < done ? done : ready;
+        int lo = done - base_chunk, hi = ready - base_chunk;
+        // chunk `lo` reads the LIF history in front of it: one whole chunk of rows must still be in the window
+        if (hi > lo && ((base_chunk > 0 && lo < 1) || hi > nwin)) {
+            atomicAdd(&status[1], 1);
+            hi = lo;
+            ready = done;
+        }
+        range[0] = lo;
+        range[1] = hi;
+        range[2] = ready;  // absolute, for the commit
+        range[3] = nwin * chunk_frames;  // frames per trial of the window (trial stride of the beamforming kernels)
+        frames[0] = ready * chunk_frames >= t_end ? t_end : ready * chunk_frames;  // (the last chunk of a recording may be ragged)
+    }
+}
+
+__global__ void rz_stream_commit_kernel(int *__restrict__ ctl, const int *__restrict__ range, int block_chunks)
+{
+    const int n = range[1] - range[0];
+    ctl[0] = range[2];
+    ctl[1] = (ctl[1] + n) % block_chunks;
+}
+
+hipError_t launch_stream_horizon(const void *enc_state, int nlanes, int bipolar, int t_end, int final_, int chunk_frames, int base_chunk,
+                                 int nwin, int *ctl, hipStream_t stream)
+{
+    const size_t nblk = (nlanes + 63) / 64;
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const unsigned char *base = reinterpret_cast<const unsigned char *>(enc_state);
+    size_t off = 256 + al(nblk * (MICLOC_MAX_IIR + 1) * 64 * sizeof(double));
+    const int *si = reinterpret_cast<const int *>(base + off);
+    off += al(nblk * 12 * 64 * sizeof(int));
+    off += al(nblk * RZ_RING * 64 * sizeof(double));
+    const int *ringP = reinterpret_cast<const int *>(base + off);
+    // ctl words: [0] done, [1] open, [4..6] range lo / hi / ready, [8] frames, [12..] status
+    hipLaunchKernelGGL(rz_stream_horizon_kernel, dim3(1), dim3(256), 0, stream, si, ringP, nlanes, bipolar, t_end, final_, chunk_frames,
+                       base_chunk, nwin, ctl, ctl + 4, ctl + 8, ctl + 12);
+    return hipGetLastError();
+}
+
+hipError_t launch_stream_commit(int *ctl, int block_chunks, hipStream_t stream)
+{
+    hipLaunchKernelGGL(rz_stream_commit_kernel, dim3(1), dim3(1), 0, stream, ctl, ctl + 4, block_chunks);
+    return hipGetLastError();
+}
+
+// dst[b][r] = src[b][r + shift] while r + shift < cap, 0 beyond: the raster window slides forward by `shift` frames.
+// ctl[0] chunks are done: the window must keep chunk (done - 1) for the LIF history, or status[1] is raised.
+__global__ __launch_bounds__(256) void rz_window_shift_kernel(const int8_t *__restrict__ src, int8_t *__restrict__ dst, size_t row_bytes,
+                                                               size_t shift_bytes, const int *__restrict__ ctl, int new_base_chunk,
+                                                               int *__restrict__ status)
+{
+    const int b = blockIdx.y;
+    const int8_t *s = src + (size_t)b * row_bytes;
+    int8_t *d = dst + (size_t)b * row_bytes;
+    const size_t keep = row_bytes - shift_bytes;
+    for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 16; i < row_bytes; i += (size_t)gridDim.x * 256 * 16) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const size_t e = i + u;
+            if (e < row_bytes) d[e] = e < keep ? s[e + shift_bytes] : (int8_t)0;
+        }
+    }
+    if (b == 0 && blockIdx.x == 0 && threadIdx.x == 0 && new_base_chunk > 0 && ctl[0] - 1 < new_base_chunk) atomicAdd(&status[1], 1);
+}
+
+hipError_t launch_window_shift(const int8_t *src, int8_t *dst, int B, size_t row_bytes, size_t shift_bytes, int *ctl, int new_base_chunk,
+                               hipStream_t stream)
+{
+    size_t gx = (row_bytes / 16 + 255) / 256;
+    gx = gx < 1 ? 1 : (gx > 256 ? 256 : gx);
+    hipLaunchKernelGGL(rz_window_shift_kernel, dim3((unsigned)gx, B), dim3(256), 0, stream, src, dst, row_bytes, shift_bytes, ctl,
+                       new_base_chunk, ctl + 12);
     return hipGetLastError();
 }
 

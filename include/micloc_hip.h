@@ -205,6 +205,36 @@ int micloc_stream_encode_f64(const micloc_plan *plan, const double *h, int B, in
                              void *stream);
 int micloc_stream_overflow(const void *state, int *count, void *stream);
 
+/* ---- streaming localisation: LIF + beamforming + power while the recording arrives ------------------------------------------
+ * The reference's live loop produces a DoA per 0.25 s frame by restarting the chain on every frame
+ * (micloc/localization_demo_snn.py:125-193); apply_to_signal (snn_beamformer.py:283-370) treats a recording as ONE stream.
+ * These calls do the latter incrementally, in O(tile) memory and without host synchronisation: the encoder scatters its spikes
+ * into a sliding WINDOW of the raster (int8 [B][window_frames][C] covering the absolute frames [window_base, window_base +
+ * window_frames), both multiples of micloc_stream_chunk_frames); after every tile micloc_stream_localize_f64 decides ON THE
+ * DEVICE which frames can no longer receive a spike (all clusters below them have closed), runs the LIF filter and the
+ * beamformer on the chunks that became final, and adds their sum of y^2 to a persistent [B][G] accumulator in exactly the order
+ * of the one-shot call's time reduction (blocks of 32 chunks, then the block sums) -- so that after the last tile power and
+ * arg-max equal micloc_lif_beamform_f64 / micloc_snn_pipeline_f64 of the whole recording BIT FOR BIT, for any tiling.  `power`
+ * [B][G] / `argmax` [B] (may be NULL) are the running values over the frames beamformed so far.
+ *   micloc_stream_encode_window_f64   like micloc_stream_encode_f64, raster = the window (zeroed on the first tile)
+ *   micloc_stream_window_shift        dst = the window moved forward to base_new (src != dst); the rows of the chunk in front
+ *                                     of the first chunk not yet beamformed must stay inside (else a lag failure is counted)
+ *   micloc_stream_localize_status     {chunks beamformed, frames beamformed, lag failures, open block fill}; synchronises
+ * loc_state: micloc_stream_localize_state_bytes (256-B aligned), zeroed by the call with first_tile = 1. */
+size_t micloc_stream_localize_state_bytes(const micloc_plan *plan, int B);
+int micloc_stream_chunk_frames(const micloc_plan *plan);
+size_t micloc_stream_localize_workspace_bytes(const micloc_plan *plan, int B, int window_frames);
+int micloc_stream_encode_window_f64(const micloc_plan *plan, const double *h, int B, int T_tile, int row_stride, long long t_base,
+                                    int first_tile, int final_tile, int8_t *window, int window_frames, long long window_base,
+                                    void *state, size_t state_bytes, void *stream);
+int micloc_stream_localize_f64(const micloc_plan *plan, const void *enc_state, void *loc_state, size_t loc_state_bytes,
+                               const int8_t *window, int B, int window_frames, long long window_base, long long t_end,
+                               int first_tile, int final_tile, double *power, int32_t *argmax, void *ws, size_t ws_bytes,
+                               void *stream);
+int micloc_stream_window_shift(const micloc_plan *plan, void *loc_state, const int8_t *src, int8_t *dst, int B, int window_frames,
+                               long long base_old, long long base_new, void *stream);
+int micloc_stream_localize_status(const void *loc_state, int *status4, void *stream);
+
 /* ---- beamforming vectors from membrane covariances (design_from_template's decomposition step) ------ */
 /* Replaces the per-DoA np.linalg.svd calls of SNNBeamformer.design_from_template (snn_beamformer.py:183-203) and
  * _find_dc_removed_sing_vec (:372-422) by one batched kernel: column g0 + i of bf_mat [C][G] from cov[i] [C][C]

@@ -20,18 +20,20 @@ def _beamformer(bipolar=True):
     return SNNBeamformer(CenterCircularArray(4.5e-2, 7), 10e-3, [1000.0, 2000.0], np.asarray([tau, tau]), bipolar_spikes=bipolar, fs=48_000)
 
 
-def _stream(bf, W, x, tiles, wrap=True):
+def _stream(bf, W, x, tiles, wrap=True, **kw):
     from haghighatshoarmuir2024_amd.streaming import StreamingLocalizer
 
     B, T, M = x.shape
     L2 = len(bf.kernel) // 2
-    s = StreamingLocalizer(bf, W, B, T, wrap_tail=x[:, T - L2 :, :] if wrap else None)
+    s = StreamingLocalizer(bf, W, B, T, wrap_tail=x[:, T - L2 :, :] if wrap else None, keep_raster=True, **kw)
     t = 0
     for n in tiles:
         s.push(x[:, t : t + n, :])
         t += n
     assert t == T
-    return s.finish(want_spikes=True)
+    out = s.finish(want_spikes=True)
+    out["status"] = s.status()
+    return out
 
 
 @pytest.mark.parametrize("bipolar", [True, False])
@@ -120,3 +122,69 @@ def test_stream_speech_length(cfg2):
     assert hashlib.sha256(np.ascontiguousarray(spikes).tobytes()).digest() == z["spikes_sha256"].tobytes()
     np.testing.assert_allclose(out["power"][0].cpu().numpy(), z["power"], rtol=1e-10)
     assert int(out["argmax"][0]) == int(z["argmax"])
+    assert out["status"]["frames"] == T and out["status"]["lag_failures"] == 0
+    # ... and bit for bit the one-shot call (its time reduction has the same, streamable order for any length)
+    one = bf.localize_batch(cfg2["bf_mat"], sig[None])
+    np.testing.assert_array_equal(out["power"].cpu().numpy(), one["power"].cpu().numpy())
+
+
+def test_stream_incremental_live_source(cfg2):
+    """The live form: the length is not known in advance (final=True comes with the last tile), no raster is kept -- memory is
+    O(tile) -- and every push returns the running power / arg-max over the frames whose spikes are final.  After the last tile
+    they equal the one-shot call bit for bit (the reference's live loop, localization_demo_snn.py:125-193, restarts the chain
+    every 0.25 s instead and never sees more than one frame)."""
+    import torch
+
+    from haghighatshoarmuir2024_amd.streaming import StreamingLocalizer
+
+    z = golden("trials_cfg2.npz")
+    rng = np.random.RandomState(4)
+    T = 48_000 + 4799  # a recording longer than the 1 s the neuron kernel is normalised over
+    x = rng.randn(3, T, 7)
+    x[:, :4799, :] += z["sig_in"]
+    bf = _beamformer()
+    W = cfg2["bf_mat"]
+    one = bf.localize_batch(W, x)
+    L2 = len(bf.kernel) // 2
+    torch.cuda.synchronize()
+    mem0 = torch.cuda.memory_allocated()
+    s = StreamingLocalizer(bf, W, 3, wrap_tail=x[:, T - L2 :, :], max_tile=2400, lag_frames=1024)
+    state_bytes = torch.cuda.memory_allocated() - mem0
+    assert state_bytes < 3 * (2400 + 480) * 7 * 8 * 8  # a few tiles' worth, nothing that grows with the recording
+    frames, t = [], 0
+    while t < T:
+        n = min(2400, T - t)
+        alloc0 = torch.cuda.memory_allocated()
+        power, argmax = s.push(torch.from_numpy(x[:, t : t + n, :]).cuda(), final=t + n == T)
+        assert torch.cuda.memory_allocated() - alloc0 <= 3 * n * 7 * 8 + 4096  # (only the tile handed in by this test)
+        t += n
+        frames.append(s.status()["frames"])
+        if frames[-1] > 0:
+            assert power.shape == (3, W.shape[1]) and float(power.min()) >= 0.0 and int(argmax.max()) < W.shape[1]
+    assert frames == sorted(frames) and frames[-1] == T and all(f % 256 == 0 for f in frames[:-1])
+    assert all(t_ - f <= 1024 + 256 for t_, f in zip(range(2400, T, 2400), frames))  # the horizon trails the input by a few clusters
+    out = s.finish()
+    np.testing.assert_array_equal(out["power"].cpu().numpy(), one["power"].cpu().numpy())
+    np.testing.assert_array_equal(out["argmax"].cpu().numpy(), one["argmax"].cpu().numpy())
+    with pytest.raises(ValueError):
+        s.finish(want_spikes=True)  # no raster was kept
+
+
+def test_stream_window_lag_is_reported(cfg2):
+    """A window too small for the input's longest silence (a plateau holds its cluster open) is an error, never a wrong result."""
+    from haghighatshoarmuir2024_amd import _lib
+    from haghighatshoarmuir2024_amd.streaming import StreamingLocalizer
+
+    bf = _beamformer()
+    rng = np.random.RandomState(5)
+    T = 9600
+    x = rng.randn(1, T, 7)
+    x[0, 1000:7000, :] = 0.0  # digital silence: the running sum stands still, the next candidate's plateau started long ago
+    one = bf.localize_batch(cfg2["bf_mat"], x)
+    ok = _stream(bf, cfg2["bf_mat"], x, [800] * 12, max_tile=800, lag_frames=8192)
+    np.testing.assert_array_equal(ok["power"].cpu().numpy(), one["power"].cpu().numpy())
+    s = StreamingLocalizer(bf, cfg2["bf_mat"], 1, T, max_tile=800, lag_frames=256)
+    for t in range(0, T, 800):
+        s.push(x[:, t : t + 800, :])
+    with pytest.raises(_lib.MiclocError, match="window"):
+        s.finish()
