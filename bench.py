@@ -268,8 +268,9 @@ def make_step(wl, nstreams, variants=True):
         runtime.counter_add_(st["epoch"], 1)
         runtime.uniform(B, 77, substream=0, lo=0.0, hi=2 * np.pi, out=st["doa"], epoch=st["epoch"])
         runtime.delay_min(st["doa"].view(B, 1), geo, out=st["shift"])
-        runtime.synth_targets(tpl, "apply_to_template", doa=st["doa"].view(B, 1), geometry=geo, shift=st["shift"], out=st["x"])
-        runtime.awgn_(st["x"], snr_db=snr_dev, seed=77, substream=0, epoch=st["epoch"], ws=st["ws"])
+        # synthesis + AWGN fused: the noise-free signal is never stored (micloc_synth_awgn_f64; same bits as synth_targets + awgn_)
+        runtime.synth_awgn(tpl, "apply_to_template", snr_dev, seed=77, substream=0, epoch=st["epoch"], ws=st["ws"], doa=st["doa"].view(B, 1),
+                           geometry=geo, shift=st["shift"], out=st["x"])
         out = plan.snn_pipeline(st["x"], want_power=True)
         _, mae = runtime.doa_error(out["argmax"], doa_list, st["doa"], groups=S, want_err=False)
         return out, mae
@@ -813,8 +814,9 @@ def run(args):
         mae_e = torch.stack(gathered).mean(dim=0)
     e2e = {"value": frames / dte, "unit": "frames/s", "ms_per_step": dte / args.steps * 1e3,
            "mae_deg_per_snr": [float(v) for v in (mae_e * 180 / np.pi).cpu().numpy()],
-           "note": "per step, inside the same HIP graph: DoA draw (Philox), delayed-template synthesis with in-kernel delays, AWGN "
-                   "(Philox + Box-Muller) at the trial's SNR, then the hot path and the DoA error; fresh trials every step"}
+           "note": "per step, inside the same HIP graph: DoA draw (Philox), delayed-template synthesis with in-kernel delays fused with the AWGN "
+                   "(Philox + Box-Muller at the trial's SNR; the noise-free signal is never stored), then the hot path and the DoA error; "
+                   "fresh trials every step"}
 
     cov_variant = f32_variant = None
     if M * 2 <= 128:

@@ -92,6 +92,8 @@ SYMBOLS = {
     "micloc_awgn_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "micloc_awgn_f64": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, ctypes.c_uint64, ctypes.c_uint32, c_void_p, ctypes.c_uint32,
                                 c_void_p, c_size_t, c_void_p]),
+    "micloc_synth_awgn_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "micloc_synth_awgn_f64": (c_int, [c_void_p, c_void_p, ctypes.c_uint64, ctypes.c_uint32, c_void_p, ctypes.c_uint32, c_void_p, c_size_t, c_void_p]),
     "micloc_doa_error_f64": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "micloc_xylo_workspace_bytes": (c_size_t, [c_int, c_int]),
     "micloc_xylo_lif_i16": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,

@@ -781,13 +781,12 @@ int micloc_synth_delay_f64(const double *time, const double *sig, const double *
     return MICLOC_OK;
 }
 
-int micloc_synth_targets_f64(const micloc_synth_args *a, void *stream)
+static int synth_args_from_abi(const micloc_synth_args *a, SynthArgs *out)
 {
     if (!a || !a->time || !a->sig || !a->slopes || !a->x || a->T < 2 || bad_batch(a->B) || a->K < 1 || a->M < 1 || !(a->fs > 0.0))
         return MICLOC_ERR_INVALID;
     if (a->mode != MICLOC_SYNTH_APPLY_TO_TEMPLATE && a->mode != MICLOC_SYNTH_SIGNAL_FROM_TEMPLATE) return MICLOC_ERR_INVALID;
     if (!a->delays && (!a->doa || !a->r_vec || !a->theta_vec || !(a->speed > 0.0))) return MICLOC_ERR_INVALID;
-    DeviceGuard guard(device_of(a->x));
     SynthArgs k{};
     k.time = a->time;
     k.sig = a->sig;
@@ -807,7 +806,37 @@ int micloc_synth_targets_f64(const micloc_synth_args *a, void *stream)
     k.mode = a->mode;
     k.inv_step = a->fs;
     k.x = a->x;
+    *out = k;
+    return MICLOC_OK;
+}
+
+int micloc_synth_targets_f64(const micloc_synth_args *a, void *stream)
+{
+    SynthArgs k{};
+    const int rc = synth_args_from_abi(a, &k);
+    if (rc != MICLOC_OK) return rc;
+    DeviceGuard guard(device_of(a->x));
     HIP_TRY(launch_synth_targets(k, (hipStream_t)stream));
+    return MICLOC_OK;
+}
+
+size_t micloc_synth_awgn_workspace_bytes(int B, int T, int M, int K)
+{
+    if (B < 1 || T < 1 || M < 1 || K < 1) return 0;
+    return synth_awgn_ws_bytes(B, (size_t)T * M, K, M);
+}
+
+int micloc_synth_awgn_f64(const micloc_synth_args *a, const double *snr_db, uint64_t seed, uint32_t substream, const uint32_t *epoch,
+                          uint32_t first_trial, void *ws, size_t ws_bytes, void *stream)
+{
+    SynthArgs k{};
+    const int rc = synth_args_from_abi(a, &k);
+    if (rc != MICLOC_OK) return rc;
+    if (!snr_db) return MICLOC_ERR_INVALID;
+    if (((size_t)k.T * k.M + 1) / 2 > 0xFFFFFFFFull || (uint64_t)first_trial + (uint64_t)k.B > 0xFFFFFFFFull) return MICLOC_ERR_INVALID;
+    if (bad_ws(ws, ws_bytes, synth_awgn_ws_bytes(k.B, (size_t)k.T * k.M, k.K, k.M))) return MICLOC_ERR_WORKSPACE;
+    DeviceGuard guard(device_of(a->x));
+    HIP_TRY(launch_synth_awgn(k, snr_db, seed, substream, epoch, first_trial, ws, (hipStream_t)stream));
     return MICLOC_OK;
 }
 

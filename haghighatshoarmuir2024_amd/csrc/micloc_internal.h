@@ -151,6 +151,11 @@ size_t awgn_ws_bytes(int B, size_t n);
 hipError_t launch_awgn(double *x, int B, size_t n, const double *snr_db, const double *sigma, uint64_t seed, uint32_t substream,
                        const uint32_t *epoch, uint32_t trial0, void *ws, hipStream_t stream);
 
+// fused: x = synth(args) + sigma N(0, 1) without ever storing the noise-free signal (same bits as synth_targets + awgn)
+size_t synth_awgn_ws_bytes(int B, size_t n, int K, int M);
+hipError_t launch_synth_awgn(const SynthArgs &a, const double *snr_db, uint64_t seed, uint32_t substream, const uint32_t *epoch,
+                             uint32_t trial0, void *ws, hipStream_t stream);
+
 // ---- sweep results ---------------------------------------------------------------------------------------------
 hipError_t launch_doa_error(const int32_t *argmax, const double *doa_list, int G, const double *doa_true, int B, int groups,
                             double *err, double *mae, hipStream_t stream);

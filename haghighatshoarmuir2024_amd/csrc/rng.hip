@@ -16,6 +16,7 @@
 // draws of substream 0 coincide with trial 0's noise.)  The normals of trial b are numbered by element pair: pair i covers
 // elements 2i, 2i+1 of the flat [T][M] frame block (z0 = r cos, z1 = r sin); a call covers fewer than 2^32 pairs.
 #include "micloc_internal.h"
+#include "synth_dev.h"
 
 namespace micloc {
 
@@ -144,9 +145,10 @@ __global__ __launch_bounds__(256) void awgn_kernel(double *__restrict__ x, size_
         const double u1 = u53_oc(r.v[0], r.v[1]);
         const double u2 = u53_co(r.v[2], r.v[3]);
         const double rad = sqrt(-2.0 * log(u1));
-        const double ang = 6.283185307179586476925286766559 * u2;
-        xb[e] = xb[e] + sg * (rad * cos(ang));
-        if (e + 1 < n) xb[e + 1] = xb[e + 1] + sg * (rad * sin(ang));
+        double sn, cs;
+        sincospi(2.0 * u2, &sn, &cs);  // cos / sin of 2 pi u2 without the product's rounding and without a pi reduction
+        xb[e] = xb[e] + sg * (rad * cs);
+        if (e + 1 < n) xb[e + 1] = xb[e + 1] + sg * (rad * sn);
     }
 }
 
@@ -170,6 +172,257 @@ hipError_t launch_awgn(double *x, int B, size_t n, const double *snr_db, const d
     }
     hipLaunchKernelGGL(awgn_kernel, dim3(nblk, B), dim3(256), 0, stream, x, n, sigma, (uint32_t)seed, (uint32_t)(seed >> 32),
                        substream, epoch, trial0);
+    return hipGetLastError();
+}
+
+// ---- synthesis + noise in one go (the input side of a throughput-mode Monte-Carlo step) ------------------------------------
+// x[b] = s[b] + sigma_b N(0, 1),  s = the synthesised array signal (synth.hip),  sigma_b = sqrt(mean(s[b]^2)) / sqrt(snr_b).
+// Done with the kernels above this costs three passes over the B x T x M tensor besides the one that has to happen (store s;
+// read it for the sum of squares; read it again to add the noise).  Here the signal is never stored without its noise:
+//   pass 1  synth_sumsq_kernel   recomputes s and reduces s^2 per block of AWGN_BLOCK elements -- the order of sumsq_kernel, so
+//                                sigma is bit-identical to the unfused path's;
+//   pass 2  synth_awgn_kernel    recomputes s, draws the normals of awgn_kernel (same counters) and stores s + sigma z once.
+// The synthesis is a handful of instructions per sample next to Box-Muller's log / sincos, so computing it twice is cheaper than
+// one round trip through HBM.  Same bits as synth_targets_kernel followed by awgn_kernel.
+// (t, m) of flat element e advance with e by fixed steps: no division in the loops.
+struct FlatTM {
+    int t, m;
+    __device__ __forceinline__ FlatTM(size_t e, int M) : t((int)(e / (size_t)M)), m((int)(e - (size_t)t * M)) {}
+    __device__ __forceinline__ void advance(int dt, int dm, int M)
+    {
+        t += dt;
+        m += dm;
+        if (m >= M) {
+            m -= M;
+            ++t;
+        }
+    }
+};
+
+// The template rows a block of AWGN_BLOCK flat elements can touch, staged in LDS: the block covers the time steps
+// [t_lo, t_hi] and a constant-DoA trial shifts them by at most max |delay| -- for the paper's 4.5 cm array 13 samples.  With the
+// rows in LDS a sample costs about 25 instructions and no global load (np.interp's bracket search runs on LDS; the original
+// kernel spends most of its time on a 64-bit division and five dependent global loads per sample).  Samples whose bracket
+// falls outside the staged window (a wider array than the window allows, a non-uniform grid) take the global-memory path:
+// same arithmetic, same bits either way.
+constexpr int SF_WIN = 1536;  // staged template rows (3 x 12 KB)
+
+struct SynthWindow {
+    const double *xp, *fp, *sl;  // LDS
+    int w0, wn;                  // first staged row, number of staged rows (0: nothing staged)
+};
+
+__device__ __forceinline__ SynthWindow stage_template(const SynthArgs &a, const double *dl, bool cached, double shift, size_t lo, size_t n,
+                                                      double *xs, double *fs_, double *ss, int *ired)
+{
+    SynthWindow w{xs, fs_, ss, 0, 0};
+    if (!cached) return w;
+    // largest |argument shift| in samples over the trial's K x M delays
+    double dm = 0.0;
+    for (int e = threadIdx.x; e < a.K * a.M; e += 256) {
+        const double d = a.mode == 0 ? (a.shift ? dl[e] - shift : dl[e]) : dl[e];
+        dm = fabs(d) > dm ? fabs(d) : dm;
+    }
+    int js = (int)(dm * a.inv_step) + 3;
+    js = dm * a.inv_step < 1.0e6 ? js : SF_WIN;  // (absurd delays: nothing staged)
+    ired[threadIdx.x] = js;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) {
+        if ((int)threadIdx.x < h) ired[threadIdx.x] = ired[threadIdx.x + h] > ired[threadIdx.x] ? ired[threadIdx.x + h] : ired[threadIdx.x];
+        __syncthreads();
+    }
+    const int jd = ired[0];
+    const size_t last = (lo + AWGN_BLOCK < n ? lo + AWGN_BLOCK : n) - 1;
+    const int t_lo = (int)(lo / (size_t)a.M), t_hi = (int)(last / (size_t)a.M);
+    int w0 = t_lo - jd, w1 = t_hi + jd;  // rows [w0, w1]
+    w0 = w0 < 0 ? 0 : w0;
+    w1 = w1 > a.T - 1 ? a.T - 1 : w1;
+    const int wn = w1 - w0 + 1;
+    if (wn > SF_WIN) return w;
+    for (int e = threadIdx.x; e < wn; e += 256) {
+        xs[e] = a.time[w0 + e];
+        fs_[e] = a.sig[w0 + e];
+        ss[e] = w0 + e < a.T - 1 ? a.slopes[w0 + e] : 0.0;
+    }
+    __syncthreads();
+    w.w0 = w0;
+    w.wn = wn;
+    return w;
+}
+
+// synth_sample for a constant-DoA trial with the template window in LDS.  np.interp's bracket search (two data-dependent
+// loops, each trip a dependent read) becomes straight-line code: on the nominally uniform grid the guess j is off by at most
+// one row, so the rows j - 1 .. j + 2 are read together, the bracket q in {j - 1, j, j + 1} is selected and VERIFIED
+// (xp[q] <= x < xp[q + 1]); anything else -- the window's edge, the ends of the template, a grid that is not uniform -- takes
+// the original routine.  Same bracket, same arithmetic, same bits.
+__device__ __forceinline__ double synth_sample_win(const SynthArgs &a, const SynthWindow &w, const double *__restrict__ dl, int b, int t, int m,
+                                                   double x0, double shift)
+{
+    const double tt = w.wn ? w.xp[t - w.w0] : a.time[t];  // (wn == 0: nothing staged, every sample takes the global rows)
+    double acc = 0.0;
+    for (int k = 0; k < a.K; ++k) {
+        double d = dl[k * a.M + m];
+        double x;
+        if (a.mode == 0) {
+            if (a.shift) d = d - shift;
+            x = tt - d;
+            x = x < x0 ? x0 : x;
+        } else {
+            x = tt + d;
+        }
+        int j = (int)((x - x0) * a.inv_step);
+        j = j < 0 ? 0 : (j > a.T - 1 ? a.T - 1 : j);
+        const int jl = j - w.w0;
+        const bool inside = w.wn > 0 && jl >= 1 && jl + 2 <= w.wn - 1 && !(x < x0);  // rows j - 1 .. j + 2 are staged (hence j + 2 <= T - 1)
+        const int jc = inside ? jl : 1;
+        const double xm = w.xp[jc - 1], xc = w.xp[jc], xn = w.xp[jc + 1], xnn = w.xp[jc + 2];
+        const double fm = w.fp[jc - 1], fc = w.fp[jc], fn = w.fp[jc + 1];
+        const double sm = w.sl[jc - 1], sc = w.sl[jc], sn = w.sl[jc + 1];
+        const bool down = xc > x, up = xn <= x;
+        const double xq = down ? xm : (up ? xn : xc);
+        const double xq1 = down ? xc : (up ? xnn : xn);
+        const double fq = down ? fm : (up ? fn : fc);
+        const double sq = down ? sm : (up ? sn : sc);
+        double r = (xq == x) ? fq : sq * (x - xq) + fq;
+        if (__builtin_expect(!(inside && xq <= x && x < xq1), 0)) r = interp_one(a.time, a.sig, a.slopes, a.T, x, x0, a.inv_step);
+        if (a.gain) r = a.gain[((size_t)b * a.K + k) * a.T + t] * r;
+        acc = (a.K == 1) ? r : acc + r;
+    }
+    return acc;
+}
+
+// CONST_DOA: the K x M delays of a trial do not depend on time (and fit the LDS table): template window + straight-line
+// interpolation.  Otherwise (moving DoAs) the general per-sample routine with its in-loop cos.
+template <bool CONST_DOA>
+__global__ __launch_bounds__(256) void synth_sumsq_kernel(SynthArgs a, int nblk, double *__restrict__ partial)
+{
+    __shared__ double dl[512];
+    __shared__ double red[256];
+    __shared__ double xs[CONST_DOA ? SF_WIN : 1], fs_[CONST_DOA ? SF_WIN : 1], ss[CONST_DOA ? SF_WIN : 1];
+    const int b = blockIdx.y;
+    constexpr bool cached = CONST_DOA;
+    if (cached) {
+        // (the launcher has put the trial's K x M delays into a table: no cos -- and none of its registers -- in this kernel)
+        for (int e = threadIdx.x; e < a.K * a.M; e += 256) dl[e] = a.delays[(size_t)b * a.K * a.M + e];
+        __syncthreads();
+    }
+    const size_t n = (size_t)a.T * a.M;
+    const size_t lo = (size_t)blockIdx.x * AWGN_BLOCK;
+    const double x0 = a.time[0];
+    const double shift = a.shift ? a.shift[b] : 0.0;
+    SynthWindow w{xs, fs_, ss, 0, 0};
+    if constexpr (CONST_DOA) w = stage_template(a, dl, true, shift, lo, n, xs, fs_, ss, reinterpret_cast<int *>(red));
+    __syncthreads();
+    FlatTM tm(lo + threadIdx.x, a.M);
+    const int dt = 256 / a.M, dm = 256 % a.M;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < AWGN_BLOCK; i += 256) {
+        if (lo + i < n) {
+            double v;
+            if constexpr (CONST_DOA)
+                v = synth_sample_win(a, w, dl, b, tm.t, tm.m, x0, shift);
+            else
+                v = synth_sample(a, nullptr, b, tm.t, tm.m, x0, shift);
+            acc = __builtin_fma(v, v, acc);
+        }
+        tm.advance(dt, dm, a.M);
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) {
+        if ((int)threadIdx.x < h) red[threadIdx.x] += red[threadIdx.x + h];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[(size_t)b * nblk + blockIdx.x] = red[0];
+}
+
+template <bool CONST_DOA>
+__global__ __launch_bounds__(256) void synth_awgn_kernel(SynthArgs a, const double *__restrict__ sigma, uint32_t k0, uint32_t k1, uint32_t sub,
+                                                          const uint32_t *__restrict__ epoch, uint32_t trial0)
+{
+    __shared__ double dl[512];
+    __shared__ double xs[CONST_DOA ? SF_WIN : 1], fs_[CONST_DOA ? SF_WIN : 1], ss[CONST_DOA ? SF_WIN : 1];
+    __shared__ int ired[256];
+    const int b = blockIdx.y;
+    constexpr bool cached = CONST_DOA;
+    if (cached) {
+        for (int e = threadIdx.x; e < a.K * a.M; e += 256) dl[e] = a.delays[(size_t)b * a.K * a.M + e];
+        __syncthreads();
+    }
+    const uint32_t ep = epoch ? *epoch : 0u;
+    const size_t n = (size_t)a.T * a.M;
+    double *xb = a.x + (size_t)b * n;
+    const double sg = sigma[b];
+    const double x0 = a.time[0];
+    const double shift = a.shift ? a.shift[b] : 0.0;
+    const size_t pair0 = (size_t)blockIdx.x * (AWGN_BLOCK / 2);
+    SynthWindow w{xs, fs_, ss, 0, 0};
+    if constexpr (CONST_DOA) w = stage_template(a, dl, true, shift, 2 * pair0, n, xs, fs_, ss, ired);
+    FlatTM tm(2 * (pair0 + threadIdx.x), a.M);
+    const int dt = 512 / a.M, dm = 512 % a.M;
+    for (int i = threadIdx.x; i < AWGN_BLOCK / 2; i += 256) {
+        const size_t pair = pair0 + i;
+        const size_t e = 2 * pair;
+        if (e >= n) break;
+        FlatTM t1 = tm;
+        t1.advance(0, 1, a.M);
+        double s0, s1 = 0.0;
+        if constexpr (CONST_DOA) {
+            s0 = synth_sample_win(a, w, dl, b, tm.t, tm.m, x0, shift);
+            if (e + 1 < n) s1 = synth_sample_win(a, w, dl, b, t1.t, t1.m, x0, shift);
+        } else {
+            s0 = synth_sample(a, nullptr, b, tm.t, tm.m, x0, shift);
+            if (e + 1 < n) s1 = synth_sample(a, nullptr, b, t1.t, t1.m, x0, shift);
+        }
+        const Philox4 r = philox4x32_10((uint32_t)pair, ep, trial0 + (uint32_t)b, sub, k0, k1);
+        const double u1 = u53_oc(r.v[0], r.v[1]);
+        const double u2 = u53_co(r.v[2], r.v[3]);
+        const double rad = sqrt(-2.0 * log(u1));
+        double sn, cs;
+        sincospi(2.0 * u2, &sn, &cs);
+        xb[e] = s0 + sg * (rad * cs);
+        if (e + 1 < n) xb[e + 1] = s1 + sg * (rad * sn);
+        tm.advance(dt, dm, a.M);
+    }
+}
+
+// table[b][k][m] = the constant-DoA delays of every trial, from the DoAs and the geometry (the cos of mic_delay, once per entry)
+__global__ __launch_bounds__(256) void delay_table_kernel(SynthArgs a, double *__restrict__ table)
+{
+    const int b = blockIdx.x;
+    for (int e = threadIdx.x; e < a.K * a.M; e += 256) table[(size_t)b * a.K * a.M + e] = mic_delay(a, b, e / a.M, 0, e % a.M);
+}
+
+size_t synth_awgn_ws_bytes(int B, size_t n, int K, int M)
+{
+    return awgn_ws_bytes(B, n) + (((size_t)B * K * M * sizeof(double) + 255) & ~(size_t)255);
+}
+
+hipError_t launch_synth_awgn(const SynthArgs &a_in, const double *snr_db, uint64_t seed, uint32_t substream, const uint32_t *epoch,
+                             uint32_t trial0, void *ws, hipStream_t stream)
+{
+    SynthArgs a = a_in;
+    const size_t n = (size_t)a.T * a.M;
+    const int nblk = (int)((n + AWGN_BLOCK - 1) / AWGN_BLOCK);
+    double *partial = reinterpret_cast<double *>(ws);
+    double *sg = partial + (size_t)a.B * nblk;
+    const bool const_doa = !a.moving && a.K * a.M <= 512;
+    if (const_doa && !a.delays) {
+        double *table = reinterpret_cast<double *>(reinterpret_cast<unsigned char *>(ws) + awgn_ws_bytes(a.B, n));
+        hipLaunchKernelGGL(delay_table_kernel, dim3(a.B), dim3(256), 0, stream, a, table);
+        a.delays = table;
+    }
+    if (const_doa)
+        hipLaunchKernelGGL(synth_sumsq_kernel<true>, dim3(nblk, a.B), dim3(256), 0, stream, a, nblk, partial);
+    else
+        hipLaunchKernelGGL(synth_sumsq_kernel<false>, dim3(nblk, a.B), dim3(256), 0, stream, a, nblk, partial);
+    hipLaunchKernelGGL(sigma_kernel, dim3(a.B), dim3(256), 0, stream, partial, nblk, n, snr_db, sg);
+    if (const_doa)
+        hipLaunchKernelGGL(synth_awgn_kernel<true>, dim3(nblk, a.B), dim3(256), 0, stream, a, sg, (uint32_t)seed, (uint32_t)(seed >> 32), substream,
+                           epoch, trial0);
+    else
+        hipLaunchKernelGGL(synth_awgn_kernel<false>, dim3(nblk, a.B), dim3(256), 0, stream, a, sg, (uint32_t)seed, (uint32_t)(seed >> 32), substream,
+                           epoch, trial0);
     return hipGetLastError();
 }
 

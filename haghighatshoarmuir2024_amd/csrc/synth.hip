@@ -18,37 +18,9 @@
 //     B x T x M crosses PCIe -- the throughput path.  This replaces the reference's T-calls-per-trial Python loop over
 //     geometry.delays (60 % of its per-trial time, snn_beamformer.py:254-256).
 #include "micloc_internal.h"
+#include "synth_dev.h"
 
 namespace micloc {
-
-__device__ __forceinline__ double interp_one(const double *__restrict__ xp, const double *__restrict__ fp,
-                                             const double *__restrict__ slopes, int T, double x, double x0, double inv_step)
-{
-    if (x < x0) return fp[0];  // np.interp: left = fp[0]
-    // bracket: guess from the (nominally) uniform grid, then correct against the stored grid
-    int j = (int)((x - x0) * inv_step);
-    j = j < 0 ? 0 : (j > T - 1 ? T - 1 : j);
-    while (j > 0 && xp[j] > x) --j;
-    while (j < T - 1 && xp[j + 1] <= x) ++j;
-    if (j == T - 1) return fp[j];  // x >= xp[T-1]: right = fp[T-1]
-    const double xj = xp[j];
-    return (xj == x) ? fp[j] : slopes[j] * (x - xj) + fp[j];
-}
-
-__device__ __forceinline__ double mic_delay(const SynthArgs &a, int b, int k, int t, int m)
-{
-    const int Td = a.moving ? a.T : 1;
-    const int td = a.moving ? t : 0;
-    const size_t bk = (size_t)b * a.K + k;
-    double d;
-    if (a.delays) {
-        d = a.delays[(bk * Td + td) * a.M + m];
-    } else {
-        // ArrayGeometry.delays (array_geometry.py:52): -r_vec * cos(theta_vec - theta) / speed, in that order
-        d = -a.r_vec[m] * cos(a.theta_vec[m] - a.doa[bk * Td + td]) / a.speed;
-    }
-    return d;
-}
 
 // constant-DoA, one target, host delays: the original fast path (one delay load per output)
 __global__ __launch_bounds__(256) void synth_kernel(const double *__restrict__ xp, const double *__restrict__ fp,
@@ -94,25 +66,8 @@ __global__ __launch_bounds__(256) void synth_targets_kernel(SynthArgs a)
     if (idx >= (size_t)a.T * a.M) return;
     const int t = (int)(idx / a.M);
     const int m = (int)(idx - (size_t)t * a.M);
-    const double x0 = a.time[0];
-    const double tt = a.time[t];
     const double shift = a.shift ? a.shift[b] : 0.0;
-    double acc = 0.0;
-    for (int k = 0; k < a.K; ++k) {
-        double d = cached ? dl[k * a.M + m] : mic_delay(a, b, k, t, m);
-        double x;
-        if (a.mode == 0) {
-            if (a.shift) d = d - shift;  // delays - delays.min()  (snn_beamformer.py:257)
-            x = tt - d;                  // :259
-            x = x < x0 ? x0 : x;         // :260
-        } else {
-            x = tt + d;  // xylo_snn_localization.py:64, multiple_targets_snn.py:147
-        }
-        double r = interp_one(a.time, a.sig, a.slopes, a.T, x, x0, a.inv_step);
-        if (a.gain) r = a.gain[((size_t)b * a.K + k) * a.T + t] * r;  // multiple_targets_snn.py:155
-        acc = (a.K == 1) ? r : acc + r;                               // :157 (sig_in = 0; sig_in += sig_target)
-    }
-    a.x[(size_t)b * a.T * a.M + idx] = acc;
+    a.x[(size_t)b * a.T * a.M + idx] = synth_sample(a, cached ? dl : nullptr, b, t, m, a.time[0], shift);
 }
 
 hipError_t launch_synth_targets(const SynthArgs &a, hipStream_t stream)

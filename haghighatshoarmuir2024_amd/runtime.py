@@ -400,13 +400,9 @@ def _as_dev(a, device):
     return a.to(device=device, dtype=torch.float64).contiguous()
 
 
-def synth_targets(template, mode, delays=None, doa=None, geometry=None, moving=False, shift=None, gain=None, out=None):
-    """micloc_synth_targets_f64: x [B, T, M] = sum_k gain * interp(...) (see include/micloc_hip.h).
-
-    delays [B, K, (T,) M] (host NumPy -> bit-exact parity) or doa [B, K(, T)] + `geometry` (runtime.Geometry: delays
-    computed in the kernel).  mode: "apply_to_template" (t - (d - shift), clamped) or "signal_from_template" (t + d)."""
+def _synth_args(template, mode, delays, doa, geometry, moving, shift, gain, out):
+    """MiclocSynthArgs for the generators below; returns (args, x, tensors to keep alive until the call has been issued)."""
     torch = _torch()
-    lib = _lib.load()
     dev = template.device
     T = template.T
     args = _lib.MiclocSynthArgs()
@@ -449,7 +445,40 @@ def synth_targets(template, mode, delays=None, doa=None, geometry=None, moving=F
     args.mode = {"apply_to_template": 0, "signal_from_template": 1}[mode]
     args.fs = template.fs
     args.x = x.data_ptr()
-    _lib.check(lib.micloc_synth_targets_f64(ctypes.byref(args), _stream(dev)), "synth_targets")
+    return args, x, (keep, sh, gn)
+
+
+def synth_targets(template, mode, delays=None, doa=None, geometry=None, moving=False, shift=None, gain=None, out=None):
+    """micloc_synth_targets_f64: x [B, T, M] = sum_k gain * interp(...) (see include/micloc_hip.h).
+
+    delays [B, K, (T,) M] (host NumPy -> bit-exact parity) or doa [B, K(, T)] + `geometry` (runtime.Geometry: delays
+    computed in the kernel).  mode: "apply_to_template" (t - (d - shift), clamped) or "signal_from_template" (t + d)."""
+    args, x, keep = _synth_args(template, mode, delays, doa, geometry, moving, shift, gain, out)
+    _lib.check(_lib.load().micloc_synth_targets_f64(ctypes.byref(args), _stream(template.device)), "synth_targets")
+    del keep
+    return x
+
+
+def synth_awgn(template, mode, snr_db, seed=0, substream=0, first_trial=0, epoch=None, ws=None, delays=None, doa=None, geometry=None,
+               moving=False, shift=None, gain=None, out=None):
+    """micloc_synth_awgn_f64: synth_targets(...) followed by awgn_(x, snr_db=...) in two passes that never store the noise-free
+    signal (one trip through HBM instead of four); the same bits as the two calls."""
+    torch = _torch()
+    lib = _lib.load()
+    dev = template.device
+    args, x, keep = _synth_args(template, mode, delays, doa, geometry, moving, shift, gain, out)
+    B, T, M = x.shape
+    if not isinstance(snr_db, torch.Tensor):
+        snr_db = np.array(np.broadcast_to(np.asarray(snr_db, dtype=np.float64), (B,)))
+    s_db = _as_dev(snr_db, dev)
+    nbytes = lib.micloc_synth_awgn_workspace_bytes(B, T, M, int(args.K))
+    if ws is None:
+        ws = _op_workspace(dev, nbytes)
+    elif ws.numel() < nbytes:
+        raise ValueError("synth_awgn workspace too small (micloc_synth_awgn_workspace_bytes)")
+    _lib.check(lib.micloc_synth_awgn_f64(ctypes.byref(args), _ptr(s_db), int(seed), int(substream), _ptr(epoch), int(first_trial), _ptr(ws), nbytes,
+                                         _stream(dev)), "synth_awgn")
+    del keep
     return x
 
 
@@ -545,9 +574,10 @@ def counter_add_(counter, inc=1):
     return counter
 
 
-def awgn_workspace(B, T, M, device):
+def awgn_workspace(B, T, M, device, K=1):
+    """Workspace of awgn_ and synth_awgn (K targets) for [B, T, M] signals."""
     torch = _torch()
-    return torch.empty(int(_lib.load().micloc_awgn_workspace_bytes(int(B), int(T), int(M))), dtype=torch.uint8, device=device)
+    return torch.empty(int(_lib.load().micloc_synth_awgn_workspace_bytes(int(B), int(T), int(M), int(K))), dtype=torch.uint8, device=device)
 
 
 def doa_error(argmax, doa_list, doa_true, groups=1, want_err=True):

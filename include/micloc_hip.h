@@ -305,6 +305,13 @@ int micloc_uniform_f64(double *out, size_t n, uint64_t seed, uint32_t substream,
 size_t micloc_awgn_workspace_bytes(int B, int T, int M);
 int micloc_awgn_f64(double *x, int B, int T, int M, const double *snr_db, const double *sigma, uint64_t seed, uint32_t substream,
                     const uint32_t *epoch, uint32_t first_trial, void *ws, size_t ws_bytes, void *stream);
+/* micloc_synth_targets_f64 followed by micloc_awgn_f64 (sigma from snr_db) WITHOUT storing the noise-free signal: pass 1 recomputes
+ * the synthesis and reduces its squares (the unfused order: sigma is bit-identical), pass 2 recomputes it, adds the normals of
+ * micloc_awgn_f64 (same counters) and stores x once -- one trip through HBM instead of four; same bits as the two calls.
+ * ws from micloc_synth_awgn_workspace_bytes(B, T, M, K). */
+size_t micloc_synth_awgn_workspace_bytes(int B, int T, int M, int K);
+int micloc_synth_awgn_f64(const micloc_synth_args *args, const double *snr_db, uint64_t seed, uint32_t substream, const uint32_t *epoch,
+                          uint32_t first_trial, void *ws, size_t ws_bytes, void *stream);
 int micloc_counter_add_u32(uint32_t *counter, uint32_t inc, void *stream); /* *counter += inc (device word) */
 
 /* ---- Monte-Carlo results ---------------------------------------------------------------------- */

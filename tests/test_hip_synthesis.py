@@ -123,3 +123,33 @@ def test_throughput_sweep_is_sharding_invariant(cfg2, geo):
     np.testing.assert_array_equal(res["argmax"], full["argmax"])  # batch split 7 vs 1100: same draws, same results
     np.testing.assert_array_equal(res["pmax"], full["pmax"])
     assert full["mae_deg"][0] > full["mae_deg"][2] and full["mae_deg"][2] < 3.0
+
+
+def test_fused_synthesis_and_noise_equals_the_two_calls(geo):
+    """micloc_synth_awgn_f64 (two passes that never store the noise-free signal) == micloc_synth_targets_f64 followed by
+    micloc_awgn_f64, bit for bit: constant and moving DoAs, several targets with gains, both delay sources and conventions,
+    ragged block ends, an epoch word."""
+    import torch
+
+    from haghighatshoarmuir2024_amd import runtime
+
+    fs = 48_000
+    rng = np.random.RandomState(11)
+    for T, B in ((4799, 5), (1171, 3), (8192 // 7 + 1, 2), (333, 1)):
+        t = np.arange(T) / fs
+        tpl = runtime.Template(t, np.sin(2 * np.pi * 1500 * t) + 0.1 * rng.randn(T), fs)
+        g = runtime.Geometry(geo)
+        snr = np.linspace(-5, 15, B)
+        ep = torch.full((1,), 3, dtype=torch.int32, device="cuda")
+        cases = []
+        doa = rng.rand(B, 1) * 2 * np.pi
+        cases.append(dict(mode="apply_to_template", doa=doa, geometry=g, shift=runtime.delay_min(torch.from_numpy(doa).cuda(), g)))
+        cases.append(dict(mode="signal_from_template", doa=doa, geometry=g))
+        cases.append(dict(mode="apply_to_template", delays=geo.delays(doa[:, 0], normalized=False)[:, None, :], shift=np.zeros(B)))
+        mv = rng.rand(B, 2, T) * 2 * np.pi
+        cases.append(dict(mode="signal_from_template", doa=mv, geometry=g, moving=True, gain=rng.rand(B, 2, T)))
+        for kw in cases:
+            want = runtime.synth_targets(tpl, **kw)
+            runtime.awgn_(want, snr_db=snr, seed=99, substream=4, first_trial=17, epoch=ep)
+            got = runtime.synth_awgn(tpl, snr_db=snr, seed=99, substream=4, first_trial=17, epoch=ep, **kw)
+            assert torch.equal(got, want), (T, B, kw["mode"], sorted(kw))
