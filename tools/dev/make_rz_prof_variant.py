@@ -64,6 +64,32 @@ if "noresolve" in abl:
     s = s.replace("            resolve_cluster(s, e, stride, w, emit, word_at, val_at, sgn);", "            emit(lastpos);")
 if "nodetectloop" in abl:
     s = s.replace("                while (__any(Ew != 0u)) {\n                    if (Ew) {", "                while (false) {\n                    if (Ew) {")
+if "size2" in abl:
+    s = s.replace("""        if (e - s <= stride)
+            emit(lastpos);
+        else
+            resolve_cluster(s, e, stride, w, emit, word_at, val_at, sgn);""", """        if (e - s <= stride)
+            emit(lastpos);
+        else if (e - s <= 2 * stride) {
+            const double v0 = *val_at(s) * sgn, v1 = *val_at(s + stride) * sgn;
+            emit(v1 >= v0 ? lastpos : first);
+        } else
+            resolve_cluster(s, e, stride, w, emit, word_at, val_at, sgn);""")
+    assert "v1 >= v0 ? lastpos : first" in s
+if "no16" in abl:
+    s = s.replace("""    if (remaining <= 16) {
+        resolve_cluster_regs<16>(s, stride, remaining, w, emit, word_at, val_at, sgn);
+        return;
+    }""", "")
+if "only4" in abl:
+    s = s.replace("""    if (remaining <= 8) {
+        resolve_cluster_regs<8>(s, stride, remaining, w, emit, word_at, val_at, sgn);
+        return;
+    }
+    if (remaining <= 16) {
+        resolve_cluster_regs<16>(s, stride, remaining, w, emit, word_at, val_at, sgn);
+        return;
+    }""", "")
 tmp = os.path.join(CS, "rzcc_prof_tmp_%s.hip" % (abl or "plain"))
 obj = "/tmp/rzcc_prof_%s.o" % (abl or "plain")
 open(tmp, "w").write(s)

@@ -1,19 +1,20 @@
 #!/bin/bash
-# Round profiling recipe (run on the GPU box from the repo root: gpurun -- 'bash tools/profile_round.sh r2').
+# Round profiling recipe (run on the GPU box from the repo root: gpurun -- 'bash tools/profile_round.sh r3').
 # Writes raw rocprofv3 output and bench JSONs under gpurun_out/<tag>/; copy the summaries into profiles/<tag>/.
 set -u
-TAG=${1:-r2}
+TAG=${1:-r3}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-python3 bench.py --steps 40 --warmup 4 > $OUT/bench_n1.json 2> $OUT/bench_n1.err
-python3 bench.py --steps 40 --warmup 4 --streams 1 --no-cpu-baseline > $OUT/bench_n1_streams1.json 2> $OUT/bench_n1_streams1.err
-python3 bench.py --steps 40 --warmup 4 --grid 449 --no-cpu-baseline > $OUT/bench_n1_grid449.json 2> $OUT/bench_n1_grid449.err
+python3 bench.py --steps 20 --warmup 5 > $OUT/bench_n1.json 2> $OUT/bench_n1.err   # the driver's command: all blocks (other configs as child runs)
+python3 bench.py --steps 40 --warmup 4 --streams 1 --no-cpu-baseline --no-other-configs > $OUT/bench_n1_streams1.json 2> $OUT/bench_n1_streams1.err
+python3 bench.py --steps 40 --warmup 4 --grid 449 --no-cpu-baseline --no-other-configs > $OUT/bench_n1_grid449.json 2> $OUT/bench_n1_grid449.err
 python3 bench.py --config speech --steps 5 --warmup 1 > $OUT/bench_n1_speech.json 2> $OUT/bench_n1_speech.err
 python3 bench.py --config stress --steps 5 --warmup 1 > $OUT/bench_n1_stress.json 2> $OUT/bench_n1_stress.err
 python3 bench.py --config xylo --steps 3 --warmup 1 > $OUT/bench_n1_xylo.json 2> $OUT/bench_n1_xylo.err
 # per-kernel times: serial steps so that every launch is timed alone
-rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace -o run -- python3 bench.py --steps 40 --warmup 4 --no-cpu-baseline --streams 1 > $OUT/trace.log 2>&1
+rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace -o run -- python3 bench.py --steps 40 --warmup 4 --no-cpu-baseline --no-other-configs --streams 1 > $OUT/trace.log 2>&1
+rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace_g449 -o run -- python3 bench.py --steps 20 --warmup 4 --grid 449 --no-cpu-baseline --no-other-configs --streams 1 > $OUT/trace_g449.log 2>&1
 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace_speech -o run -- python3 bench.py --config speech --steps 3 --warmup 1 --streams 1 > $OUT/trace_speech.log 2>&1
 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace_stress -o run -- python3 bench.py --config stress --steps 3 --warmup 1 --streams 1 > $OUT/trace_stress.log 2>&1
 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace_xylo -o run -- python3 bench.py --config xylo --steps 2 --warmup 1 --streams 1 > $OUT/trace_xylo.log 2>&1
@@ -22,8 +23,8 @@ rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace_xylo -o run -
 hipcc -O3 --offload-arch=gfx950 -o /tmp/store_bw tools/store_bw.hip > /dev/null 2>&1 && /tmp/store_bw > $OUT/store_bw.txt 2>&1
 # ablation: four MFMA k-steps for 14 channels instead of 3 + 2 channels on the vector ALU (same box, alternating)
 for i in 1 2; do
-  python3 bench.py --steps 40 --warmup 4 --no-cpu-baseline | tail -1 > $OUT/ab_kv_$i.json 2>/dev/null
-  MICLOC_WS_K4=1 python3 bench.py --steps 40 --warmup 4 --no-cpu-baseline | tail -1 > $OUT/ab_k4_$i.json 2>/dev/null
+  python3 bench.py --steps 40 --warmup 4 --no-cpu-baseline --no-other-configs | tail -1 > $OUT/ab_kv_$i.json 2>/dev/null
+  MICLOC_WS_K4=1 python3 bench.py --steps 40 --warmup 4 --no-cpu-baseline --no-other-configs | tail -1 > $OUT/ab_k4_$i.json 2>/dev/null
 done
 python3 - <<PY > $OUT/ablation_kstep.txt
 import json
@@ -36,12 +37,13 @@ rm -f $OUT/ab_kv_*.json $OUT/ab_k4_*.json
 # counters: separate passes, nothing but --pmc (+ kernel trace)
 for cfg in noisy stress speech xylo; do
   steps=6; [ $cfg = speech ] && steps=2; [ $cfg = xylo ] && steps=2
-  extra="--config $cfg --steps $steps --warmup 1 --no-cpu-baseline --streams 1"
+  extra="--config $cfg --steps $steps --warmup 1 --repeats 1 --no-cpu-baseline --no-other-configs --streams 1"
   rocprofv3 --output-format csv --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch_$cfg -o run -- python3 bench.py $extra > $OUT/pmc_fetch_$cfg.log 2>&1
   rocprofv3 --output-format csv --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write_$cfg -o run -- python3 bench.py $extra > $OUT/pmc_write_$cfg.log 2>&1
   rocprofv3 --output-format csv --kernel-trace --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE -d $OUT/pmc_sq_$cfg -o run -- python3 bench.py $extra > $OUT/pmc_sq_$cfg.log 2>&1
 done
 python3 tools/summarize_profiles.py trace $OUT/trace $OUT/kernel_trace_summary_by_shape.csv
+python3 tools/summarize_profiles.py trace $OUT/trace_g449 $OUT/kernel_trace_summary_grid449.csv
 python3 tools/summarize_profiles.py trace $OUT/trace_speech $OUT/kernel_trace_summary_speech.csv
 python3 tools/summarize_profiles.py trace $OUT/trace_stress $OUT/kernel_trace_summary_stress.csv
 python3 tools/summarize_profiles.py trace $OUT/trace_xylo $OUT/kernel_trace_summary_xylo.csv
@@ -51,5 +53,5 @@ python3 tools/summarize_profiles.py pmc $OUT/pmc_summary_speech.csv pmc_fetch=$O
 python3 tools/summarize_profiles.py pmc $OUT/pmc_summary_xylo.csv pmc_fetch=$OUT/pmc_fetch_xylo pmc_write=$OUT/pmc_write_xylo pmc_sq=$OUT/pmc_sq_xylo
 find $OUT/trace -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats_bench_steps40_streams1.csv \;
 # keep the merge-back small: drop the raw per-dispatch traces
-rm -rf $OUT/trace $OUT/trace_speech $OUT/trace_stress $OUT/trace_xylo $OUT/pmc_fetch_* $OUT/pmc_write_* $OUT/pmc_sq_*
+rm -rf $OUT/trace $OUT/trace_g449 $OUT/trace_speech $OUT/trace_stress $OUT/trace_xylo $OUT/pmc_fetch_* $OUT/pmc_write_* $OUT/pmc_sq_*
 ls -la $OUT
