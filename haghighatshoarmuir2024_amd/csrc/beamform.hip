@@ -1181,9 +1181,10 @@ __global__ __launch_bounds__(256 * S) void power_argmax_kernel(const double *__r
                                                                 int Gp, int G, int complex_pairs, int Ghp,
                                                                 double *__restrict__ power, int32_t *__restrict__ argmax)
 {
+    constexpr int U = S > 1 ? 4 : 1;  // blocks per slice and round: S * U block sums in flight between two barriers
     __shared__ double sv[256];
     __shared__ int si[256];
-    __shared__ double ps[S][256];
+    __shared__ double ps[U][S][256];
     const int b = blockIdx.x;
     const int col = threadIdx.x & 255;
     const int slice = threadIdx.x >> 8;
@@ -1194,27 +1195,34 @@ __global__ __launch_bounds__(256 * S) void power_argmax_kernel(const double *__r
     for (int g0 = 0; g0 < G; g0 += 256) {
         const int g = g0 + col;
         double total = 0.0;
-        for (int blk0 = 0; blk0 < nblocks; blk0 += S) {
-            const int blk = blk0 + slice;
-            double s = 0.0;
-            if (g < G && blk < nblocks) {
-                const int c_hi = (blk + 1) * PA_BLOCK < nchunks ? (blk + 1) * PA_BLOCK : nchunks;
-                for (int ch = blk * PA_BLOCK; ch < c_hi; ++ch) {
-                    s += pb[(size_t)ch * Gp + g];
-                    if (complex_pairs) s += pb[(size_t)ch * Gp + Ghp + g];
+        for (int blk0 = 0; blk0 < nblocks; blk0 += S * U) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int blk = blk0 + S * u + slice;
+                double s = 0.0;
+                if (g < G && blk < nblocks) {
+                    const int c_hi = (blk + 1) * PA_BLOCK < nchunks ? (blk + 1) * PA_BLOCK : nchunks;
+                    for (int ch = blk * PA_BLOCK; ch < c_hi; ++ch) {
+                        s += pb[(size_t)ch * Gp + g];
+                        if (complex_pairs) s += pb[(size_t)ch * Gp + Ghp + g];
+                    }
                 }
+                if (S > 1)
+                    ps[u][slice][col] = s;
+                else
+                    total += s;
             }
             if (S > 1) {
-                ps[slice][col] = s;
                 __syncthreads();
                 if (slice == 0) {
+                    // the block sums onto the total in ascending block order: blk0 + S u + v
 #pragma unroll
-                    for (int u = 0; u < S; ++u)
-                        if (blk0 + u < nblocks) total += ps[u][col];
+                    for (int u = 0; u < U; ++u)
+#pragma unroll
+                        for (int v = 0; v < S; ++v)
+                            if (blk0 + S * u + v < nblocks) total += ps[u][v][col];
                 }
                 __syncthreads();
-            } else {
-                total += s;
             }
         }
         if (slice == 0 && g < G) {
