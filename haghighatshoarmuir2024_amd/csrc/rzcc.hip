@@ -875,14 +875,14 @@ __global__ __launch_bounds__(448, SW == 64 ? 4 : 6) void bandpass_rzcc_fast_kern
                         const double v = *reinterpret_cast<const double *>(xt + (size_t)(je > 0 ? je - 1 : 0) * ROW * 8);
                         vev[u] = je > 0 ? v : prev;
                     }
+                    // unconditional stores: a lane without a (further) event writes into its next free slot without taking it (a whole
+                    // tile of appends is reserved, see the ring-space check) -- no exec-mask bookkeeping around six LDS writes
 #pragma unroll
                     for (int u = 0; u < DET_PF; ++u) {
-                        if (jev[u] >= 0) {
-                            const int slot = n & (RING - 1);
-                            ringP[slot][lane] = lfv[u] + tbase + jev[u] - 1;  // left + t - 1; position = word >> 1 (plateau midpoint)
-                            ringV[slot][lane] = vev[u];
-                            ++n;
-                        }
+                        const int slot = n & (RING - 1);
+                        ringP[slot][lane] = lfv[u] + tbase + jev[u] - 1;  // left + t - 1; position = word >> 1 (plateau midpoint)
+                        ringV[slot][lane] = vev[u];
+                        n += jev[u] >= 0 ? 1 : 0;
                     }
                 }
                 while (__any(Ew != 0u)) {

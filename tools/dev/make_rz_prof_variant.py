@@ -64,6 +64,15 @@ if "noresolve" in abl:
     s = s.replace("            resolve_cluster(s, e, stride, w, emit, word_at, val_at, sgn);", "            emit(lastpos);")
 if "nodetectloop" in abl:
     s = s.replace("                while (__any(Ew != 0u)) {\n                    if (Ew) {", "                while (false) {\n                    if (Ew) {")
+if "noA" in abl:   # detect: no fp64 compares (rise / fall words constant)
+    old = """                    Rw = (unsigned)add_lane_mask2((int)Rw, __builtin_amdgcn_fcmp(c[jj], pj, 2));  // ordered >
+                    Fw = (unsigned)add_lane_mask2((int)Fw, __builtin_amdgcn_fcmp(c[jj], pj, 4));  // ordered <"""
+    assert old in s
+    s = s.replace(old, "                    Rw = 0x1111u + (unsigned)(pj > 1e300); Fw = 0x4444u;")
+if "noC" in abl:   # detect: no events appended
+    old = "                Ew = livel ? Ew : 0u;"
+    assert old in s
+    s = s.replace(old, "                Ew = 0u;")
 if "size2" in abl:
     s = s.replace("""        if (e - s <= stride)
             emit(lastpos);
