@@ -251,16 +251,19 @@ __device__ __forceinline__ SynthWindow stage_template(const SynthArgs &a, const 
 }
 
 // synth_sample for a constant-DoA trial with the template window in LDS.  np.interp's bracket search (two data-dependent
-// loops, each trip a dependent read) becomes straight-line code: on the nominally uniform grid the guess j is off by at most
-// one row, so the rows j - 1 .. j + 2 are read together, the bracket q in {j - 1, j, j + 1} is selected and VERIFIED
+// loops, each trip a dependent read) becomes straight-line code: on the nominally uniform grid the truncating guess j is the
+// bracket or one row low, so the rows j .. j + 2 are read together, the bracket q in {j, j + 1} is selected and VERIFIED
 // (xp[q] <= x < xp[q + 1]); anything else -- the window's edge, the ends of the template, a grid that is not uniform -- takes
 // the original routine.  Same bracket, same arithmetic, same bits.
+// SIMPLE: one target, no per-sample gain (the throughput-mode sweep): no loop over targets
+template <bool SIMPLE>
 __device__ __forceinline__ double synth_sample_win(const SynthArgs &a, const SynthWindow &w, const double *__restrict__ dl, int b, int t, int m,
                                                    double x0, double shift)
 {
-    const double tt = w.wn ? w.xp[t - w.w0] : a.time[t];  // (wn == 0: nothing staged, every sample takes the global rows)
+    const double tt = w.xp[t - w.w0];  // (callers take this routine only with a staged window: an LDS-or-global select here becomes a FLAT load per sample)
     double acc = 0.0;
-    for (int k = 0; k < a.K; ++k) {
+    const int K = SIMPLE ? 1 : a.K;
+    for (int k = 0; k < K; ++k) {
         double d = dl[k * a.M + m];
         double x;
         if (a.mode == 0) {
@@ -273,29 +276,62 @@ __device__ __forceinline__ double synth_sample_win(const SynthArgs &a, const Syn
         int j = (int)((x - x0) * a.inv_step);
         j = j < 0 ? 0 : (j > a.T - 1 ? a.T - 1 : j);
         const int jl = j - w.w0;
-        const bool inside = w.wn > 0 && jl >= 1 && jl + 2 <= w.wn - 1 && !(x < x0);  // rows j - 1 .. j + 2 are staged (hence j + 2 <= T - 1)
-        const int jc = inside ? jl : 1;
-        const double xm = w.xp[jc - 1], xc = w.xp[jc], xn = w.xp[jc + 1], xnn = w.xp[jc + 2];
-        const double fm = w.fp[jc - 1], fc = w.fp[jc], fn = w.fp[jc + 1];
-        const double sm = w.sl[jc - 1], sc = w.sl[jc], sn = w.sl[jc + 1];
-        const bool down = xc > x, up = xn <= x;
-        const double xq = down ? xm : (up ? xn : xc);
-        const double xq1 = down ? xc : (up ? xnn : xn);
-        const double fq = down ? fm : (up ? fn : fc);
-        const double sq = down ? sm : (up ? sn : sc);
+        // The guess truncates, so when it is wrong it is one row LOW (on the sweep's grid 3 % of the samples: a microphone whose
+        // delay is zero sits exactly on the grid points) -- and a wave takes the slow routine if ANY lane needs it: rows j .. j + 2
+        // are read together, the bracket q = j or j + 1 selected and verified, its value and slope read from there.
+        const bool inside = jl >= 0 && jl + 2 <= w.wn - 1 && !(x < x0);  // rows j .. j + 2 staged (hence q + 1 <= T - 1)
+        const int jc = inside ? jl : 0;
+        const double xa = w.xp[jc], xb = w.xp[jc + 1], xc = w.xp[jc + 2];
+        const bool up = xb <= x;
+        const int q = jc + (up ? 1 : 0);
+        const double xq = up ? xb : xa, xq1 = up ? xc : xb;
+        const double fq = w.fp[q], sq = w.sl[q];
         double r = (xq == x) ? fq : sq * (x - xq) + fq;
         if (__builtin_expect(!(inside && xq <= x && x < xq1), 0)) r = interp_one(a.time, a.sig, a.slopes, a.T, x, x0, a.inv_step);
+        if (SIMPLE) return r;
         if (a.gain) r = a.gain[((size_t)b * a.K + k) * a.T + t] * r;
         acc = (a.K == 1) ? r : acc + r;
     }
     return acc;
 }
 
+// The straight-line part of synth_sample_win<true> alone: value, argument and whether the bracket verified.  Callers keep
+// several samples of a lane in flight (their LDS round trips overlap) and run the slow routine after the batch.
+__device__ __forceinline__ double synth_fast(const SynthArgs &a, const SynthWindow &w, const double *__restrict__ dl, int t, int m, double x0,
+                                             double shift, double &x_out, bool &ok)
+{
+    const double tt = w.xp[t - w.w0];
+    double d = dl[m];
+    double x;
+    if (a.mode == 0) {
+        if (a.shift) d = d - shift;
+        x = tt - d;
+        x = x < x0 ? x0 : x;
+    } else {
+        x = tt + d;
+    }
+    int j = (int)((x - x0) * a.inv_step);
+    j = j < 0 ? 0 : (j > a.T - 1 ? a.T - 1 : j);
+    const int jl = j - w.w0;
+    const bool inside = jl >= 0 && jl + 2 <= w.wn - 1 && !(x < x0);
+    const int jc = inside ? jl : 0;
+    const double xa = w.xp[jc], xb = w.xp[jc + 1], xc = w.xp[jc + 2];
+    const bool up = xb <= x;
+    const int q = jc + (up ? 1 : 0);
+    const double xq = up ? xb : xa, xq1 = up ? xc : xb;
+    const double fq = w.fp[q], sq = w.sl[q];
+    x_out = x;
+    ok = inside && xq <= x && x < xq1;
+    return (xq == x) ? fq : sq * (x - xq) + fq;
+}
+
 // CONST_DOA: the K x M delays of a trial do not depend on time (and fit the LDS table): template window + straight-line
 // interpolation.  Otherwise (moving DoAs) the general per-sample routine with its in-loop cos.
-template <bool CONST_DOA>
+template <int MODE>  // 0: moving DoAs; 1: constant DoAs; 2: constant DoAs, one target, no gain
 __global__ __launch_bounds__(256) void synth_sumsq_kernel(SynthArgs a, int nblk, double *__restrict__ partial)
 {
+    constexpr bool CONST_DOA = MODE >= 1;
+    constexpr bool SIMPLE = MODE == 2;
     __shared__ double dl[512];
     __shared__ double red[256];
     __shared__ double xs[CONST_DOA ? SF_WIN : 1], fs_[CONST_DOA ? SF_WIN : 1], ss[CONST_DOA ? SF_WIN : 1];
@@ -316,16 +352,41 @@ __global__ __launch_bounds__(256) void synth_sumsq_kernel(SynthArgs a, int nblk,
     FlatTM tm(lo + threadIdx.x, a.M);
     const int dt = 256 / a.M, dm = 256 % a.M;
     double acc = 0.0;
-    for (int i = threadIdx.x; i < AWGN_BLOCK; i += 256) {
-        if (lo + i < n) {
-            double v;
-            if constexpr (CONST_DOA)
-                v = synth_sample_win(a, w, dl, b, tm.t, tm.m, x0, shift);
-            else
-                v = synth_sample(a, nullptr, b, tm.t, tm.m, x0, shift);
-            acc = __builtin_fma(v, v, acc);
+    if (SIMPLE && w.wn > 0) {  // (workgroup-uniform)
+        // four samples of a lane in flight; the per-thread sum keeps its order
+        static_assert(AWGN_BLOCK % 1024 == 0, "batches of four strided samples");
+        for (int i = threadIdx.x; i < AWGN_BLOCK; i += 1024) {
+            double xv[4], rv[4];
+            bool okv[4], live[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                live[u] = lo + i + 256 * u < n;
+                okv[u] = true;
+                xv[u] = 0.0;
+                rv[u] = live[u] ? synth_fast(a, w, dl, tm.t, tm.m, x0, shift, xv[u], okv[u]) : 0.0;
+                tm.advance(dt, dm, a.M);
+            }
+            if (__any(!(okv[0] && okv[1] && okv[2] && okv[3]))) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (!okv[u]) rv[u] = interp_one(a.time, a.sig, a.slopes, a.T, xv[u], x0, a.inv_step);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (live[u]) acc = __builtin_fma(rv[u], rv[u], acc);
         }
-        tm.advance(dt, dm, a.M);
+    } else {
+        for (int i = threadIdx.x; i < AWGN_BLOCK; i += 256) {
+            if (lo + i < n) {
+                double v;
+                if (CONST_DOA && w.wn > 0)  // (workgroup-uniform)
+                    v = synth_sample_win<SIMPLE>(a, w, dl, b, tm.t, tm.m, x0, shift);
+                else
+                    v = synth_sample(a, CONST_DOA ? dl : nullptr, b, tm.t, tm.m, x0, shift);
+                acc = __builtin_fma(v, v, acc);
+            }
+            tm.advance(dt, dm, a.M);
+        }
     }
     red[threadIdx.x] = acc;
     __syncthreads();
@@ -336,10 +397,12 @@ __global__ __launch_bounds__(256) void synth_sumsq_kernel(SynthArgs a, int nblk,
     if (threadIdx.x == 0) partial[(size_t)b * nblk + blockIdx.x] = red[0];
 }
 
-template <bool CONST_DOA>
+template <int MODE>
 __global__ __launch_bounds__(256) void synth_awgn_kernel(SynthArgs a, const double *__restrict__ sigma, uint32_t k0, uint32_t k1, uint32_t sub,
                                                           const uint32_t *__restrict__ epoch, uint32_t trial0)
 {
+    constexpr bool CONST_DOA = MODE >= 1;
+    constexpr bool SIMPLE = MODE == 2;
     __shared__ double dl[512];
     __shared__ double xs[CONST_DOA ? SF_WIN : 1], fs_[CONST_DOA ? SF_WIN : 1], ss[CONST_DOA ? SF_WIN : 1];
     __shared__ int ired[256];
@@ -367,12 +430,12 @@ __global__ __launch_bounds__(256) void synth_awgn_kernel(SynthArgs a, const doub
         FlatTM t1 = tm;
         t1.advance(0, 1, a.M);
         double s0, s1 = 0.0;
-        if constexpr (CONST_DOA) {
-            s0 = synth_sample_win(a, w, dl, b, tm.t, tm.m, x0, shift);
-            if (e + 1 < n) s1 = synth_sample_win(a, w, dl, b, t1.t, t1.m, x0, shift);
+        if (CONST_DOA && w.wn > 0) {  // (workgroup-uniform)
+            s0 = synth_sample_win<SIMPLE>(a, w, dl, b, tm.t, tm.m, x0, shift);
+            if (e + 1 < n) s1 = synth_sample_win<SIMPLE>(a, w, dl, b, t1.t, t1.m, x0, shift);
         } else {
-            s0 = synth_sample(a, nullptr, b, tm.t, tm.m, x0, shift);
-            if (e + 1 < n) s1 = synth_sample(a, nullptr, b, t1.t, t1.m, x0, shift);
+            s0 = synth_sample(a, CONST_DOA ? dl : nullptr, b, tm.t, tm.m, x0, shift);
+            if (e + 1 < n) s1 = synth_sample(a, CONST_DOA ? dl : nullptr, b, t1.t, t1.m, x0, shift);
         }
         const Philox4 r = philox4x32_10((uint32_t)pair, ep, trial0 + (uint32_t)b, sub, k0, k1);
         const double u1 = u53_oc(r.v[0], r.v[1]);
@@ -412,17 +475,21 @@ hipError_t launch_synth_awgn(const SynthArgs &a_in, const double *snr_db, uint64
         hipLaunchKernelGGL(delay_table_kernel, dim3(a.B), dim3(256), 0, stream, a, table);
         a.delays = table;
     }
-    if (const_doa)
-        hipLaunchKernelGGL(synth_sumsq_kernel<true>, dim3(nblk, a.B), dim3(256), 0, stream, a, nblk, partial);
+    const int mode = !const_doa ? 0 : ((a.K == 1 && !a.gain) ? 2 : 1);
+#define SA_LAUNCH(MD)                                                                                                                      \
+    do {                                                                                                                                   \
+        hipLaunchKernelGGL(synth_sumsq_kernel<MD>, dim3(nblk, a.B), dim3(256), 0, stream, a, nblk, partial);                               \
+        hipLaunchKernelGGL(sigma_kernel, dim3(a.B), dim3(256), 0, stream, partial, nblk, n, snr_db, sg);                                   \
+        hipLaunchKernelGGL(synth_awgn_kernel<MD>, dim3(nblk, a.B), dim3(256), 0, stream, a, sg, (uint32_t)seed, (uint32_t)(seed >> 32),    \
+                           substream, epoch, trial0);                                                                                      \
+    } while (0)
+    if (mode == 2)
+        SA_LAUNCH(2);
+    else if (mode == 1)
+        SA_LAUNCH(1);
     else
-        hipLaunchKernelGGL(synth_sumsq_kernel<false>, dim3(nblk, a.B), dim3(256), 0, stream, a, nblk, partial);
-    hipLaunchKernelGGL(sigma_kernel, dim3(a.B), dim3(256), 0, stream, partial, nblk, n, snr_db, sg);
-    if (const_doa)
-        hipLaunchKernelGGL(synth_awgn_kernel<true>, dim3(nblk, a.B), dim3(256), 0, stream, a, sg, (uint32_t)seed, (uint32_t)(seed >> 32), substream,
-                           epoch, trial0);
-    else
-        hipLaunchKernelGGL(synth_awgn_kernel<false>, dim3(nblk, a.B), dim3(256), 0, stream, a, sg, (uint32_t)seed, (uint32_t)(seed >> 32), substream,
-                           epoch, trial0);
+        SA_LAUNCH(0);
+#undef SA_LAUNCH
     return hipGetLastError();
 }
 
