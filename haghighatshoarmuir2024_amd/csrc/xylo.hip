@@ -157,9 +157,8 @@ typedef short short2_t __attribute__((ext_vector_type(2)));
 typedef int int4_t __attribute__((ext_vector_type(4)));
 
 constexpr int XP_WAVES = 4;                  // 4 x 128 = 512 neurons per workgroup
-constexpr int XP_TT = 128;                   // time steps staged per LDS tile: 4 KB + 8 KB per wave = 28 KB for the sweep's 360
-                                             // neurons, so that 5 workgroups fit a CU and all 1100 trials are resident at once
-                                             // (with 256-step tiles 4 fit, and the 76 left over ran alone afterwards: +45 %)
+constexpr int XP_TT = 128;                   // time steps staged per LDS tile: 4 KB + 4 KB per wave = 16 KB for the sweep's 360
+                                             // neurons: all 1100 trials are resident at once (4-5 workgroups per CU)
 constexpr int XP_NEUR = XP_WAVES * 128;
 
 __device__ __forceinline__ short2_t xp_s2(int w) { return __builtin_bit_cast(short2_t, w); }
@@ -180,8 +179,8 @@ __global__ __launch_bounds__(XP_WAVES * 64) void xylo_lif_pk_kernel(const int8_t
                                                                      uint8_t *__restrict__ spikes_out, int *__restrict__ rate)
 {
     __shared__ __attribute__((aligned(16))) unsigned char tile[XP_TT][32 * KQ];
-    extern __shared__ __attribute__((aligned(16))) int cur_dyn[];  // [waves][2][4][64][4]: only the waves that hold neurons
-    int(*cur)[2][4][64][4] = reinterpret_cast<int(*)[2][4][64][4]>(cur_dyn);
+    extern __shared__ __attribute__((aligned(16))) int cur_dyn[];  // [waves][4][64][4]: only the waves that hold neurons
+    int(*cur)[4][64][4] = reinterpret_cast<int(*)[4][64][4]>(cur_dyn);
     int8_t *raw = reinterpret_cast<int8_t *>(cur_dyn);  // staging area for the raster bytes of a tile (between barriers)
     const int tid = threadIdx.x;
     const int nthreads = blockDim.x;
@@ -209,8 +208,11 @@ __global__ __launch_bounds__(XP_WAVES * 64) void xylo_lif_pk_kernel(const int8_t
     const int8_t *sb = raster + (size_t)b * T * tc;
     uint8_t *ob = WANT_OUT ? spikes_out + (size_t)b * T * N : nullptr;
 
-    // currents of 16 steps (tile16 `i` of the staged rows) -> the wave's LDS slice `buf`
-    auto produce = [&](int i, int buf) {
+    // currents of 16 steps (tile16 `i` of the staged rows) -> the wave's LDS slice.  ONE slice per wave (4 KB): the 16 steps of
+    // a tile are read into registers before the next tile's currents overwrite them (LDS operations of a wave execute in
+    // order), so a workgroup takes 16 instead of 28 KB and a CU that holds four or five of them still has room for a
+    // workgroup of the stages in front (the chunked encoder: 80 KB) -- with 28 KB the three stages of the sweep took turns.
+    auto produce = [&](int i) {
         int4_t acc[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[j] = int4_t{0, 0, 0, 0};
@@ -225,7 +227,7 @@ __global__ __launch_bounds__(XP_WAVES * 64) void xylo_lif_pk_kernel(const int8_t
             int4_t pk;
 #pragma unroll
             for (int r = 0; r < 4; ++r) pk[r] = (int)__builtin_amdgcn_perm((unsigned)acc[2 * k + 1][r], (unsigned)acc[2 * k][r], 0x05040100u);
-            *reinterpret_cast<int4_t *>(&cur[wv][buf][q][16 * k + lc][0]) = pk;  // steps 4 q .. 4 q + 3 of pair lane 16 k + lc
+            *reinterpret_cast<int4_t *>(&cur[wv][q][16 * k + lc][0]) = pk;  // steps 4 q .. 4 q + 3 of pair lane 16 k + lc
         }
     };
 
@@ -317,20 +319,29 @@ __global__ __launch_bounds__(XP_WAVES * 64) void xylo_lif_pk_kernel(const int8_t
         __syncthreads();
         const int ntile = (steps + 15) >> 4;
         cnt = short2_t{0, 0};
-        produce(0, 0);
+        produce(0);
         for (int i = 0; i < ntile; ++i) {
-            if (i + 1 < ntile) produce(i + 1, (i + 1) & 1);
             const int jn = steps - 16 * i < 16 ? steps - 16 * i : 16;
-            const int4_t *cw = reinterpret_cast<const int4_t *>(&cur[wv][i & 1][0][l][0]);
+            const int4_t *cw = reinterpret_cast<const int4_t *>(&cur[wv][0][l][0]);
+            int4_t in4[4];
+#pragma unroll
+            for (int t4 = 0; t4 < 4; ++t4) in4[t4] = cw[64 * t4];
+            if (i + 1 < ntile) produce(i + 1);  // (overwrites the slice: after the reads above, in program order)
             if (jn == 16) {
 #pragma unroll
                 for (int t4 = 0; t4 < 4; ++t4) {
-                    const int4_t in4 = cw[64 * t4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) step(in4[r], t0 + 16 * i + 4 * t4 + r);
+                    for (int r = 0; r < 4; ++r) step(in4[t4][r], t0 + 16 * i + 4 * t4 + r);
                 }
             } else {  // the last steps of the signal
-                for (int j = 0; j < jn; ++j) step(cur[wv][i & 1][j >> 2][l][j & 3], t0 + 16 * i + j);
+                for (int j = 0; j < jn; ++j) {
+                    int w_in = 0;
+#pragma unroll
+                    for (int t4 = 0; t4 < 4; ++t4)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) w_in = (j == 4 * t4 + r) ? in4[t4][r] : w_in;
+                    step(w_in, t0 + 16 * i + j);
+                }
             }
         }
         total0 += steps + cnt.x;
@@ -424,7 +435,7 @@ hipError_t launch_xylo_resident(const void *spikes_in, int ternary_C, int B, int
         const int nblk = xp_npad(N) / XP_NEUR;
         const int waves = nblk > 1 ? XP_WAVES : (N + 127) / 128;
         const dim3 pgrid(nblk, B), pblock(waves * 64);
-        size_t plds = (size_t)waves * 2 * 4 * 64 * 4 * sizeof(int);
+        size_t plds = (size_t)waves * 4 * 64 * 4 * sizeof(int);
         const size_t rawb = (size_t)XP_TT * ternary_C + 48;
         plds = plds > rawb ? plds : rawb;
         const int8_t *rs = reinterpret_cast<const int8_t *>(spikes_in);
