@@ -220,15 +220,15 @@ int micloc_plan_create(const micloc_config *cfg, micloc_plan **out)
         tp.kstep = stride2 ? 2 : 1;
         tp.klo = klo;
         const int ntaps = (khi - klo) / tp.kstep + 1;
-        const int U = 8 / tp.kstep;
+        const int U = STHT_R / tp.kstep;
         tp.ngroups = (ntaps + U - 1) / U;
         compact.assign((size_t)(tp.ngroups + 1) * U, 0.0);  // +1 all-zero group: the kernel prefetches one group ahead
         for (int j = 0; j < ntaps; ++j) compact[j] = cfg->stht_kernel[klo + j * tp.kstep];
     }
     {
-        const int U = 8 / tp.kstep;
+        const int U = STHT_R / tp.kstep;
         const int kmax = tp.klo + (tp.ngroups * U > 0 ? (tp.ngroups * U - 1) * tp.kstep : 0);
-        tp.halo = tp.klo + 8 * ((kmax - tp.klo + 7) / 8);
+        tp.halo = tp.klo + STHT_R * ((kmax - tp.klo + STHT_R - 1) / STHT_R);
         tp.shift = L / 2;
     }
     if (stht_lds_bytes(tp, p->M) > 160 * 1024) {

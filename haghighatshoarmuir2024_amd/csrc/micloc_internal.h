@@ -9,16 +9,17 @@
 namespace micloc {
 
 // ---- STHT ---------------------------------------------------------------------------------------
-constexpr int STHT_TILE = 512;  // outputs per wave-task: 64 lanes x 8 consecutive samples
-constexpr int STHT_MAX_MB = 8;  // mics per block (one wave each)
+constexpr int STHT_R = 8;                // consecutive output samples per lane (register window; groups of STHT_R delays)
+constexpr int STHT_TILE = 64 * STHT_R;   // outputs per wave-task
+constexpr int STHT_MAX_MB = 8;           // mics per block (one wave each)
 
 struct SthtTaps {
     // compact tap table on device: taps[j] = ker[klo + j * kstep], zero padded to a multiple of 8/kstep
     const double *taps;
-    int ngroups;  // number of groups of (8 / kstep) taps
+    int ngroups;  // number of groups of (STHT_R / kstep) taps
     int klo;      // delay of the first tap
     int kstep;    // 1 or 2
-    int halo;     // Hh: samples staged before the tile; Hh == klo (mod 8), Hh >= largest delay
+    int halo;     // Hh: samples staged before the tile; Hh == klo (mod STHT_R), Hh >= largest delay
     int shift;    // L / 2 (np.roll amount)
 };
 

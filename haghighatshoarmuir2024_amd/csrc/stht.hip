@@ -2,12 +2,17 @@
 // kernel (reference: micloc/snn_beamformer.py:325-327, micloc/beamformer.py:281-283).
 //
 // Mapping (wave64): one block = one trial x one 512-sample time tile x up to 8 microphones; each wave
-// owns one microphone, each lane 8 consecutive output samples (8 independent fp64 FMA chains).  The
+// owns one microphone, each lane R = 8 consecutive output samples (8 independent fp64 FMA chains).  The
 // (tile + halo) x mics frame block is read once from HBM with coalesced loads ([t][mic] rows are
-// contiguous) and transposed into per-microphone LDS rows.  The per-lane 8-sample sliding window
-// lives in registers; every tap costs one 16-byte LDS read (kstep 2) and 8 v_fma_f64, the tap value
-// comes from a scalar load.  Rows are skewed by 16 B every 64 B so the 64-B lane stride is
+// contiguous) and transposed into per-microphone LDS rows.  The per-lane R-sample sliding window
+// lives in registers; every tap costs one 16-byte LDS read (kstep 2) and R v_fma_f64, the tap value
+// comes from a scalar load.  Rows are skewed by 16 B every R doubles so the lane stride is
 // conflict-free for ds_read_b128.
+// R is a compile-time constant (STHT_R).  R = 16 (half the LDS reads per FMA: with R = 8 the 64-lane b128 read of a tap
+// holds the CU's LDS pipe for 8 cycles against 32 cycles of FMAs per wave, 14 waves on 4 SIMDs) was built and measured in
+// round 3: 1024-sample tiles need 13.7 KB of LDS per microphone row, so a block holds 4 (2) microphones and a CU 8 (10)
+// waves instead of 14 -- 0.49 (0.53) ms against 0.44-0.46 ms on the sweep shape.  The kernel is bound by how well staging,
+// FIR and stores of co-resident blocks overlap, not by the LDS pipe.
 //
 // Arithmetic contract (== oracle/micloc_oracle.c oracle_stht): acc = +0; for taps k ascending:
 // acc = fma(ker[k], x[t-k], acc); exact-zero taps contribute nothing (skipped when every second tap
@@ -16,7 +21,9 @@
 
 namespace micloc {
 
-__device__ __forceinline__ int skew(int q) { return q + 2 * (q >> 3); }
+constexpr int R = STHT_R;
+static_assert(R == 8 || R == 16, "window / skew period");
+__device__ __forceinline__ int skew(int q) { return q + 2 * (q / R); }
 
 template <int S, bool WRITE_RE>
 __global__ __launch_bounds__(64 * STHT_MAX_MB) void stht_kernel(const double *__restrict__ x,
@@ -26,7 +33,7 @@ __global__ __launch_bounds__(64 * STHT_MAX_MB) void stht_kernel(const double *__
                                                                  int Ts, int MB, int rowstride)
 {
     extern __shared__ __attribute__((aligned(16))) double Xs[];
-    constexpr int U = 8 / S;
+    constexpr int U = R / S;
     const int tid = threadIdx.x;
     // XCD-aware placement (speed only, never correctness): workgroups are dealt round-robin over the 8 XCDs, each with
     // its own 4 MB L2, and consecutive time tiles of a (trial, mic group) row share `halo` input samples -- half of
@@ -47,12 +54,12 @@ __global__ __launch_bounds__(64 * STHT_MAX_MB) void stht_kernel(const double *__
     const int t0 = tile_x * STHT_TILE;
     const int m0 = (row_yz % gridDim.y) * MB;
     const int b = row_yz / gridDim.y;
-    const int N = 8 + halo + STHT_TILE;
-    const int tq0 = t0 - halo - 8;  // global time of logical LDS index 0
+    const int N = R + halo + STHT_TILE;
+    const int tq0 = t0 - halo - R;  // global time of logical LDS index 0
     const double *xb = x + (size_t)b * T * M;
 
     // ---- stage (tile + halo) x MB mics, transposed to per-mic rows, zero outside [0, T) ----------
-    // Loads are issued in one batch of 16 per thread (clamped addresses, so unconditional) before any LDS write: the
+    // Loads are issued in one batch of NB per thread (clamped addresses, so unconditional) before any LDS write: the
     // block pays the HBM latency once per tile instead of once per row.
     {
         const int mm = tid % MB;
@@ -60,10 +67,10 @@ __global__ __launch_bounds__(64 * STHT_MAX_MB) void stht_kernel(const double *__
         const int mc = m < M ? m : M - 1;
         double *row = Xs + (size_t)mm * rowstride;
         const int q0 = tid / MB;
-        constexpr int NB = 16;  // loads in flight per thread: the whole tile + halo of the default shape in one batch
+        constexpr int NB = R == 8 ? 16 : 24;  // loads in flight per thread: the whole tile + halo of the default shape in one batch
         if (m < M && tq0 >= 0 && tq0 + N <= T && N <= 64 * NB) {
             // interior tile (workgroup-uniform apart from m < M): no clamping, constant strides on both sides.
-            // skew(q0 + 64 i) = skew(q0) + 80 i because 64 is a multiple of 8.
+            // skew(q0 + 64 i) = skew(q0) + (64 + 128 / R) i because 64 is a multiple of R.
             const double *src = xb + (size_t)(tq0 + q0) * M + m;
             double *dst = row + skew(q0);
             double v[NB];
@@ -74,7 +81,7 @@ __global__ __launch_bounds__(64 * STHT_MAX_MB) void stht_kernel(const double *__
             }
 #pragma unroll
             for (int i = 0; i < NB; ++i)
-                if (q0 + 64 * i < N) dst[80 * i] = v[i];
+                if (q0 + 64 * i < N) dst[(64 + 128 / R) * i] = v[i];
         } else {
             for (int qb = q0; qb < N; qb += 64 * NB) {
                 double v[NB];
@@ -98,19 +105,19 @@ __global__ __launch_bounds__(64 * STHT_MAX_MB) void stht_kernel(const double *__
     const int wv = tid >> 6;
     const int lane = tid & 63;
     const int m = m0 + wv;
-    const int tb = t0 + lane * 8;
+    const int tb = t0 + lane * R;
     if (m >= M || tb >= T) return;
     const double *row = Xs + (size_t)wv * rowstride;
 
     // ---- quadrature: FIR over the sliding register window -------------------------------------------
-    double acc[8];
-    double w[8];
+    double acc[R];
+    double w[R];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) acc[r] = 0.0;
-    int j = lane * 8 + (halo + 8 - klo);  // logical index of x[tb - klo]; j % 8 == 0
+    for (int r = 0; r < R; ++r) acc[r] = 0.0;
+    int j = lane * R + (halo + R - klo);  // logical index of x[tb - klo]; j % R == 0
     int pj = skew(j);
 #pragma unroll
-    for (int r = 0; r < 8; r += 2) {
+    for (int r = 0; r < R; r += 2) {
         const double2 v2 = *reinterpret_cast<const double2 *>(row + pj + r);
         w[r] = v2.x;
         w[r + 1] = v2.y;
@@ -121,7 +128,7 @@ __global__ __launch_bounds__(64 * STHT_MAX_MB) void stht_kernel(const double *__
 #pragma unroll
     for (int u = 0; u < U; ++u) tpn[u] = taps[u];
     for (int g = 0; g < ngroups; ++g) {
-        pj -= 10;  // skew(j - 8)
+        pj -= R + 2;  // skew(j - R)
         double tp[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) tp[u] = tpn[u];
@@ -132,35 +139,36 @@ __global__ __launch_bounds__(64 * STHT_MAX_MB) void stht_kernel(const double *__
             double nx[S];
             if (S == 2) {
                 // pj and the offset are even and rows are 16-byte aligned: one ds_read_b128
-                const double2 v2 = *reinterpret_cast<const double2 *>(row + pj + (8 - (u + 1) * S));
+                const double2 v2 = *reinterpret_cast<const double2 *>(row + pj + (R - (u + 1) * S));
                 nx[0] = v2.x;
                 nx[S - 1] = v2.y;
             } else {
 #pragma unroll
-                for (int e = 0; e < S; ++e) nx[e] = row[pj + (8 - (u + 1) * S + e)];
+                for (int e = 0; e < S; ++e) nx[e] = row[pj + (R - (u + 1) * S + e)];
             }
 #pragma unroll
-            for (int r = 0; r < 8; ++r) acc[r] = __builtin_fma(tp[u], w[(r - u * S) & 7], acc[r]);
+            for (int r = 0; r < R; ++r) acc[r] = __builtin_fma(tp[u], w[(r - u * S) & (R - 1)], acc[r]);
 #pragma unroll
-            for (int e = 0; e < S; ++e) w[(8 - (u + 1) * S + e) & 7] = nx[e];
+            for (int e = 0; e < S; ++e) w[(R - (u + 1) * S + e) & (R - 1)] = nx[e];
         }
     }
 
     const int C = 2 * M;
     double *him = h + ((size_t)b * C + M + m) * Ts + tb;
+    // (rows are padded to a multiple of 8 samples, a lane covers 16: its second half may lie beyond the row)
 #pragma unroll
-    for (int r = 0; r < 8; r += 2) {
+    for (int r = 0; r < R; r += 2) {
         double2 v2 = make_double2(acc[r], acc[r + 1]);
-        *reinterpret_cast<double2 *>(him + r) = v2;
+        if (tb + r < Ts) *reinterpret_cast<double2 *>(him + r) = v2;
     }
 
     // ---- in-phase: np.roll(x, shift, axis=0) --------------------------------------------------------
     // (skipped in the fused pipelines: the band-pass kernel's loader reads the rolled input frames itself)
     if (!WRITE_RE) return;
     const int sh = shift % T;
-    double re[8];
+    double re[R];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
+    for (int r = 0; r < R; ++r) {
         const int t = tb + r;
         double v = 0.0;
         if (t < T) {
@@ -176,16 +184,16 @@ __global__ __launch_bounds__(64 * STHT_MAX_MB) void stht_kernel(const double *__
     }
     double *hre = h + ((size_t)b * C + m) * Ts + tb;
 #pragma unroll
-    for (int r = 0; r < 8; r += 2) {
+    for (int r = 0; r < R; r += 2) {
         double2 v2 = make_double2(re[r], re[r + 1]);
-        *reinterpret_cast<double2 *>(hre + r) = v2;
+        if (tb + r < Ts) *reinterpret_cast<double2 *>(hre + r) = v2;
     }
 }
 
 static int stht_rowstride(const SthtTaps &tp)
 {
-    const int N = 8 + tp.halo + STHT_TILE;
-    int np = N + 2 * ((N + 7) >> 3) + 2;
+    const int N = STHT_R + tp.halo + STHT_TILE;
+    int np = N + 2 * ((N + STHT_R - 1) / STHT_R) + 2;
     np = (np + 1) & ~1;  // keep rows 16-byte aligned
     return np + 2;       // +16 B so consecutive mic rows start on different bank groups
 }
