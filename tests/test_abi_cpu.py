@@ -77,6 +77,40 @@ def test_round2_entry_points_validate_before_touching_the_device():
     assert lib.micloc_lif_beamform_workspace_bytes(None, 1, 10) == 0
 
 
+def test_round3_entry_points_validate_before_touching_the_device():
+    """Round-3 entry points: bad arguments are rejected on the host, size queries are pure functions."""
+    lib = _lib.load()
+    vp = ctypes.c_void_p
+    one = vp(256)
+    # Gram matrix of a planar signal
+    assert lib.micloc_planar_gram_workspace_bytes(0, 100, 14, 0) == 0 and lib.micloc_planar_gram_workspace_bytes(1, 100, 14, 100) == 0
+    assert lib.micloc_planar_gram_workspace_bytes(2, 4799, 14, 480) >= 2 * 3 * 256 * 8  # 2 trials x 3 chunks x one 16 x 16 tile
+    assert lib.micloc_planar_gram_workspace_bytes(1, 2048, 128, 0) == 36 * 256 * 8       # 8 channel tiles: 36 tile pairs
+    assert lib.micloc_planar_gram_f64(None, 1, 14, 100, 104, 0, 1, one, one, 1 << 20, None) == _lib.MICLOC_ERR_INVALID
+    assert lib.micloc_planar_gram_f64(one, 1, 129, 100, 104, 0, 1, one, one, 1 << 20, None) == _lib.MICLOC_ERR_INVALID  # more than 128 channels
+    assert lib.micloc_planar_gram_f64(one, 1, 14, 100, 96, 0, 1, one, one, 1 << 20, None) == _lib.MICLOC_ERR_SHAPE      # row stride < T
+    assert lib.micloc_planar_gram_f64(one, 1, 14, 100, 104, 0, 1, one, one, 16, None) == _lib.MICLOC_ERR_WORKSPACE
+    # fused synthesis + noise
+    assert lib.micloc_synth_awgn_workspace_bytes(0, 10, 7, 1) == 0
+    assert lib.micloc_synth_awgn_workspace_bytes(3, 4799, 7, 2) >= lib.micloc_awgn_workspace_bytes(3, 4799, 7) + 3 * 2 * 7 * 8
+    assert lib.micloc_synth_awgn_f64(None, one, 0, 0, None, 0, one, 1 << 20, None) == _lib.MICLOC_ERR_INVALID
+    args = _lib.MiclocSynthArgs()
+    args.time = args.sig = args.slopes = args.x = args.doa = args.r_vec = args.theta_vec = 256
+    args.T, args.B, args.K, args.M, args.fs, args.mode, args.speed = 100, 1, 1, 7, 48000.0, 0, 340.0
+    assert lib.micloc_synth_awgn_f64(ctypes.byref(args), None, 0, 0, None, 0, one, 1 << 20, None) == _lib.MICLOC_ERR_INVALID  # no SNR
+    assert lib.micloc_synth_awgn_f64(ctypes.byref(args), one, 0, 0, None, 0, one, 16, None) == _lib.MICLOC_ERR_WORKSPACE
+    assert lib.micloc_synth_awgn_f64(ctypes.byref(args), one, 0, 0, None, 0xFFFFFFFF, one, 1 << 20, None) == _lib.MICLOC_ERR_INVALID  # trial ids
+    # the reserved trial word of the uniform generator / the pair index is one counter word
+    assert lib.micloc_awgn_f64(one, 2, 10, 7, one, None, 0, 0, None, 0xFFFFFFFE, one, 1 << 20, None) == _lib.MICLOC_ERR_INVALID
+    # streaming localisation
+    assert lib.micloc_stream_localize_state_bytes(None, 4) == 0 and lib.micloc_stream_localize_workspace_bytes(None, 4, 512) == 0
+    assert lib.micloc_stream_chunk_frames(None) == _lib.MICLOC_ERR_NOT_SET
+    assert lib.micloc_stream_encode_window_f64(None, one, 1, 16, 16, 0, 1, 0, one, 512, 0, one, 1 << 20, None) == _lib.MICLOC_ERR_INVALID
+    assert lib.micloc_stream_localize_f64(None, one, one, 1 << 20, one, 1, 512, 0, 16, 1, 0, None, None, one, 1 << 20, None) == _lib.MICLOC_ERR_INVALID
+    assert lib.micloc_stream_window_shift(None, one, one, vp(512), 1, 512, 0, 256, None) == _lib.MICLOC_ERR_INVALID
+    assert lib.micloc_stream_localize_status(None, None, None) == _lib.MICLOC_ERR_INVALID
+
+
 def test_no_silent_cpu_fallback():
     import torch
 
