@@ -188,3 +188,31 @@ def test_stream_window_lag_is_reported(cfg2):
         s.push(x[:, t : t + 800, :])
     with pytest.raises(_lib.MiclocError, match="window"):
         s.finish()
+
+
+@pytest.mark.parametrize("num_mic,G", [(16, 75), (40, 130)])
+def test_stream_other_kernel_families(num_mic, G):
+    """More than 8 microphones take the other LIF + beamforming kernels (time-stationary: 512-frame chunks; slab: more than 64
+    channels): the device-side chunk range and the window's trial stride reach them too -- streamed == one-shot, bit for bit."""
+    from micloc.array_geometry import CircularArray
+    from micloc.snn_beamformer import SNNBeamformer
+    from haghighatshoarmuir2024_amd.streaming import StreamingLocalizer
+
+    tau = 1 / (2 * np.pi * 2000)
+    bf = SNNBeamformer(CircularArray(0.1, num_mic), 10e-3, [1000.0, 2000.0], np.asarray([tau, tau]), bipolar_spikes=True, fs=48_000)
+    rng = np.random.RandomState(num_mic)
+    W = rng.randn(2 * num_mic, G)
+    W /= np.linalg.norm(W, axis=0, keepdims=True)
+    T = 6000
+    x = rng.randn(3, T, num_mic)
+    one = bf.localize_batch(W, x)
+    L2 = len(bf.kernel) // 2
+    for tiles in ([T], [1600, 1600, 1600, 1200], [2048, 512, 3440]):
+        s = StreamingLocalizer(bf, W, 3, T, wrap_tail=x[:, T - L2 :, :], max_tile=max(tiles), lag_frames=2048)
+        t = 0
+        for n in tiles:
+            s.push(x[:, t : t + n, :])
+            t += n
+        out = s.finish()
+        np.testing.assert_array_equal(out["power"].cpu().numpy(), one["power"].cpu().numpy(), err_msg=f"tiles={tiles}")
+        np.testing.assert_array_equal(out["argmax"].cpu().numpy(), one["argmax"].cpu().numpy())
