@@ -881,7 +881,7 @@ int micloc_awgn_f64(double *x, int B, int T, int M, const double *snr_db, const 
     if (((size_t)T * M + 1) / 2 > 0xFFFFFFFFull || (uint64_t)first_trial + (uint64_t)B > 0xFFFFFFFFull) return MICLOC_ERR_INVALID;
     if (!sigma && bad_ws(ws, ws_bytes, awgn_ws_bytes(B, (size_t)T * M))) return MICLOC_ERR_WORKSPACE;
     DeviceGuard guard(device_of(x));
-    HIP_TRY(launch_awgn(x, B, (size_t)T * M, snr_db, sigma, seed, substream, epoch, first_trial, ws, (hipStream_t)stream));
+    HIP_TRY(launch_awgn(x, B, (size_t)T * M, M, snr_db, sigma, seed, substream, epoch, first_trial, ws, (hipStream_t)stream));
     return MICLOC_OK;
 }
 

@@ -149,7 +149,7 @@ hipError_t launch_uniform(double *out, size_t n, uint64_t seed, uint32_t substre
                           hipStream_t stream);
 hipError_t launch_counter_add(uint32_t *counter, uint32_t inc, hipStream_t stream);
 size_t awgn_ws_bytes(int B, size_t n);
-hipError_t launch_awgn(double *x, int B, size_t n, const double *snr_db, const double *sigma, uint64_t seed, uint32_t substream,
+hipError_t launch_awgn(double *x, int B, size_t n, int M, const double *snr_db, const double *sigma, uint64_t seed, uint32_t substream,
                        const uint32_t *epoch, uint32_t trial0, void *ws, hipStream_t stream);
 
 // fused: x = synth(args) + sigma N(0, 1) without ever storing the noise-free signal (same bits as synth_targets + awgn)

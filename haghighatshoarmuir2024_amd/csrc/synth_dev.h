@@ -4,18 +4,30 @@
 
 namespace micloc {
 
-__device__ __forceinline__ double interp_one(const double *__restrict__ xp, const double *__restrict__ fp,
-                                             const double *__restrict__ slopes, int T, double x, double x0, double inv_step)
+// np.interp's bracket for x >= xp[0]: the largest j with xp[j] <= x (T - 1 when x >= xp[T-1]); the guess from the (nominally)
+// uniform grid is corrected against the stored grid
+__device__ __forceinline__ int interp_bracket(const double *__restrict__ xp, int T, double x, double x0, double inv_step)
 {
-    if (x < x0) return fp[0];  // np.interp: left = fp[0]
-    // bracket: guess from the (nominally) uniform grid, then correct against the stored grid
     int j = (int)((x - x0) * inv_step);
     j = j < 0 ? 0 : (j > T - 1 ? T - 1 : j);
     while (j > 0 && xp[j] > x) --j;
     while (j < T - 1 && xp[j + 1] <= x) ++j;
+    return j;
+}
+
+__device__ __forceinline__ double interp_at(const double *__restrict__ xp, const double *__restrict__ fp, const double *__restrict__ slopes, int T,
+                                            double x, int j)
+{
     if (j == T - 1) return fp[j];  // x >= xp[T-1]: right = fp[T-1]
     const double xj = xp[j];
     return (xj == x) ? fp[j] : slopes[j] * (x - xj) + fp[j];
+}
+
+__device__ __forceinline__ double interp_one(const double *__restrict__ xp, const double *__restrict__ fp,
+                                             const double *__restrict__ slopes, int T, double x, double x0, double inv_step)
+{
+    if (x < x0) return fp[0];  // np.interp: left = fp[0]
+    return interp_at(xp, fp, slopes, T, x, interp_bracket(xp, T, x, x0, inv_step));
 }
 
 __device__ __forceinline__ double mic_delay(const SynthArgs &a, int b, int k, int t, int m)

@@ -153,3 +153,38 @@ def test_fused_synthesis_and_noise_equals_the_two_calls(geo):
             runtime.awgn_(want, snr_db=snr, seed=99, substream=4, first_trial=17, epoch=ep)
             got = runtime.synth_awgn(tpl, snr_db=snr, seed=99, substream=4, first_trial=17, epoch=ep, **kw)
             assert torch.equal(got, want), (T, B, kw["mode"], sorted(kw))
+
+
+def test_fused_synthesis_other_shapes():
+    """The fused kernels' wave-per-microphone order (csrc/rng.hip TimeMap) on shapes the sweep does not have: fewer microphones
+    than waves, more than a wave, more than a workgroup; recordings shorter than one 64-row chunk; an array so wide that the
+    template window does not fit LDS; a jittered (non-uniform) time grid, where the constant row offset does not hold and every
+    sample is searched; two constant-DoA targets with gains.  Always the bits of synth_targets + awgn_."""
+    import torch
+
+    from haghighatshoarmuir2024_amd import runtime
+    from micloc.array_geometry import CenterCircularArray
+
+    fs = 48_000
+    rng = np.random.RandomState(5)
+    ep = torch.full((1,), 9, dtype=torch.int32, device="cuda")
+    shapes = [(4.5e-2, 2, 2500, 3), (4.5e-2, 3, 4799, 2), (4.5e-2, 64, 700, 2), (4.5e-2, 300, 300, 2), (4.5e-2, 7, 5, 3), (4.5e-2, 7, 63, 2),
+              (3.0, 7, 3000, 2), (0.5, 16, 2100, 2)]
+    for radius, M, T, B in shapes:
+        geo = CenterCircularArray(radius, M)
+        g = runtime.Geometry(geo)
+        snr = np.linspace(0, 10, B)
+        doa = rng.rand(B, 1) * 2 * np.pi
+        for jitter in (0.0, 0.3):
+            t = (np.arange(T) + jitter * (rng.rand(T) - 0.5)) / fs
+            tpl = runtime.Template(t, np.sin(2 * np.pi * 900 * t) + 0.1 * rng.randn(T), fs)
+            cases = [dict(mode="apply_to_template", doa=doa, geometry=g, shift=runtime.delay_min(torch.from_numpy(doa).cuda(), g)),
+                     dict(mode="signal_from_template", doa=doa, geometry=g)]
+            if M <= 64:
+                doa2 = rng.rand(B, 2) * 2 * np.pi
+                cases.append(dict(mode="signal_from_template", doa=doa2, geometry=g, gain=rng.rand(B, 2, T)))
+            for kw in cases:
+                want = runtime.synth_targets(tpl, **kw)
+                runtime.awgn_(want, snr_db=snr, seed=5, substream=2, first_trial=3, epoch=ep)
+                got = runtime.synth_awgn(tpl, snr_db=snr, seed=5, substream=2, first_trial=3, epoch=ep, **kw)
+                assert torch.equal(got, want), (radius, M, T, B, jitter, kw["mode"], sorted(kw))
