@@ -161,23 +161,16 @@ def build_workload(args, rank, device):
     beamf = SNNBeamformer(geometry=geometry, kernel_duration=10.0e-3, tau_vec=np.asarray([tau, tau]), freq_range=freq_range, fs=fs,
                           bipolar_spikes=True, device=device)
     doa_list = np.linspace(-np.pi, np.pi, G)
-    if cfg == "stress":
-        # the reference's own design (snn_beamformer.py:82-211) for the 64-mic array: per-DoA chain and 128 x 128 membrane
-        # covariance on the device (lif_cov_wide_kernel), the singular vectors by host LAPACK like the reference (the batched
-        # Jacobi kernel serves up to 16 microphones); a one-off cost outside the timed region
-        torch.cuda.synchronize()
-        t_design = time.perf_counter()
-        bf_mat = beamf.design_from_template(chirp_template(fs, freq_range), doa_list, svd="host", device_synthesis=True, doa_batch=48)
-        torch.cuda.synchronize()
-        t_design = time.perf_counter() - t_design
-    else:
-        # the whole design on the device: delayed templates, chain, covariance, batched Jacobi SVD (micloc_design_vectors_f64)
-        beamf.design_from_template(chirp_template(fs, freq_range), doa_list[:8], svd="device")  # warm-up (allocations, module load)
-        torch.cuda.synchronize()
-        t_design = time.perf_counter()
-        bf_mat = beamf.design_from_template(chirp_template(fs, freq_range), doa_list, svd="device")
-        torch.cuda.synchronize()
-        t_design = time.perf_counter() - t_design
+    # the whole design on the device: delayed templates, chain, membrane covariance (lif_cov_kernel / lif_cov_wide_kernel), batched
+    # Jacobi decompositions (micloc_design_vectors_f64: two-sided up to 16 microphones, one-sided up to 64 -- config 5's 128 x 128
+    # matrices); a one-off cost outside the timed region
+    kw = dict(svd="device", doa_batch=48) if cfg == "stress" else dict(svd="device")
+    beamf.design_from_template(chirp_template(fs, freq_range), doa_list[:8], **kw)  # warm-up (allocations, module load)
+    torch.cuda.synchronize()
+    t_design = time.perf_counter()
+    bf_mat = beamf.design_from_template(chirp_template(fs, freq_range), doa_list, **kw)
+    torch.cuda.synchronize()
+    t_design = time.perf_counter() - t_design
 
     # test signals (target_snn_localization.py:435-455 / :148-154,213-245): synthetic, generated here, noise drawn on the device
     if cfg == "speech":
@@ -895,12 +888,11 @@ def run(args):
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": f"{names[args.config]}: {M}-mic, {wl['fs'] // 1000} kHz, T={T}, {B} trials/GPU/step, "
-                                   f"{G}-DoA grid, bipolar RZCC" + (", bf_mat designed on device from the 1 s chirp" if args.config != "stress" else ", bf_mat designed from the 1 s chirp (device chain + covariance, host LAPACK SVD)"),
+                                   f"{G}-DoA grid, bipolar RZCC, bf_mat designed on device from the 1 s chirp",
                        "trials_per_gpu": B, "frames_per_trial": T, "num_mic": M, "num_doa": G, "mic_samples_per_s": value * M,
                        "parallelism": f"trial-sharded x{group_size}", "hip_streams": nstreams, "hip_graphs": True,
                        "design_from_template_seconds": wl["design_seconds"],
-                       "design_note": ("bf_mat from the 1 s chirp for all G DoAs, entirely on the device (reference: 24.8 s for 449 DoAs on 8 vCPUs, SURVEY 6)"
-                                       if args.config != "stress" else "bf_mat from the 1 s chirp for all G DoAs: per-DoA chain + 128 x 128 covariance on the device, SVD by host LAPACK")},
+                       "design_note": "bf_mat from the 1 s chirp for all G DoAs, entirely on the device (reference: 24.8 s for 449 DoAs on 8 vCPUs, SURVEY 6)"},
             "mae_deg_per_snr": [float(v) for v in (mae * 180 / np.pi).cpu().numpy()],
             "value_e2e": e2e["value"],
             "e2e": e2e,

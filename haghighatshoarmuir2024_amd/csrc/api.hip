@@ -951,7 +951,7 @@ int micloc_design_vectors_f64(const double *cov, int n_doa, int C, int bipolar, 
                               void *stream)
 {
     if (!cov || !bf_mat || n_doa < 1 || C < 2 || G < 1 || g0 < 0 || g0 + n_doa > G || !(rel_prec > 0.0)) return MICLOC_ERR_INVALID;
-    if (C > 32 || (bipolar && (C & 1))) return MICLOC_ERR_SHAPE;
+    if (C > 128 || (C > 32 && (C & 1)) || (bipolar && (C & 1))) return MICLOC_ERR_SHAPE;  // (the one-sided kernel pairs all columns: even C)
     DeviceGuard guard(device_of(bf_mat));
     HIP_TRY(launch_design_vec(cov, n_doa, C, bipolar ? 1 : 0, rel_prec, bf_mat, G, g0, (hipStream_t)stream));
     return MICLOC_OK;

@@ -384,7 +384,7 @@ hipError_t launch_lif_cov(const NeuronTab &nt, const int8_t *spikes, int B, int 
         case 1: return launch_cov_ct<1>(nt, spikes, B, T, C, t_start, partial, stream);
         case 2: return launch_cov_ct<2>(nt, spikes, B, T, C, t_start, partial, stream);
         case 3: return launch_cov_ct<3>(nt, spikes, B, T, C, t_start, partial, stream);
-        case 4: return launch_cov_ct<4>(nt, spikes, B, T, C, t_start, partial, stream);
+        case 4: return launch_cov_wide<4>(nt, spikes, B, T, C, t_start, partial, stream);  // (ten Gram tiles per wave: the register form's reduction buffer alone is 160 KB)
         case 5: return launch_cov_wide<5>(nt, spikes, B, T, C, t_start, partial, stream);
         case 6: return launch_cov_wide<6>(nt, spikes, B, T, C, t_start, partial, stream);
         case 7: return launch_cov_wide<7>(nt, spikes, B, T, C, t_start, partial, stream);

@@ -216,8 +216,8 @@ class SNNBeamformer:
         if svd == "device":
             import torch
 
-            if 2 * len(self.geometry) > 32:
-                raise ValueError("svd='device' supports up to 16 microphones")
+            if 2 * len(self.geometry) > 128:
+                raise ValueError("svd='device' supports up to 64 microphones")
             bf_dev = torch.empty((2 * len(self.geometry), len(doa_list)), dtype=torch.float64, device=runtime.require_gpu(self.device))
         for start in range(0, len(doa_list), doa_batch):
             doas = doa_list[start : start + doa_batch]

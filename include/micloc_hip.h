@@ -241,9 +241,11 @@ int micloc_stream_localize_status(const void *loc_state, int *status4, void *str
  * (micloc_lif_covariance_f64's output).  bipolar = 0: the DC-removed conditional singular vector (secular equation solved by
  * the reference's bisection to rel_prec; the result does not depend on the signs of the singular vectors).  bipolar = 1: the
  * leading left singular vector of the folded complex covariance, stacked [Re; Im]; its unit phase -- arbitrary by
- * definition, LAPACK's being an artefact of its bidiagonalisation -- is fixed by making the largest component real and
- * positive, so columns agree with the reference's up to that phase and |W^H W| agrees.  Cyclic Jacobi in LDS, C <= 32.
- * Device buffers. */
+ * definition -- is fixed by making the FIRST component real and negative (what LAPACK's zgesdd leaves on these matrices, to
+ * ~2e-4 of the component's modulus; a convention that is continuous along the DoA grid), so columns agree with the reference's
+ * up to that residual phase and |W^H W| agrees.  C <= 32: cyclic two-sided Jacobi in LDS, one wave per DoA; 32 < C <= 128
+ * (C even): one-sided (Hestenes) Jacobi on the matrix / the real embedding of the complex fold, one workgroup per DoA.
+ * MICLOC_ERR_SHAPE beyond that.  Device buffers. */
 int micloc_design_vectors_f64(const double *cov, int n_doa, int C, int bipolar, double rel_prec, double *bf_mat, int G, int g0,
                               void *stream);
 

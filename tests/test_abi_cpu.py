@@ -64,7 +64,8 @@ def test_round2_entry_points_validate_before_touching_the_device():
     args.mode = 0
     assert lib.micloc_synth_targets_f64(ctypes.byref(args), None) == _lib.MICLOC_ERR_INVALID  # neither delays nor (doa, geometry)
     assert lib.micloc_delay_min_f64(one, 1, 1, 1, one, one, 7, 0.0, one, None) == _lib.MICLOC_ERR_INVALID  # speed must be positive
-    assert lib.micloc_design_vectors_f64(one, 1, 40, 1, 1e-8, one, 4, 0, None) == _lib.MICLOC_ERR_SHAPE      # more than 32 channels
+    assert lib.micloc_design_vectors_f64(one, 1, 130, 1, 1e-8, one, 4, 0, None) == _lib.MICLOC_ERR_SHAPE     # more than 128 channels
+    assert lib.micloc_design_vectors_f64(one, 1, 41, 0, 1e-8, one, 4, 0, None) == _lib.MICLOC_ERR_SHAPE      # the wide kernel pairs all columns: even count
     assert lib.micloc_design_vectors_f64(one, 1, 13, 1, 1e-8, one, 4, 0, None) == _lib.MICLOC_ERR_SHAPE      # bipolar needs an even count
     assert lib.micloc_design_vectors_f64(one, 3, 14, 1, 1e-8, one, 4, 2, None) == _lib.MICLOC_ERR_INVALID    # columns past G
     assert lib.micloc_peak_location_i32(one, 1, 449, 1, 14, one, None) == _lib.MICLOC_ERR_INVALID            # even window (utils.py:100)

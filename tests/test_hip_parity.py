@@ -297,11 +297,12 @@ def test_covariance_form_power_and_membrane_covariance(plan2, cfg2):
 
 
 def test_covariance_form_wide(torch):
-    """C = 32 and C = 48 channels (two / three channel tiles -> 3 / 6 Gram tiles); C = 80 and C = 128 channels (the
-    LDS-shared kernel of BASELINE config 5: 36 Gram tiles dealt over the waves), incl. a ragged T and t_start."""
+    """C = 32 and C = 48 channels (two / three channel tiles -> 3 / 6 Gram tiles, register form); C = 56, 64, 80 and 128 channels
+    (four to eight channel tiles: the LDS-shared kernel of BASELINE config 5, up to 36 Gram tiles dealt over the waves), incl. a
+    ragged T and t_start."""
     from haghighatshoarmuir2024_amd.runtime import Plan
 
-    for M, G, T in [(16, 40, 900), (24, 20, 530), (40, 33, 700), (64, 70, 1111)]:
+    for M, G, T in [(16, 40, 900), (24, 20, 530), (28, 25, 650), (32, 30, 800), (40, 33, 700), (64, 70, 1111)]:
         fs = 96_000
         rng = np.random.RandomState(M)
         ker = O.stht_kernel(fs, 10e-3)

@@ -323,6 +323,58 @@ def test_full_design_on_device_jacobi(cfg2):
         bf.design_from_template((time_temp, sig_temp), z["doa_list"][:2], svd="gpu")
 
 
+def test_design_vectors_wide_one_sided_jacobi():
+    """micloc_design_vectors_f64 for 32 < C <= 128 (up to 64 microphones; one-sided Jacobi, csrc/design.hip) against LAPACK on
+    random covariances: the DC-removed conditional singular vector (snn_beamformer.py:372-422) directly, the leading left singular
+    vector of the complex fold (:191-203) up to its unit phase, whose convention (first component real and negative) is checked.
+    Then a 32-microphone bipolar design end to end: svd="device" against svd="host"."""
+    import torch
+
+    from haghighatshoarmuir2024_amd import runtime
+    from micloc.array_geometry import CenterCircularArray
+    from micloc.snn_beamformer import SNNBeamformer
+
+    rng = np.random.RandomState(3)
+    helper = make_beamformer()
+    for C in (34, 64, 100, 128):
+        n_doa = 5
+        A = rng.randn(n_doa, C, 3 * C)
+        cov = A @ A.transpose(0, 2, 1) / (3 * C) + 0.5 * np.exp(rng.randn(n_doa, 1, 1)) * (np.ones((C, C)) + np.eye(C))
+        cov_d = torch.from_numpy(cov).cuda()
+        for bipolar in (False, True):
+            out = torch.zeros((C, n_doa + 2), dtype=torch.float64, device="cuda")
+            runtime.design_vectors(cov_d, bipolar, out, 1, rel_prec=1e-8)
+            W = out.cpu().numpy()
+            assert np.all(W[:, 0] == 0) and np.all(W[:, -1] == 0)  # only columns g0 .. g0 + n are written
+            W = W[:, 1:-1]
+            np.testing.assert_allclose(np.linalg.norm(W, axis=0), 1.0, rtol=0, atol=1e-12)
+            for i in range(n_doa):
+                if not bipolar:
+                    ref = helper._find_dc_removed_sing_vec(cov[i], rel_prec=1e-8)
+                    np.testing.assert_allclose(W[:, i], ref, rtol=0, atol=1e-7)
+                    assert abs(np.sum(W[:, i])) < 1e-4  # orthogonal to the all-one vector (to the bisection's rel_prec)
+                else:
+                    d = C // 2
+                    Cc = (cov[i][:d, :d] + cov[i][d:, d:]) / 2 + 1j * ((cov[i][:d, d:] + cov[i][d:, :d].T) / 2)
+                    U, S, _ = np.linalg.svd(Cc)
+                    w = W[:d, i] + 1j * W[d:, i]
+                    assert abs(abs(np.vdot(U[:, 0], w)) - 1.0) < 1e-9, (C, i, S[:3])
+                    assert w[0].real < 0 and abs(w[0].imag) < 1e-12
+    fs = 48_000
+    geo = CenterCircularArray(8e-2, 32)
+    tau = 1 / (2 * np.pi * 1500)
+    bf = SNNBeamformer(geo, 10e-3, [1000, 2000], np.asarray([tau, tau]), bipolar_spikes=True, fs=fs)
+    t = np.arange(0, 0.2, step=1 / fs)
+    sig = np.sin(2 * np.pi * np.cumsum(1000 + 1000 * t / t[-1]) / fs)
+    doas = np.linspace(-np.pi, np.pi, 9)
+    Wh = bf.design_from_template((t, sig), doas, svd="host", device_synthesis=True)
+    Wd = bf.design_from_template((t, sig), doas, svd="device")
+    assert Wd.shape == (64, 9)
+    Wh, Wd = Wh[:32] + 1j * Wh[32:], Wd[:32] + 1j * Wd[32:]
+    np.testing.assert_allclose(np.abs(np.sum(np.conj(Wh) * Wd, axis=0)), 1.0, rtol=0, atol=1e-8)
+    np.testing.assert_allclose(np.abs(Wd.conj().T @ Wd), np.abs(Wh.conj().T @ Wh), rtol=0, atol=1e-7)
+
+
 def test_live_demo_frame_processing(cfg2):
     """localization_demo_snn.Demo.process_frame == filterbank -> apply_to_signal per band -> summed power -> arg-max,
     checked against the oracle composition; weak packs give NaN (reference :153-159)."""
