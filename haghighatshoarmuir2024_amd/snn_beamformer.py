@@ -193,7 +193,7 @@ class SNNBeamformer:
         """Reference :82-211.  The per-DoA chain (delayed template -> STHT -> band-pass -> RZCC -> LIF -> covariance of the
         last 3/4) runs on the device for `doa_batch` DoAs at a time.  svd="host": the 2M x 2M decompositions by LAPACK like
         the reference (same singular-vector phases: bf_mat equals the reference's fixture); svd="device": one batched
-        Jacobi kernel (micloc_design_vectors_f64; unipolar columns equal the reference's, bipolar ones up to a residual unit phase
+        Jacobi kernel (micloc_design_vectors_f64, up to 64 microphones; unipolar columns equal the reference's, bipolar ones up to a residual unit phase
         of ~2e-4 rad: the kernel follows LAPACK's convention, first component real and negative, because the real-projected
         spectrum is not invariant to that phase -- 97 % of the reference's arg-maxima on its accuracy sweep, MAE within 0.03 deg),
         with the delayed templates synthesised on the device as well -- nothing but the template and bf_mat crosses PCIe."""
