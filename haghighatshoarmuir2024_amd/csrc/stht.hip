@@ -17,6 +17,8 @@
 // Arithmetic contract (== oracle/micloc_oracle.c oracle_stht): acc = +0; for taps k ascending:
 // acc = fma(ker[k], x[t-k], acc); exact-zero taps contribute nothing (skipped when every second tap
 // is zero, which is the case for every even-length Hilbert kernel).
+#include <cstdlib>
+
 #include "micloc_internal.h"
 
 namespace micloc {
@@ -198,6 +200,183 @@ static int stht_rowstride(const SthtTaps &tp)
     return np + 2;       // +16 B so consecutive mic rows start on different bank groups
 }
 
+// ---- the quadrature FIR on the matrix cores (fused pipelines: quadrature rows only) ---------------------------------------
+// On gfx950 the fp64 matrix pipe and the fp64 vector pipe have the same peak, so a FIR gains no flops by moving to
+// v_mfma_f64_16x16x4_f64 -- but the vector form above is pinned to ~57 % of it: every tap costs a 16-byte LDS read per lane,
+// which keeps the CU's LDS pipe exactly as busy as the FMAs keep the SIMDs.  As a Toeplitz product the same chain reads
+// two 8-byte fragments per 1024 multiply-adds.
+//   Every second tap of an even-length Hilbert kernel is zero (kstep == 2): y[t] = sum_j g[j] x[t - klo - 2j].  Outputs of one
+//   parity, t = 2i + p, see inputs of ONE parity: u_p[i] = sum_j g[j] X_pi[i + o - j] with X_pi[v] = x[2v + pi],
+//   pi = (p - klo) mod 2, o = floor((p - klo) / 2) -- two dense FIRs of J taps on de-interleaved data.
+//   D[stream][i] += A[stream][k] B[k][i]:  A = X_pi[v_top - 4s - k][stream] (16 streams = 16 rows, data from LDS),
+//   B = G[il + 4s + k] with G[idx] = g[idx - 15] (zero outside the kernel: the Toeplitz corners), k-steps s = 0 .. NK - 1 from
+//   the newest input backwards.  For output i the k-th product of step s is tap j = il - 15 + 4s + k: the chain runs over the
+//   taps in ascending order, products with a zero coefficient in front of and behind it leave the accumulator untouched (it
+//   is never -0), and the matrix core accumulates its four products in k order as fused multiply-adds (the LIF product of
+//   csrc/beamform.hip rests on the same two facts) -- bit for bit the contract of the kernel above.
+// A workgroup = 16 consecutive (trial, microphone) streams x TI = 128 NTW outputs per parity, 8 waves, NTW tiles per wave and
+// parity (2 NTW independent accumulator chains per wave, two waves per SIMD: the matrix pipe never waits).  Both parities of
+// (stream, i) sit in the same lane: y[2i], y[2i + 1] leave as one 16-byte store, 256 contiguous bytes per stream row.
+constexpr int SM_WAVES = 8;
+constexpr int SM_THREADS = 64 * SM_WAVES;
+
+template <int NTW>
+__global__ __launch_bounds__(SM_THREADS) void stht_mfma_kernel(const double *__restrict__ x, double *__restrict__ h,
+                                                               const double *__restrict__ taps, int J, int klo, int NK, int T, int M,
+                                                               int Ts, int nstreams)
+{
+    typedef double double4_t __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) double Xs[];
+    constexpr int TI = SM_WAVES * NTW * 16;  // outputs per parity and workgroup
+    const int R = TI + 4 * NK - 16;          // staged rows per input parity
+    double *XS0 = Xs, *XS1 = Xs + (size_t)R * 16, *G = XS1 + (size_t)R * 16;
+    const int tid = threadIdx.x;
+    // consecutive time tiles of a stream group share most of their input: keep them on one XCD (one L2) -- see above
+    int tile = blockIdx.x, grp = blockIdx.y;
+    {
+        const int ntile = gridDim.x, ngrp = gridDim.y;
+        const int L = tile + ntile * grp;
+        const int full = (ngrp >> 3) << 3;
+        if (L < full * ntile) {
+            const int j = L >> 3;
+            const int rq = j / ntile;
+            tile = j - rq * ntile;
+            grp = 8 * rq + (L & 7);
+        }
+    }
+    const int I0 = tile * TI;
+    // input parity and offset of the two output parities
+    const int e0 = -klo, e1 = 1 - klo;
+    const int pi0 = e0 & 1, pi1 = e1 & 1;
+    const int o0 = (e0 - pi0) / 2, o1 = (e1 - pi1) / 2;
+
+    for (int idx = tid; idx < 4 * NK + 16; idx += SM_THREADS) {
+        const int j = idx - 15;
+        G[idx] = (j >= 0 && j < J) ? taps[j] : 0.0;
+    }
+    {
+        const int sl = tid & 15;
+        const int sigma = grp * 16 + sl;
+        const bool valid = sigma < nstreams;
+        const int b = valid ? sigma / M : 0, m = valid ? sigma - b * M : 0;
+        const double *xs = x + (size_t)b * T * M + m;
+        constexpr int RP = SM_THREADS / 16;  // rows per pass
+#pragma unroll
+        for (int par = 0; par < 2; ++par) {
+            double *dst = par ? XS1 : XS0;
+            const int tau0 = 2 * (I0 + (par ? o1 : o0) - (4 * NK - 16)) + (par ? pi1 : pi0);  // input time of staged row 0
+            for (int r0 = tid >> 4; r0 < R; r0 += RP * 8) {
+                double v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    int tau = tau0 + 2 * (r0 + RP * i);
+                    tau = tau < 0 ? 0 : (tau >= T ? T - 1 : tau);
+                    v[i] = xs[(size_t)tau * M];
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int rho = r0 + RP * i;
+                    const int tau = tau0 + 2 * rho;
+                    if (rho < R) dst[rho * 16 + sl] = (valid && tau >= 0 && tau < T) ? v[i] : 0.0;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l = tid & 63, lc = l & 15, q = l >> 4;
+    const int irel = wv * NTW * 16;  // first output of this wave, relative to I0
+    if (2 * (I0 + irel) >= Ts) return;  // (wave-uniform; no barrier below)
+    double4_t acc0[NTW], acc1[NTW];
+#pragma unroll
+    for (int tt = 0; tt < NTW; ++tt) {
+        acc0[tt] = double4_t{0.0, 0.0, 0.0, 0.0};
+        acc1[tt] = double4_t{0.0, 0.0, 0.0, 0.0};
+    }
+    // row of k-step s, lane group q, tile tt: irel + 16 tt + 4 NK - 1 - 4 s - q
+    const double *a0 = XS0 + (size_t)(irel + 4 * NK - 1 - q) * 16 + lc;
+    const double *a1 = XS1 + (size_t)(irel + 4 * NK - 1 - q) * 16 + lc;
+    const double *bp = G + lc + q;
+    auto kstep = [&](const double *p0, const double *p1, const double *pb) {
+        const double bn = *pb;
+        double av0[NTW], av1[NTW];
+#pragma unroll
+        for (int tt = 0; tt < NTW; ++tt) {
+            av0[tt] = p0[tt * 256];
+            av1[tt] = p1[tt * 256];
+        }
+#pragma unroll
+        for (int tt = 0; tt < NTW; ++tt) {
+            acc0[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av0[tt], bn, acc0[tt], 0, 0, 0);
+            acc1[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av1[tt], bn, acc1[tt], 0, 0, 0);
+        }
+    };
+    int s = 0;
+    for (; s + 4 <= NK; s += 4) {  // four k-steps per pointer update: non-negative immediate offsets
+        a0 -= 4 * 64;
+        a1 -= 4 * 64;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) kstep(a0 + (3 - u) * 64 + 64, a1 + (3 - u) * 64 + 64, bp + 4 * u);
+        bp += 16;
+    }
+    for (; s < NK; ++s) {
+        kstep(a0, a1, bp);
+        a0 -= 64;
+        a1 -= 64;
+        bp += 4;
+    }
+
+    const int C = 2 * M;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int sigma = grp * 16 + q + 4 * r;
+        if (sigma >= nstreams) continue;
+        const int b = sigma / M, m = sigma - b * M;
+        double *row = h + ((size_t)b * C + M + m) * Ts;
+#pragma unroll
+        for (int tt = 0; tt < NTW; ++tt) {
+            const int t = 2 * (I0 + irel + 16 * tt + lc);
+            if (t < Ts) *reinterpret_cast<double2 *>(row + t) = make_double2(acc0[tt][r], acc1[tt][r]);
+        }
+    }
+}
+
+// in-phase rows beside the matrix-core form: h[b][m][t] = x[b][(t - shift) mod T][m] (np.roll), zero in the row padding.
+// 64 frames x M microphones per workgroup through an LDS tile: row-major reads, planar writes, both coalesced.
+__global__ __launch_bounds__(256) void stht_inphase_kernel(const double *__restrict__ x, double *__restrict__ h, int shift, int T, int M, int Ts)
+{
+    extern __shared__ __attribute__((aligned(16))) double Xs[];
+    const int b = blockIdx.y, t0 = blockIdx.x * 64;
+    const int sh = shift % T;
+    const double *xb = x + (size_t)b * T * M;
+    for (int e = threadIdx.x; e < 64 * M; e += 256) {
+        const int tl = e / M, m = e - tl * M;
+        const int t = t0 + tl;
+        double v = 0.0;
+        if (t < T) {
+            int src = t - sh;
+            if (src < 0) src += T;
+            v = xb[(size_t)src * M + m];
+        }
+        Xs[tl * M + m] = v;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 64 * M; e += 256) {
+        const int m = e >> 6, tl = e & 63;
+        const int t = t0 + tl;
+        if (t < Ts) h[((size_t)b * 2 * M + m) * Ts + t] = Xs[tl * M + m];
+    }
+}
+
+// LDS of the matrix-core form with NTW tiles per wave and parity; NK k-steps for J compact taps
+static size_t stht_mfma_lds(int J, int NTW)
+{
+    const int NK = (J + 15 + 3) / 4;
+    const size_t R = (size_t)SM_WAVES * NTW * 16 + 4 * NK - 16;
+    return (2 * R * 16 + 4 * (size_t)NK + 16) * sizeof(double);
+}
+
 size_t stht_lds_bytes(const SthtTaps &tp, int M)
 {
     const int MB = M < STHT_MAX_MB ? M : STHT_MAX_MB;
@@ -207,6 +386,30 @@ size_t stht_lds_bytes(const SthtTaps &tp, int M)
 hipError_t launch_stht(const SthtTaps &tp, const double *x, double *h, int B, int T, int M, int Ts,
                        hipStream_t stream, bool write_re)
 {
+    // every second tap zero: the matrix-core form, if its tile fits LDS (MICLOC_STHT_VALU=1: never), in-phase rows by a copy kernel
+    static const bool force_valu = [] {
+        const char *e = getenv("MICLOC_STHT_VALU");
+        return e && e[0] == '1';
+    }();
+    if (tp.kstep == 2 && tp.ngroups > 0 && !force_valu && ((size_t)B * M + 15) / 16 <= 65535 && B <= 65535) {
+        const int J = tp.ngroups * (STHT_R / tp.kstep);  // compact taps incl. the zero padding of the last group
+        const int NK = (J + 15 + 3) / 4;
+        const int ntw = stht_mfma_lds(J, 2) <= 160 * 1024 ? 2 : (stht_mfma_lds(J, 1) <= 160 * 1024 ? 1 : 0);
+        if (ntw) {
+            const int TI = SM_WAVES * ntw * 16;
+            const int nstreams = B * M;
+            dim3 grid((Ts / 2 + TI - 1) / TI, (nstreams + 15) / 16);
+            const size_t lds = stht_mfma_lds(J, ntw);
+            auto k = ntw == 2 ? &stht_mfma_kernel<2> : &stht_mfma_kernel<1>;
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(k, grid, dim3(SM_THREADS), lds, stream, x, h, tp.taps, J, tp.klo, NK, T, M, Ts, nstreams);
+            if (write_re)
+                hipLaunchKernelGGL(stht_inphase_kernel, dim3((Ts + 63) / 64, B), dim3(256), (size_t)64 * M * sizeof(double), stream, x, h,
+                                   tp.shift, T, M, Ts);
+            return hipGetLastError();
+        }
+    }
     const int MB = M < STHT_MAX_MB ? M : STHT_MAX_MB;
     const int rowstride = stht_rowstride(tp);
     const size_t lds = (size_t)MB * rowstride * sizeof(double);
