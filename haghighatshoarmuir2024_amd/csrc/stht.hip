@@ -221,15 +221,18 @@ constexpr int SM_WAVES = 8;
 constexpr int SM_THREADS = 64 * SM_WAVES;
 
 template <int NTW>
-__global__ __launch_bounds__(SM_THREADS) void stht_mfma_kernel(const double *__restrict__ x, double *__restrict__ h,
-                                                               const double *__restrict__ taps, int J, int klo, int NK, int T, int M,
-                                                               int Ts, int nstreams)
+__global__ __launch_bounds__(SM_THREADS, 2) void stht_mfma_kernel(const double *__restrict__ x, double *__restrict__ h,
+                                                                  const double *__restrict__ taps, int J, int klo, int NK, int T, int M,
+                                                                  int Ts, int nstreams)
 {
     typedef double double4_t __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) double Xs[];
     constexpr int TI = SM_WAVES * NTW * 16;  // outputs per parity and workgroup
     const int R = TI + 4 * NK - 16;          // staged rows per input parity
-    double *XS0 = Xs, *XS1 = Xs + (size_t)R * 16, *G = XS1 + (size_t)R * 16;
+    // ONE staged array: the two output parities are independent problems on different input samples, so the workgroup loads
+    // both into registers at once, then stages / multiplies one after the other through the same LDS rows -- half the LDS,
+    // two workgroups per CU (one multiplies while the other waits for its loads).
+    double *XS = Xs, *G = Xs + (size_t)R * 16;
     const int tid = threadIdx.x;
     // consecutive time tiles of a stream group share most of their input: keep them on one XCD (one L2) -- see above
     int tile = blockIdx.x, grp = blockIdx.y;
@@ -254,78 +257,101 @@ __global__ __launch_bounds__(SM_THREADS) void stht_mfma_kernel(const double *__r
         const int j = idx - 15;
         G[idx] = (j >= 0 && j < J) ? taps[j] : 0.0;
     }
-    {
-        const int sl = tid & 15;
-        const int sigma = grp * 16 + sl;
-        const bool valid = sigma < nstreams;
-        const int b = valid ? sigma / M : 0, m = valid ? sigma - b * M : 0;
-        const double *xs = x + (size_t)b * T * M + m;
-        constexpr int RP = SM_THREADS / 16;  // rows per pass
-#pragma unroll
-        for (int par = 0; par < 2; ++par) {
-            double *dst = par ? XS1 : XS0;
-            const int tau0 = 2 * (I0 + (par ? o1 : o0) - (4 * NK - 16)) + (par ? pi1 : pi0);  // input time of staged row 0
-            for (int r0 = tid >> 4; r0 < R; r0 += RP * 8) {
-                double v[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    int tau = tau0 + 2 * (r0 + RP * i);
-                    tau = tau < 0 ? 0 : (tau >= T ? T - 1 : tau);
-                    v[i] = xs[(size_t)tau * M];
-                }
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int rho = r0 + RP * i;
-                    const int tau = tau0 + 2 * rho;
-                    if (rho < R) dst[rho * 16 + sl] = (valid && tau >= 0 && tau < T) ? v[i] : 0.0;
-                }
-            }
-        }
-    }
-    __syncthreads();
-
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l = tid & 63, lc = l & 15, q = l >> 4;
-    const int irel = wv * NTW * 16;  // first output of this wave, relative to I0
-    if (2 * (I0 + irel) >= Ts) return;  // (wave-uniform; no barrier below)
+    const int irel = wv * NTW * 16;                  // first output of this wave, relative to I0
+    const bool active = 2 * (I0 + irel) < Ts;        // (wave-uniform)
     double4_t acc0[NTW], acc1[NTW];
 #pragma unroll
     for (int tt = 0; tt < NTW; ++tt) {
         acc0[tt] = double4_t{0.0, 0.0, 0.0, 0.0};
         acc1[tt] = double4_t{0.0, 0.0, 0.0, 0.0};
     }
-    // row of k-step s, lane group q, tile tt: irel + 16 tt + 4 NK - 1 - 4 s - q
-    const double *a0 = XS0 + (size_t)(irel + 4 * NK - 1 - q) * 16 + lc;
-    const double *a1 = XS1 + (size_t)(irel + 4 * NK - 1 - q) * 16 + lc;
-    const double *bp = G + lc + q;
-    auto kstep = [&](const double *p0, const double *p1, const double *pb) {
-        const double bn = *pb;
-        double av0[NTW], av1[NTW];
+    // the Toeplitz product of one parity: row of k-step s, lane group q, tile tt = irel + 16 tt + 4 NK - 1 - 4 s - q
+    auto multiply = [&](double4_t *acc) {
+        const double *ap = XS + (size_t)(irel + 4 * NK - 1 - q) * 16 + lc;
+        const double *bp = G + lc + q;
+        auto kstep = [&](const double *pa, const double *pb) {
+            const double bn = *pb;
+            double av[NTW];
 #pragma unroll
-        for (int tt = 0; tt < NTW; ++tt) {
-            av0[tt] = p0[tt * 256];
-            av1[tt] = p1[tt * 256];
+            for (int tt = 0; tt < NTW; ++tt) av[tt] = pa[tt * 256];
+#pragma unroll
+            for (int tt = 0; tt < NTW; ++tt) acc[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[tt], bn, acc[tt], 0, 0, 0);
+        };
+        int s = 0;
+        for (; s + 4 <= NK; s += 4) {  // four k-steps per pointer update: non-negative immediate offsets
+            ap -= 4 * 64;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) kstep(ap + (4 - u) * 64, bp + 4 * u);
+            bp += 16;
         }
-#pragma unroll
-        for (int tt = 0; tt < NTW; ++tt) {
-            acc0[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av0[tt], bn, acc0[tt], 0, 0, 0);
-            acc1[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av1[tt], bn, acc1[tt], 0, 0, 0);
+        for (; s < NK; ++s) {
+            kstep(ap, bp);
+            ap -= 64;
+            bp += 4;
         }
     };
-    int s = 0;
-    for (; s + 4 <= NK; s += 4) {  // four k-steps per pointer update: non-negative immediate offsets
-        a0 -= 4 * 64;
-        a1 -= 4 * 64;
+
+    const int sl = tid & 15;
+    const int sg = grp * 16 + sl;
+    const bool valid = sg < nstreams;
+    const int bs = valid ? sg / M : 0, ms = valid ? sg - bs * M : 0;
+    const double *xs = x + (size_t)bs * T * M + ms;
+    constexpr int RP = SM_THREADS / 16;  // rows per pass
+    constexpr int NB = 16;               // loads in flight per thread and parity: the whole tile of the default shape in one batch
+    const int tau00 = 2 * (I0 + o0 - (4 * NK - 16)) + pi0, tau01 = 2 * (I0 + o1 - (4 * NK - 16)) + pi1;  // input time of staged row 0
+    if (R <= RP * NB) {
+        // both parities in flight at once; the second one waits in registers while the first is multiplied
+        double v0[NB], v1[NB];
+        const int r0 = tid >> 4;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) kstep(a0 + (3 - u) * 64 + 64, a1 + (3 - u) * 64 + 64, bp + 4 * u);
-        bp += 16;
+        for (int i = 0; i < NB; ++i) {
+            int ta = tau00 + 2 * (r0 + RP * i), tb = tau01 + 2 * (r0 + RP * i);
+            ta = ta < 0 ? 0 : (ta >= T ? T - 1 : ta);
+            tb = tb < 0 ? 0 : (tb >= T ? T - 1 : tb);
+            v0[i] = xs[(size_t)ta * M];
+            v1[i] = xs[(size_t)tb * M];
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int rho = r0 + RP * i, ta = tau00 + 2 * rho;
+            if (rho < R) XS[rho * 16 + sl] = (valid && ta >= 0 && ta < T) ? v0[i] : 0.0;
+        }
+        __syncthreads();
+        if (active) multiply(acc0);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int rho = r0 + RP * i, tb = tau01 + 2 * rho;
+            if (rho < R) XS[rho * 16 + sl] = (valid && tb >= 0 && tb < T) ? v1[i] : 0.0;
+        }
+        __syncthreads();
+        if (active) multiply(acc1);
+    } else {
+#pragma unroll
+        for (int par = 0; par < 2; ++par) {
+            const int tau0 = par ? tau01 : tau00;
+            if (par) __syncthreads();
+            for (int r0 = tid >> 4; r0 < R; r0 += RP * NB) {
+                double v[NB];
+#pragma unroll
+                for (int i = 0; i < NB; ++i) {
+                    int ta = tau0 + 2 * (r0 + RP * i);
+                    ta = ta < 0 ? 0 : (ta >= T ? T - 1 : ta);
+                    v[i] = xs[(size_t)ta * M];
+                }
+#pragma unroll
+                for (int i = 0; i < NB; ++i) {
+                    const int rho = r0 + RP * i, ta = tau0 + 2 * rho;
+                    if (rho < R) XS[rho * 16 + sl] = (valid && ta >= 0 && ta < T) ? v[i] : 0.0;
+                }
+            }
+            __syncthreads();
+            if (active) multiply(par ? acc1 : acc0);
+        }
     }
-    for (; s < NK; ++s) {
-        kstep(a0, a1, bp);
-        a0 -= 64;
-        a1 -= 64;
-        bp += 4;
-    }
+    if (!active) return;
 
     const int C = 2 * M;
 #pragma unroll
@@ -374,7 +400,7 @@ static size_t stht_mfma_lds(int J, int NTW)
 {
     const int NK = (J + 15 + 3) / 4;
     const size_t R = (size_t)SM_WAVES * NTW * 16 + 4 * NK - 16;
-    return (2 * R * 16 + 4 * (size_t)NK + 16) * sizeof(double);
+    return (R * 16 + 4 * (size_t)NK + 16) * sizeof(double);
 }
 
 size_t stht_lds_bytes(const SthtTaps &tp, int M)
@@ -394,7 +420,8 @@ hipError_t launch_stht(const SthtTaps &tp, const double *x, double *h, int B, in
     if (tp.kstep == 2 && tp.ngroups > 0 && !force_valu && ((size_t)B * M + 15) / 16 <= 65535 && B <= 65535) {
         const int J = tp.ngroups * (STHT_R / tp.kstep);  // compact taps incl. the zero padding of the last group
         const int NK = (J + 15 + 3) / 4;
-        const int ntw = stht_mfma_lds(J, 2) <= 160 * 1024 ? 2 : (stht_mfma_lds(J, 1) <= 160 * 1024 ? 1 : 0);
+        // two workgroups per CU if the tile allows it
+        const int ntw = stht_mfma_lds(J, 2) <= 80 * 1024 ? 2 : (stht_mfma_lds(J, 1) <= 80 * 1024 ? 1 : (stht_mfma_lds(J, 2) <= 160 * 1024 ? 2 : (stht_mfma_lds(J, 1) <= 160 * 1024 ? 1 : 0)));
         if (ntw) {
             const int TI = SM_WAVES * ntw * 16;
             const int nstreams = B * M;
