@@ -54,8 +54,14 @@ def test_stht_dense_and_odd_kernels(torch):
     from haghighatshoarmuir2024_amd.runtime import Plan
 
     rng = np.random.RandomState(3)
+    # (the stride-2 kernels -- odd taps only, even taps only, leading zeros, 960 taps: one tile per wave and the looped staging --
+    #  run on the matrix cores, csrc/stht.hip stht_mfma_kernel; the dense ones on the vector ALU)
     for L, maker in [(37, lambda L: rng.randn(L)), (64, lambda L: np.r_[np.zeros(5), rng.randn(L - 5)]), (16, lambda L: np.zeros(L)),
-                     (50, lambda L: np.where(np.arange(L) % 2 == 1, rng.randn(L), 0.0))]:
+                     (50, lambda L: np.where(np.arange(L) % 2 == 1, rng.randn(L), 0.0)),
+                     (51, lambda L: np.where(np.arange(L) % 2 == 0, rng.randn(L), 0.0)),
+                     (70, lambda L: np.where((np.arange(L) % 2 == 0) & (np.arange(L) >= 6), rng.randn(L), 0.0)),
+                     (960, lambda L: np.where(np.arange(L) % 2 == 1, rng.randn(L), 0.0)),
+                     (9, lambda L: np.where(np.arange(L) == 3, 1.5, 0.0))]:
         ker = maker(L)
         p = Plan(5, ker, [1.0], [1.0], 3, True)
         x = rng.randn(2, 700, 5)
