@@ -34,6 +34,19 @@ for tag in ("kv", "k4"):
         print(tag, i, "ms_per_step %.4f" % d["ms_per_step"], "value %.4g" % d["value"], "beamform launch %.4f ms" % d["roofline"]["avg_launch_ms"], "frac %.3f" % d["roofline"]["frac"])
 PY
 rm -f $OUT/ab_kv_*.json $OUT/ab_k4_*.json
+# ablation: the STHT on the vector ALU (round 2's kernel) instead of the matrix cores (same box, alternating)
+for i in 1 2; do
+  python3 bench.py --steps 40 --warmup 4 --no-cpu-baseline --no-other-configs | tail -1 > $OUT/ab_mfma_$i.json 2>/dev/null
+  MICLOC_STHT_VALU=1 python3 bench.py --steps 40 --warmup 4 --no-cpu-baseline --no-other-configs | tail -1 > $OUT/ab_valu_$i.json 2>/dev/null
+done
+python3 - <<PY > $OUT/ablation_stht.txt
+import json
+for tag in ("mfma", "valu"):
+    for i in (1, 2):
+        d = json.load(open("$OUT/ab_%s_%d.json" % (tag, i)))
+        print("stht", tag, i, "ms_per_step %.4f" % d["ms_per_step"], "value %.4g" % d["value"], "e2e ms_per_step %.4f" % d["e2e"]["ms_per_step"])
+PY
+rm -f $OUT/ab_mfma_*.json $OUT/ab_valu_*.json
 # counters: separate passes, nothing but --pmc (+ kernel trace)
 for cfg in noisy stress speech xylo; do
   steps=6; [ $cfg = speech ] && steps=2; [ $cfg = xylo ] && steps=2
