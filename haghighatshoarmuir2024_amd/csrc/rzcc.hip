@@ -1243,15 +1243,17 @@ __global__ __launch_bounds__(64) void rzcc_unit_fallback_kernel(const double *__
 // Zero fill as an ordinary kernel.  hipMemsetAsync is avoided on purpose: captured into a HIP graph (ROCm 7.x) the
 // memset NODE was observed not to be ordered before the kernel nodes that follow it -- the fallback kernel then read a
 // stale flagged-stream counter and faulted on the third replay -- whereas kernel -> kernel edges are honoured.
+// `extra` (may be null): a second, 256-byte block zeroed by the same launch (the encoder's counters beside its spike tensor)
 __global__ __launch_bounds__(256) void zero_fill_kernel(uint4 *__restrict__ p16, size_t n16, unsigned char *__restrict__ tail,
-                                                         int ntail)
+                                                         int ntail, uint4 *__restrict__ extra)
 {
     const size_t stride = (size_t)gridDim.x * 256;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride) p16[i] = make_uint4(0, 0, 0, 0);
     if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = 0;
+    if (extra && blockIdx.x == gridDim.x - 1 && threadIdx.x < 16) extra[threadIdx.x] = make_uint4(0, 0, 0, 0);
 }
 
-static hipError_t zero_fill(void *ptr, size_t bytes, hipStream_t stream)
+static hipError_t zero_fill(void *ptr, size_t bytes, hipStream_t stream, void *extra256 = nullptr)
 {
     // torch / hipMalloc buffers are at least 16-byte aligned; the scatter target [B][T][C] int8 may have any size
     const size_t n16 = bytes / 16;
@@ -1260,7 +1262,7 @@ static hipError_t zero_fill(void *ptr, size_t bytes, hipStream_t stream)
     if (blocks > 2048) blocks = 2048;
     if (blocks == 0) blocks = 1;
     hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, reinterpret_cast<uint4 *>(ptr), n16,
-                       reinterpret_cast<unsigned char *>(ptr) + n16 * 16, ntail);
+                       reinterpret_cast<unsigned char *>(ptr) + n16 * 16, ntail, reinterpret_cast<uint4 *>(extra256));
     return hipGetLastError();
 }
 
@@ -1421,9 +1423,7 @@ hipError_t launch_bandpass_rzcc(const IirCoef &coef, const double *h, int nlanes
     const RzScratch sc = rz_scratch(nlanes, T, g.P);
     unsigned char *base = reinterpret_cast<unsigned char *>(scratch);
     if (spikes) {
-        hipError_t e = zero_fill(base + sc.count, 256, stream);
-        if (e != hipSuccess) return e;
-        e = zero_fill(spikes, (size_t)nlanes * T, stream);
+        hipError_t e = zero_fill(spikes, (size_t)nlanes * T, stream, base + sc.count);  // (+ the 256-byte counter block: one launch)
         if (e != hipSuccess) return e;
     }
 #define RZ_CASE(NN)                                                                                                 \
