@@ -220,11 +220,15 @@ static int stht_rowstride(const SthtTaps &tp)
 constexpr int SM_WAVES = 8;
 constexpr int SM_THREADS = 64 * SM_WAVES;
 
-template <int NTW>
+// NKT: the number of k-steps when it is known at compile time (the 480-tap kernel of the paper: 64), else 0.  With a constant
+// trip count the multiply loop unrolls completely and every s_waitcnt counts exactly the reads it needs; inside a loop the
+// compiler waits for the operands of the NEXT group as well (it cannot tell the back edge's reads from the new ones).
+template <int NTW, int NKT>
 __global__ __launch_bounds__(SM_THREADS, 2) void stht_mfma_kernel(const double *__restrict__ x, double *__restrict__ h,
-                                                                  const double *__restrict__ taps, int J, int klo, int NK, int T, int M,
+                                                                  const double *__restrict__ taps, int J, int klo, int NK_rt, int T, int M,
                                                                   int Ts, int nstreams)
 {
+    const int NK = NKT ? NKT : NK_rt;
     typedef double double4_t __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) double Xs[];
     constexpr int TI = SM_WAVES * NTW * 16;  // outputs per parity and workgroup
@@ -268,26 +272,61 @@ __global__ __launch_bounds__(SM_THREADS, 2) void stht_mfma_kernel(const double *
         acc1[tt] = double4_t{0.0, 0.0, 0.0, 0.0};
     }
     // the Toeplitz product of one parity: row of k-step s, lane group q, tile tt = irel + 16 tt + 4 NK - 1 - 4 s - q
+    // The operands of a group of k-steps are requested while the previous group is being multiplied (two register sets): issued
+    // right before their own MFMAs, the reads left the matrix pipe idle for an LDS round trip per group (12 % of the kernel by
+    // ablation).
     auto multiply = [&](double4_t *acc) {
-        const double *ap = XS + (size_t)(irel + 4 * NK - 1 - q) * 16 + lc;
-        const double *bp = G + lc + q;
-        auto kstep = [&](const double *pa, const double *pb) {
-            const double bn = *pb;
-            double av[NTW];
+        constexpr int GK = 2;  // k-steps per group: 2 NTW MFMAs (>= 256 cycles of matrix pipe) cover the next group's LDS round trip
+        const double *ap0 = XS + (size_t)(irel + 4 * NK - 1 - q) * 16 + lc;
+        const double *bp0 = G + lc + q;
+        auto fetch = [&](int g, double (&av)[GK][NTW], double (&bv)[GK]) {
+            const double *pa = ap0 - (size_t)(64 * GK) * (g + 1), *pb = bp0 + 4 * GK * g;
 #pragma unroll
-            for (int tt = 0; tt < NTW; ++tt) av[tt] = pa[tt * 256];
+            for (int u = 0; u < GK; ++u) {
+                bv[u] = pb[4 * u];
 #pragma unroll
-            for (int tt = 0; tt < NTW; ++tt) acc[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[tt], bn, acc[tt], 0, 0, 0);
+                for (int tt = 0; tt < NTW; ++tt) av[u][tt] = pa[(GK - u) * 64 + tt * 256];
+            }
         };
-        int s = 0;
-        for (; s + 4 <= NK; s += 4) {  // four k-steps per pointer update: non-negative immediate offsets
-            ap -= 4 * 64;
+        auto mult = [&](const double (&av)[GK][NTW], const double (&bv)[GK]) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) kstep(ap + (4 - u) * 64, bp + 4 * u);
-            bp += 16;
+            for (int u = 0; u < GK; ++u)
+#pragma unroll
+                for (int tt = 0; tt < NTW; ++tt) acc[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][tt], bv[u], acc[tt], 0, 0, 0);
+        };
+        const int NG = NK / GK;
+        if constexpr (NKT > 0) {
+            static_assert(NKT % (2 * GK) == 0, "whole pairs of groups");
+            double a0[GK][NTW], b0[GK], a1[GK][NTW], b1[GK];
+            fetch(0, a0, b0);
+#pragma unroll
+            for (int g = 0; g < NKT / GK; g += 2) {
+                fetch(g + 1, a1, b1);
+                __builtin_amdgcn_sched_barrier(0);  // (the scheduler would sink the reads back in front of their MFMAs)
+                mult(a0, b0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (g + 2 < NKT / GK) fetch(g + 2, a0, b0);
+                __builtin_amdgcn_sched_barrier(0);
+                mult(a1, b1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else if (NG > 0) {
+            double a0[GK][NTW], b0[GK], a1[GK][NTW], b1[GK];
+            fetch(0, a0, b0);
+            for (int g = 0;; g += 2) {
+                if (g + 1 < NG) fetch(g + 1, a1, b1);
+                mult(a0, b0);
+                if (g + 1 >= NG) break;
+                if (g + 2 < NG) fetch(g + 2, a0, b0);
+                mult(a1, b1);
+                if (g + 2 >= NG) break;
+            }
         }
-        for (; s < NK; ++s) {
-            kstep(ap, bp);
+        const double *ap = ap0 - (size_t)(64 * GK) * NG, *bp = bp0 + 4 * GK * NG;
+        for (int s = GK * NG; s < NK; ++s) {
+            const double bn = *bp;
+#pragma unroll
+            for (int tt = 0; tt < NTW; ++tt) acc[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[tt * 256], bn, acc[tt], 0, 0, 0);
             ap -= 64;
             bp += 4;
         }
@@ -427,7 +466,7 @@ hipError_t launch_stht(const SthtTaps &tp, const double *x, double *h, int B, in
             const int nstreams = B * M;
             dim3 grid((Ts / 2 + TI - 1) / TI, (nstreams + 15) / 16);
             const size_t lds = stht_mfma_lds(J, ntw);
-            auto k = ntw == 2 ? &stht_mfma_kernel<2> : &stht_mfma_kernel<1>;
+            auto k = ntw == 2 ? (NK == 64 ? &stht_mfma_kernel<2, 64> : &stht_mfma_kernel<2, 0>) : &stht_mfma_kernel<1, 0>;
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return e;
             hipLaunchKernelGGL(k, grid, dim3(SM_THREADS), lds, stream, x, h, tp.taps, J, tp.klo, NK, T, M, Ts, nstreams);
