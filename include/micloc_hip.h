@@ -105,7 +105,10 @@ size_t micloc_workspace_bytes(const micloc_plan *plan, int B, int T);
 
 /* ---- stages (device pointers) ----------------------------------------------------------------- */
 /* STHT: roll by L/2 + 1j * FIR.  Replaces snn_beamformer.py:325-327 / :158-160,
- * beamformer.py:281-283, xylo_snn_localization.py:329-331.   x [B][T][M] -> h planar [B][2M][Ts]. */
+ * beamformer.py:281-283, xylo_snn_localization.py:329-331.   x [B][T][M] -> h planar [B][2M][Ts].
+ * The FIR is the chain acc = fma(ker[k], x[t - k], acc) over the non-zero taps in ascending k, from +0.  When every second tap
+ * is zero (every even-length Hilbert kernel) it runs as a Toeplitz product on the fp64 matrix cores -- the same chain, the same
+ * bits -- otherwise (or with MICLOC_STHT_VALU=1 in the environment, for A/B timing) on the vector ALU. */
 int micloc_stht_f64(const micloc_plan *plan, const double *x, int B, int T, double *h, int Ts, void *stream);
 
 /* Band-pass (DF2T, lfilter(b,a,.)) + RZCC encoder.  Replaces snn_beamformer.py:330-338 and
