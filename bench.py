@@ -544,8 +544,10 @@ def other_configs_block(args):
     """The other BASELINE configs on the same box, a few steps each, as CHILD processes of this (GPU-initialised) process --
     started, never exec'ed; one at a time."""
     out = {}
-    for cfg, steps in (("speech", 3), ("xylo", 3), ("stress", 3)):
-        cmd = [sys.executable, os.path.abspath(__file__), "--config", cfg, "--steps", str(steps), "--warmup", "1", "--repeats", "3",
+    # (enough steps per timed region for the three streams to drift out of step: with one step per stream they start together and
+    #  finish together, which is not the steady state -- xylo 18.0 ms/step at 3 steps, 17.0 at 12)
+    for cfg, steps in (("speech", 9), ("xylo", 12), ("stress", 9)):
+        cmd = [sys.executable, os.path.abspath(__file__), "--config", cfg, "--steps", str(steps), "--warmup", "3", "--repeats", "3",
                "--no-cpu-baseline", "--no-other-configs", "--streams", str(args.streams)]
         t0 = time.perf_counter()
         try:
