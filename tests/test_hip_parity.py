@@ -574,3 +574,32 @@ def test_planar_gram_against_numpy(torch):
             np.testing.assert_array_equal(g, np.transpose(g, (0, 2, 1)))  # exactly symmetric: one tile serves both halves
     with pytest.raises(ValueError):
         runtime.planar_gram(xd, 2049, t_start=2049)
+
+
+def test_stht_vector_form_still_exact():
+    """MICLOC_STHT_VALU=1 (the A/B switch of tools/dev/ab_headline.sh) sends stride-2 kernels through the vector-ALU STHT again:
+    a fresh child process (the switch is read once per process) checks it against the oracle like test_stht_bit_exact does."""
+    import subprocess
+    import sys
+
+    code = r"""
+import numpy as np, sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from oracle import oracle as O
+from haghighatshoarmuir2024_amd.runtime import Plan
+fs = 48000
+ker = O.stht_kernel(fs, 10e-3)
+b, a = O.bandpass(fs, [1000.0, 2000.0])
+p = Plan(7, ker, b, a, O.robust_width(fs, 2000.0), True)
+rng = np.random.RandomState(1)
+for T in (33, 700, 1500):
+    x = rng.randn(2, T, 7)
+    h = p.stht(p.to_device(x))[:, :, :T].cpu().numpy().transpose(0, 2, 1)
+    for i in range(2):
+        re, im = O.stht(x[i], ker)
+        assert np.array_equal(h[i][:, :7], re) and np.array_equal(h[i][:, 7:], im), T
+print("ok")
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MICLOC_STHT_VALU="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0 and b"ok" in r.stdout, r.stderr.decode()[-2000:]
