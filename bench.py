@@ -624,8 +624,9 @@ def run_xylo(args, rank, local_rank, world):
     pipe = runtime.StreamPipeline(plans)
 
     def body(pl):
-        hq = pl.stht(x)
-        _, raster = pl.bandpass_rzcc(hq, T, want_pre=False, want_spikes=True)
+        # STHT + band-pass + RZCC of the fused pipeline (Demo.raster_device): only the quadrature rows go through HBM, the encoder reads
+        # the in-phase ones -- the rolled input frames -- from x itself
+        raster = pl.snn_pipeline(x, want_spikes=True, want_power=False, stages=3)["spikes"]
         counts = net.run(raster, ternary=True)[1]  # the +/- split of spike_encoding happens in the kernel's staging loop
         idx = runtime.peak_location(counts, G, win)
         _, mae = runtime.doa_error(idx, d_list, d_doa, groups=groups, want_err=False)

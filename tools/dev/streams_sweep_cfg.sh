@@ -1,7 +1,7 @@
 #!/bin/bash
 # step time of one bench config against the number of HIP streams: usage bash tools/dev/streams_sweep_cfg.sh speech "2 3 4 6"
 for s in $2; do
-  python bench.py --config $1 --steps 4 --warmup 1 --repeats 3 --no-cpu-baseline --no-other-configs --streams $s > gpurun_out/ssc.log 2>&1
+  python bench.py --config $1 --steps ${3:-12} --warmup 3 --repeats 3 --no-cpu-baseline --no-other-configs --streams $s > gpurun_out/ssc.log 2>&1
   python - <<PY
 import json
 try:
