@@ -10,7 +10,7 @@ import csv, glob
 f = glob.glob("$OUT/trace/**/*kernel_trace.csv", recursive=True)[0]
 rows = [r for r in csv.DictReader(open(f))]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-big = [r for r in rows if (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) > 200000]
+big = [r for r in rows if (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) > int("${3:-200000}")]
 # everything that takes longer than 0.2 ms -> long.csv (relative ms); print the pipelined region: the launches between the
 # first and the last stht kernel of the timed steps
 t0 = int(big[0]["Start_Timestamp"])
