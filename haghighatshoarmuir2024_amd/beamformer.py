@@ -79,7 +79,16 @@ class Beamformer:
         sig_in_vec += noise
         return self.apply_to_signal(bf_mat=bf_mat, sig_in=sig_in_vec)
 
-    def design_from_template(self, template, doa_list, interference_removal=False, doa_batch=32):
+    def design_from_template(self, template, doa_list, interference_removal=False, doa_batch=32, svd="host"):
+        """Reference :73-192.  svd="host" (default): the M x M decompositions by LAPACK like the reference (its singular-vector
+        phases).  svd="device" (not with interference_removal): the leading singular vectors by the batched Jacobi kernel
+        (micloc_design_vectors_f64 on the real embedding [[A, B], [-B, A]] of cov = A + jB), equal to LAPACK's up to the unit phase
+        of each column -- the kernel makes the first component real and negative; |bf_mat^H bf_mat| and the beamformed power do not
+        depend on it."""
+        if svd not in ("host", "device"):
+            raise ValueError("svd must be 'host' or 'device'")
+        if svd == "device" and interference_removal:
+            raise ValueError("interference_removal needs the generalised eigenproblem of the host path (svd='host')")
         try:
             time_temp, sig_temp = template
         except Exception:
@@ -110,6 +119,19 @@ class Beamformer:
             cov_mat_list.extend(list(cov))
 
         bf_mat = []
+        if svd == "device":
+            import torch
+
+            if 2 * M > 128:
+                raise ValueError("svd='device' supports up to 64 microphones")
+            cov = np.asarray(cov_mat_list)
+            A, B = cov.real, cov.imag
+            emb = np.concatenate([np.concatenate([A, B], axis=2), np.concatenate([-B, A], axis=2)], axis=1)  # [n, 2M, 2M]
+            dev = runtime.require_gpu(self.device)
+            out = torch.empty((2 * M, len(cov_mat_list)), dtype=torch.float64, device=dev)
+            runtime.design_vectors(torch.from_numpy(np.ascontiguousarray(emb)).to(dev), True, out, 0)
+            W = out.cpu().numpy()
+            return W[:M] + 1j * W[M:], cov_mat_list
         if not interference_removal:
             for cov_mat in cov_mat_list:
                 U, _, _ = np.linalg.svd(cov_mat)

@@ -141,6 +141,16 @@ def test_beamformer_class_surface(cfg2):
     np.testing.assert_allclose(np.asarray(covs), z["cov_list"][:5], rtol=0, atol=1e-11)
     phase = np.sum(np.conj(W) * z["bf_mat"][:, :5], axis=0)
     np.testing.assert_allclose(W * (phase / np.abs(phase)), z["bf_mat"][:, :5], rtol=0, atol=1e-8)
+    # the same design with the decompositions on the device (Jacobi on the real embedding of the Hermitian covariance): the
+    # reference's columns up to their unit phase; the kernel's convention is "first component real and negative"
+    Wd, covs_d = bf.design_from_template((t, s), z["doa_list"][:5], svd="device")
+    np.testing.assert_allclose(np.asarray(covs_d), z["cov_list"][:5], rtol=0, atol=1e-11)
+    phase = np.sum(np.conj(Wd) * z["bf_mat"][:, :5], axis=0)
+    np.testing.assert_allclose(np.abs(phase), 1.0, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(Wd * (phase / np.abs(phase)), z["bf_mat"][:, :5], rtol=0, atol=1e-8)
+    assert np.all(Wd[0].real < 0) and np.max(np.abs(Wd[0].imag)) < 1e-12
+    with pytest.raises(ValueError):
+        bf.design_from_template((t, s), z["doa_list"][:2], svd="device", interference_removal=True)
 
 
 def test_beamformer_design_interference_removal():
