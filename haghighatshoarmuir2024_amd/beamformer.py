@@ -6,7 +6,8 @@ reference method                      -> what runs here
                                          form of conj(bf_mat) on the fp64 matrix cores
   apply_to_template    :194-258       -> host synthesis (same np.random draws) + the above
   design_from_template :73-192        -> STHT and the complex covariance (micloc_planar_gram_f64) on the GPU per DoA; the M x M
-                                         SVD / generalised eigh on the host (LAPACK, like the reference: its phases)
+                                         SVD / generalised eigh on the host (LAPACK, like the reference: its phases), or --
+                                         svd="device" -- the batched Jacobi kernel (micloc_design_vectors_f64)
   localize_batch (new)                -> power [B,G], arg-max [B] for a batch of trials, no T x G temporary
 """
 from numbers import Number
