@@ -232,6 +232,29 @@ __global__ __launch_bounds__(XP_WAVES * 64) void xylo_lif_pk_kernel(const int8_t
     };
 
     short2_t cnt = {0, 0};
+    // The second-spike test (v >= th again after the reset: two compares, a scalar or and a branch per step) is not run per step
+    // in whole tiles: the steps only keep the largest membrane word they left behind, one test per tile decides, and a tile in
+    // which some step did need the exact sequence is walked again from its saved state with the per-step test (`step` below).
+    short2_t vmx = {-32768, -32768};
+    auto step_fast = [&](int in_word, int t) {
+        short2_t i2 = xp_decay(isyn, ds);
+        short2_t v2 = xp_decay(vmem, dm);
+        i2 = __builtin_elementwise_add_sat(i2, xp_s2(in_word));
+        v2 = __builtin_elementwise_add_sat(v2, i2);
+        const short2_t d = __builtin_elementwise_sub_sat(v2, th);
+        const short2_t fifteen = {15, 15};
+        const short2_t m = d >> fifteen;  // all ones: below threshold
+        const int vw = (xp_i(m) & xp_i(v2)) | (~xp_i(m) & xp_i(d));
+        cnt += m;
+        vmx = __builtin_elementwise_max(vmx, xp_s2(vw));
+        if constexpr (WANT_OUT) {
+            const size_t row = (size_t)t * N;
+            if (act0) ob[row + n0] = (uint8_t)(1 + m.x);
+            if (act1) ob[row + n1] = (uint8_t)(1 + m.y);
+        }
+        isyn = i2;
+        vmem = xp_s2(vw);
+    };
     auto step = [&](int in_word, int t) {
         short2_t i2 = xp_decay(isyn, ds);
         short2_t v2 = xp_decay(vmem, dm);
@@ -328,10 +351,24 @@ __global__ __launch_bounds__(XP_WAVES * 64) void xylo_lif_pk_kernel(const int8_t
             for (int t4 = 0; t4 < 4; ++t4) in4[t4] = cw[64 * t4];
             if (i + 1 < ntile) produce(i + 1);  // (overwrites the slice: after the reads above, in program order)
             if (jn == 16) {
+                const short2_t isyn_s = isyn, vmem_s = vmem, cnt_s = cnt;
+                vmx = short2_t{-32768, -32768};
 #pragma unroll
                 for (int t4 = 0; t4 < 4; ++t4) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) step(in4[t4][r], t0 + 16 * i + 4 * t4 + r);
+                    for (int r = 0; r < 4; ++r) step_fast(in4[t4][r], t0 + 16 * i + 4 * t4 + r);
+                }
+                const short2_t fifteen = {15, 15};
+                const short2_t below = __builtin_elementwise_sub_sat(vmx, th) >> fifteen;  // all ones: never reached th again
+                if (__builtin_expect(__any(xp_i(below) != -1), 0)) {
+                    isyn = isyn_s;
+                    vmem = vmem_s;
+                    cnt = cnt_s;
+#pragma unroll
+                    for (int t4 = 0; t4 < 4; ++t4) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) step(in4[t4][r], t0 + 16 * i + 4 * t4 + r);
+                    }
                 }
             } else {  // the last steps of the signal
                 for (int j = 0; j < jn; ++j) {
