@@ -168,7 +168,7 @@ def test_fused_synthesis_other_shapes():
     fs = 48_000
     rng = np.random.RandomState(5)
     ep = torch.full((1,), 9, dtype=torch.int32, device="cuda")
-    shapes = [(4.5e-2, 2, 2500, 3), (4.5e-2, 3, 4799, 2), (4.5e-2, 64, 700, 2), (4.5e-2, 300, 300, 2), (4.5e-2, 7, 5, 3), (4.5e-2, 7, 63, 2),
+    shapes = [(4.5e-2, 1, 901, 2), (4.5e-2, 2, 2500, 3), (4.5e-2, 3, 4799, 2), (4.5e-2, 64, 700, 2), (4.5e-2, 300, 300, 2), (4.5e-2, 7, 5, 3), (4.5e-2, 7, 63, 2),
               (3.0, 7, 3000, 2), (0.5, 16, 2100, 2)]
     for radius, M, T, B in shapes:
         geo = CenterCircularArray(radius, M)
