@@ -198,7 +198,7 @@ def build_workload(args, rank, device):
         plan.set_encoder_chunk(args.encoder_chunk)
     return dict(beamf=beamf, plan=plan, x=x, doa=torch.from_numpy(doa).to(device), doa_list=torch.from_numpy(doa_list).to(device),
                 bf_mat=bf_mat, nir=nir, snr_groups=groups, fs=fs, encoder_chunk=args.encoder_chunk,
-                template=(time_test, sig_test), snr_db=snr_db, rank=rank, design_seconds=t_design)
+                template=(time_test, sig_test), snr_db=snr_db, rank=rank, design_seconds=t_design, freq_range=freq_range)
 
 
 def make_step(wl, nstreams, variants=True):
@@ -538,6 +538,93 @@ def api_per_call_block(device, calls=40):
             "reference_ms_per_trial": "24.7-27.5 (8 vCPU Xeon 2.1 GHz, SURVEY 6)",
             "note": "one trial per call exactly as the script's loop does it: host synthesis + host MT19937 noise (reference draw order), H2D, "
                     "STHT -> RZCC -> LIF -> beamforming with y stored, D2H of T x G, power / arg-max in NumPy; PCIe- and host-bound, never `value`"}
+
+
+def beamformer_c128_block(wl, args):
+    """SURVEY 8a row a11 -- the NON-spiking Beamformer (micloc/beamformer.py:260-292: STHT, band-pass, sig @ conj(bf_mat), the dense
+    steering-matrix x analytic-signal contraction) on the headline's batch and grid: `Beamformer.localize_batch`'s pipeline
+    (power / arg-max, no T x G temporary) captured per stream like the headline, the contraction kernel alone (HIP events), and the
+    API-faithful form that stores apply_to_signal's T x G complex128 array (16 G bytes per frame: HBM-write bound)."""
+    import torch
+
+    from haghighatshoarmuir2024_amd import runtime
+    from haghighatshoarmuir2024_amd.beamformer import Beamformer
+
+    x = wl["x"]
+    B, T, M = x.shape
+    G = wl["bf_mat"].shape[1]
+    dev = x.device
+    sb = wl["beamf"]
+    bm = Beamformer(geometry=sb.geometry, kernel_duration=sb.kernel_duration, freq_range=wl["freq_range"], fs=sb.fs, device=dev)
+    doa_list = np.linspace(-np.pi, np.pi, G)
+    t0 = time.perf_counter()
+    bf_mat, _ = bm.design_from_template(chirp_template(sb.fs, wl["freq_range"]), doa_list, svd="device")
+    torch.cuda.synchronize()
+    t_design = time.perf_counter() - t0
+    b, a = bm.bandpass_filter
+    plans = [runtime.Plan(M, bm.kernel, b, a, 1, False, device=dev) for _ in range(max(1, args.streams))]
+    for p in plans:
+        p.set_bf_mat(bf_mat)
+    pipe = runtime.StreamPipeline(plans)
+    replay = pipe.capture(lambda plan: plan.beamformer_pipeline(x, want_y=False, want_power=True))
+
+    fn = replay  # (timed below with THIS pipeline's streams in the bracket, single rank: the variant is reported at N = 1 only)
+
+    pipe.synchronize()
+    for _ in range(args.warmup):
+        fn()
+    times = []
+    for _ in range(3):
+        pipe.synchronize()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = fn()
+        pipe.synchronize()
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    dt = float(np.median(times))
+
+    def ev(fn_, iters=10, inner=2):
+        fn_()
+        torch.cuda.synchronize()
+        e0 = [torch.cuda.Event(enable_timing=True) for _ in range(iters)]
+        e1 = [torch.cuda.Event(enable_timing=True) for _ in range(iters)]
+        for i in range(iters):
+            e0[i].record()
+            for _ in range(inner):
+                fn_()
+            e1[i].record()
+        torch.cuda.synchronize()
+        return float(np.mean([a_.elapsed_time(b_) for a_, b_ in zip(e0, e1)])) / inner
+
+    plan = plans[0]
+    h = plan.stht(x)
+    pre, _ = plan.bandpass_rzcc(h, T, want_pre=True, want_spikes=False)
+    del h
+    o = plan.beamform_c128(pre, T, want_y=False, want_power=True)
+    ms_k = ev(lambda: plan.beamform_c128(pre, T, out=o))
+    same = bool(torch.equal(o["argmax"], out["argmax"]))
+    flop = 8 * M * G + 4 * G
+    ach = B * T * flop / (ms_k * 1e-3) / 1e12
+    res = {"ms_per_step": dt / args.steps * 1e3, "value": B * T * args.steps / dt, "unit": "frames/s",
+           "workload": f"Beamformer.localize_batch: {B} trials x {T} frames x {M} mics, {G}-DoA complex bf_mat (designed on the device, {t_design:.2f} s), "
+                       f"STHT -> band-pass -> sig @ conj(bf_mat) -> mean|y|^2 -> arg-max; {len(plans)} HIP streams, graphs",
+           "roofline": {"kernel": "beamform_wsc_kernel", "bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": ach / FP64_MFMA_PEAK_TFLOPS, "avg_launch_ms": ms_k, "flop_per_frame": flop,
+                        "note": "8 M G (complex multiply-adds of sig @ conj(bf_mat)) + 4 G (|y|^2) flop per frame; HIP events around the launch + power_argmax_kernel"},
+           "argmax_stage_equal_to_pipeline": same}
+    # API-faithful: y [B, T, G] complex128 stored (apply_to_signal's return value), in batches that fit 24 GB
+    By = max(1, min(B, int(24e9 // (T * G * 16))))
+    oy = plan.beamform_c128(pre[:By], T, want_y=True, want_power=False)
+    ms_y = ev(lambda: plan.beamform_c128(pre[:By], T, out=oy), iters=5, inner=1)
+    gbs = By * T * (16 * G + 8 * 2 * M) / (ms_y * 1e-3) / 1e9
+    res["y_stored"] = {"ms_per_launch": ms_y, "trials": By, "frames_per_s": By * T / (ms_y * 1e-3), "bytes_per_frame": 16 * G + 16 * M,
+                       "roofline": {"kernel": "beamform_wsc_kernel<.., WANT_Y>", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                    "frac": gbs / HBM_PEAK_GBS},
+                       "note": "apply_to_signal's T x G complex128 result written to HBM (16 G bytes per frame) + the planar input read (16 M)"}
+    del oy, pre
+    return res
 
 
 def other_configs_block(args):
@@ -907,6 +994,8 @@ def run(args):
                              "note": "compute-bound path (about 300 flop/B): small by construction, the binding roof is in `roofline`"},
             "variants": {"covariance_power": cov_variant, "f32_mfma_beamform": f32_variant},
         }
+        if noisy and M * 2 <= 16:
+            result["variants"]["beamformer_c128"] = beamformer_c128_block(wl, args)
         if noisy and group_size == 1 and not args.no_other_configs:
             torch.cuda.synchronize()
             result["mae_ref"] = reference_mae_block(device)

@@ -415,10 +415,10 @@ int micloc_beamform_c128_f64(const micloc_plan *p, const double *pre, int B, int
     const bool want_power = power || argmax;
     if (want_power && bad_ws(ws, ws_bytes, beamform_partial_bytes(B, T, Gp))) return MICLOC_ERR_WORKSPACE;
     double *partial = want_power ? reinterpret_cast<double *>(ws) : nullptr;
-    HIP_TRY(launch_planar_beamform(p->W, pre, B, T, Ts, y, 1, partial, (hipStream_t)stream));
+    int nch = 0;
+    HIP_TRY(launch_planar_beamform(p->W, pre, B, T, Ts, y, 1, partial, (hipStream_t)stream, &nch));
     if (want_power)
-        HIP_TRY(launch_power_argmax(partial, B, T, beamform_nchunks_ct(T, p->W.CT), Gp, p->G_out, 1, Gp / 2, power, argmax,
-                                    (hipStream_t)stream));
+        HIP_TRY(launch_power_argmax(partial, B, T, nch, Gp, p->G_out, 1, Gp / 2, power, argmax, (hipStream_t)stream));
     return MICLOC_OK;
 }
 
@@ -481,9 +481,9 @@ int micloc_beamformer_pipeline_f64(const micloc_plan *p, const double *x, int B,
     const int Gp = 16 * p->W.GT;
     const bool want_power = power || argmax;
     double *partial = want_power ? reinterpret_cast<double *>(base + w.partial) : nullptr;
-    HIP_TRY(launch_planar_beamform(p->W, pre, B, T, Ts, y, 1, partial, st));
-    if (want_power)
-        HIP_TRY(launch_power_argmax(partial, B, T, beamform_nchunks_ct(T, p->W.CT), Gp, p->G_out, 1, Gp / 2, power, argmax, st));
+    int nch = 0;
+    HIP_TRY(launch_planar_beamform(p->W, pre, B, T, Ts, y, 1, partial, st, &nch));
+    if (want_power) HIP_TRY(launch_power_argmax(partial, B, T, nch, Gp, p->G_out, 1, Gp / 2, power, argmax, st));
     return MICLOC_OK;
 }
 

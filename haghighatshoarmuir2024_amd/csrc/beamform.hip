@@ -852,6 +852,231 @@ static hipError_t launch_ws(const BeamformW &W, const NeuronTab &nt, const int8_
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// The complex Beamformer's contraction  y = h @ conj(bf_mat)  (micloc/beamformer.py:290) in the bf_mat-stationary form.
+// Real stacked form: [h_re | h_im] (T x 2M) @ [Wre; Wim | -Wim; Wre] (2M x 2 Ghp): columns [0, Ghp) are Re y, columns
+// [Ghp, 2 Ghp) Im y -- 8 M G flop per frame, exactly the complex product's count.  No LIF: the planar band-passed rows
+// [B][2M][Ts] are read as MFMA A-fragments straight from HBM (lane l of k-step k: channel 4k + (l>>4), frame l&15 -- four
+// 128-byte segments per load) and parked in LDS in fragment order; from there on it is beamform_ws_kernel's stage 2: a
+// wave keeps the fragments of up to three DoA tiles in registers and walks the 16 time tiles of the chunk, then takes
+// its next three tiles (G = 360 complex: 46 tiles, two passes) -- 32 KB of LDS, <= 80 VGPRs, three workgroups per CU.
+// Same order of the channel sum as beamform_kernel (k-steps ascending, the last KV channels as plain FMAs behind them).
+//
+// With y stored (apply_to_signal's T x G complex128 array, 16 G bytes per frame: HBM-write bound) a wave owns PAIRS of
+// tiles (Re and Im of the same 16 DoAs), two pairs per pass = 256 complex columns per workgroup and pass; after every
+// time tile the workgroup assembles 8 rows x 256 interleaved (re, im) values in LDS and every wave copies one row segment
+// (4 KB contiguous) out -- whole-cache-line stores whatever G is (tools/store_bw.hip).
+// ---------------------------------------------------------------------------------------------------------------
+template <int TILES, int KM, int KV, bool FLAT>
+__device__ __forceinline__ void wsc_stage2_y(const double *Vl, const double *__restrict__ Wp, int GT, int Gc, int wv, int l, int ntile,
+                                             int nrows, double2 *stg, double2 *__restrict__ yb, double *__restrict__ pout)
+{
+    const int Gp = 16 * GT, GTc = GT >> 1;
+    const int lc = l & 15, q = l >> 4;
+    constexpr int KVD = KV > 0 ? KV : 1;
+    for (int p0 = 0; 16 * p0 < GTc; ++p0) {  // pass: complex DoA tiles 16 p0 .. 16 p0 + 15 (the same trip count in every wave)
+        const int g0 = 256 * p0;
+        const int ncol = Gc - g0 < 256 ? Gc - g0 : 256;
+        double Wf[2][2][KM], Wv[2][2][KVD];
+        bool own[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int ct = 16 * p0 + wv + BF_WAVES * j;
+            own[j] = ct < GTc;  // (wave-uniform; a wave without a pair multiplies a clamped one and stores nothing)
+#pragma unroll
+            for (int part = 0; part < 2; ++part) {
+                const double *wp = Wp + 16 * ((own[j] ? ct : GTc - 1) + part * GTc) + lc;
+#pragma unroll
+                for (int k = 0; k < KM; ++k) Wf[j][part][k] = wp[(size_t)(4 * k + q) * Gp];
+#pragma unroll
+                for (int i = 0; i < KV; ++i) Wv[j][part][i] = wp[(size_t)(4 * KM + i) * Gp];
+            }
+        }
+        double sq[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+        for (int t = 0; t < ntile; ++t) {
+            double V[KM];
+            const double *p = Vl + (size_t)t * 256 + l;
+#pragma unroll
+            for (int k = 0; k < KM; ++k) V[k] = p[64 * k];
+            double4_t acc[2][2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int part = 0; part < 2; ++part) acc[j][part] = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int k = 0; k < KM; ++k)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int part = 0; part < 2; ++part)
+                        acc[j][part] = __builtin_amdgcn_mfma_f64_16x16x4f64(V[k], Wf[j][part][k], acc[j][part], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < KV; ++i) {
+                double Vv[4];
+                const double *pv = Vl + (size_t)t * 256 + 64 * KM + q + 16 * i;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Vv[r] = pv[4 * r];
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int part = 0; part < 2; ++part)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[j][part][r] = __builtin_fma(Vv[r], Wv[j][part][i], acc[j][part][r]);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int part = 0; part < 2; ++part) sq[j][part] = __builtin_fma(acc[j][part][r], acc[j][part][r], sq[j][part]);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {  // rows 8h .. 8h + 7 of the time tile (accumulator rows q + 4r, r = 2h, 2h + 1)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int col = 16 * (wv + BF_WAVES * j) + lc;
+                    if (own[j] && col < ncol) {
+#pragma unroll
+                        for (int rr = 0; rr < 2; ++rr) {
+                            double2 v;
+                            v.x = acc[j][0][2 * h + rr];
+                            v.y = acc[j][1][2 * h + rr];
+                            stg[(q + 4 * rr) * ncol + col] = v;
+                        }
+                    }
+                }
+                __syncthreads();
+                if constexpr (FLAT) {
+                    // (G <= 256) one pass covers every column: the 8 rows are ONE contiguous block of y, copied front to back
+                    const int r0 = 16 * t + 8 * h;
+                    const int n = (nrows - r0 < 8 ? (nrows - r0 > 0 ? nrows - r0 : 0) : 8) * Gc;
+                    double2 *yo = yb + (size_t)r0 * Gc;
+                    for (int e = wv * 64 + l; e < n; e += BF_THREADS) yo[e] = stg[e];
+                } else {
+                    const int trow = 16 * t + 8 * h + wv;  // wave wv copies row wv of the block: one contiguous segment
+                    if (trow < nrows) {
+                        double2 *yo = yb + (size_t)trow * Gc + g0;
+                        const double2 *so = stg + wv * ncol;
+                        for (int c = l; c < ncol; c += 64) yo[c] = so[c];
+                    }
+                }
+                __syncthreads();  // the block is on its way: the next half tile may overwrite it
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int part = 0; part < 2; ++part) {
+                const double s = row_sum4(sq[j][part]);
+                const int ct = 16 * p0 + wv + BF_WAVES * j;
+                if (pout && l < 16 && own[j]) pout[16 * (ct + part * GTc) + l] = s;
+            }
+    }
+}
+
+template <int KM, int KV, bool WANT_Y, bool FLAT = false>
+__global__ __launch_bounds__(BF_THREADS, WANT_Y ? 4 : 6) void beamform_wsc_kernel(const double *__restrict__ pre,
+                                                                                   const double *__restrict__ Wp, int GT, int C, int T,
+                                                                                   int Ts, double *__restrict__ partial, int Gc,
+                                                                                   double *__restrict__ y)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NT = 2;                   // 16-frame tiles per wave
+    constexpr int CH = BF_WAVES * NT * 16;  // frames per workgroup (256)
+    constexpr int TILES = CH / 16;
+    constexpr int KF = KM + (KV > 0 ? 1 : 0);  // fragments per time tile (the last one holds the KV tail channels)
+    const int Gp = 16 * GT;
+    const int tid = threadIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l = tid & 63;
+    const int lc = l & 15;
+    const int q = l >> 4;
+    const int chunk = blockIdx.x, b = blockIdx.y;
+    const int nchunks = gridDim.x;
+    const int cs = chunk * CH;
+    double *Vl = reinterpret_cast<double *>(smem);  // [TILES][4][64]: fragment order
+
+    // ---- stage 1: this wave's two time tiles as A-fragments, HBM -> registers -> LDS ------------------------------
+    {
+        const double *pb = pre + (size_t)b * C * Ts;
+        double v[NT][KF];
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) {
+            const int t = cs + (wv * NT + tt) * 16 + lc;
+#pragma unroll
+            for (int k = 0; k < KF; ++k) {
+                const int c = 4 * k + q;
+                v[tt][k] = pb[(size_t)(c < C ? c : C - 1) * Ts + (t < T ? t : T - 1)];  // (clamped: unconditional loads)
+            }
+        }
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) {
+            const int t = cs + (wv * NT + tt) * 16 + lc;
+#pragma unroll
+            for (int k = 0; k < KF; ++k) {
+                const int c = 4 * k + q;
+                Vl[(size_t)(wv * NT + tt) * 256 + 64 * k + l] = (t < T && c < C) ? v[tt][k] : 0.0;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- stage 2 ---------------------------------------------------------------------------------------------------
+    int ntile = (T - cs + 15) >> 4;
+    ntile = ntile > TILES ? TILES : ntile;
+    double *pout = partial ? partial + ((size_t)b * nchunks + chunk) * Gp : nullptr;
+    if constexpr (WANT_Y) {
+        double2 *stg = reinterpret_cast<double2 *>(Vl + TILES * 256);  // 8 rows x <= 256 complex columns
+        wsc_stage2_y<TILES, KM, KV, FLAT>(Vl, Wp, GT, Gc, wv, l, ntile, T - cs, stg, reinterpret_cast<double2 *>(y) + ((size_t)b * T + cs) * Gc,
+                                    pout);
+    } else {
+        const int ntl = (GT - wv + BF_WAVES - 1) / BF_WAVES;  // DoA tiles of this wave: wv, wv + 8, ... (wave-uniform)
+        for (int j0 = 0; j0 < ntl; j0 += 3) {
+            const int n = ntl - j0;
+            if (n >= 3)
+                ws_stage2_kv<3, TILES, KM, KV, true>(Vl, Wp, Gp, wv, l, ntile, pout, j0);
+            else if (n == 2)
+                ws_stage2_kv<2, TILES, KM, KV, true>(Vl, Wp, Gp, wv, l, ntile, pout, j0);
+            else
+                ws_stage2_kv<1, TILES, KM, KV, true>(Vl, Wp, Gp, wv, l, ntile, pout, j0);
+        }
+    }
+}
+
+constexpr int WSC_CHUNK = BF_WAVES * 2 * 16;
+
+static bool wsc_eligible(const BeamformW &W) { return W.CT == 1 && W.complex_pairs && (W.GT & 1) == 0; }
+
+template <int KM, int KV>
+static hipError_t launch_wsc_k(const BeamformW &W, const double *pre, int B, int T, int Ts, double *y, double *partial,
+                               hipStream_t stream)
+{
+    const size_t lds = (size_t)16 * 256 * sizeof(double) + (y ? (size_t)8 * 256 * sizeof(double2) : 0);
+    dim3 grid((T + WSC_CHUNK - 1) / WSC_CHUNK, B), block(BF_THREADS);
+    if (y && W.G / 2 <= 256)
+        hipLaunchKernelGGL((beamform_wsc_kernel<KM, KV, true, true>), grid, block, lds, stream, pre, W.Wp, W.GT, W.C, T, Ts, partial, W.G / 2, y);
+    else if (y)
+        hipLaunchKernelGGL((beamform_wsc_kernel<KM, KV, true>), grid, block, lds, stream, pre, W.Wp, W.GT, W.C, T, Ts, partial, W.G / 2, y);
+    else
+        hipLaunchKernelGGL((beamform_wsc_kernel<KM, KV, false>), grid, block, lds, stream, pre, W.Wp, W.GT, W.C, T, Ts, partial, W.G / 2, y);
+    return hipGetLastError();
+}
+
+static hipError_t launch_wsc(const BeamformW &W, const double *pre, int B, int T, int Ts, double *y, double *partial, hipStream_t stream)
+{
+#define WSC_K(KM_, KV_) return launch_wsc_k<KM_, KV_>(W, pre, B, T, Ts, y, partial, stream)
+    switch (W.C) {  // (2 x microphones: even)
+        case 2: case 4: WSC_K(1, 0);
+        case 6: WSC_K(1, 2);
+        case 8: WSC_K(2, 0);
+        case 10: WSC_K(2, 2);
+        case 12: WSC_K(3, 0);
+        case 14: WSC_K(3, 2);
+        case 16: WSC_K(4, 0);
+        default: return hipErrorInvalidValue;
+    }
+#undef WSC_K
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Many-channel variant (C > 64, e.g. the 64-microphone stress configuration): bf_mat no longer fits in LDS and the
 // membrane fragments of 4 time tiles no longer fit in registers.  Workgroup = 8 waves x 2 time tiles (256 frames);
 // the membrane fragments stay in registers (2 x CT x 4 doubles per lane), bf_mat is streamed through LDS in
@@ -1162,8 +1387,13 @@ int lif_beamform_chunk_frames(const BeamformW &W, const NeuronTab &nt)
 }
 
 hipError_t launch_planar_beamform(const BeamformW &W, const double *pre, int B, int T, int Ts, double *y,
-                                  int y_complex, double *partial, hipStream_t stream)
+                                  int y_complex, double *partial, hipStream_t stream, int *nchunks)
 {
+    if (y_complex && wsc_eligible(W)) {  // up to 8 microphones: the bf_mat-stationary form
+        *nchunks = (T + WSC_CHUNK - 1) / WSC_CHUNK;
+        return launch_wsc(W, pre, B, T, Ts, y, partial, stream);
+    }
+    *nchunks = beamform_nchunks_ct(T, W.CT);
     return dispatch_ct<false>(W, nullptr, nullptr, pre, B, T, Ts, y, y_complex, partial, stream);
 }
 

@@ -88,8 +88,9 @@ size_t beamform_partial_bytes(int B, int T, int Gp);
 // *nchunks: number of partial-sum rows per trial the chosen kernel wrote (input of launch_power_argmax)
 hipError_t launch_lif_beamform(const BeamformW &W, const NeuronTab &nt, const int8_t *spikes, int B, int T,
                                double *y, double *partial, hipStream_t stream, int *nchunks);
+// *nchunks: partial-sum rows per trial the chosen kernel wrote
 hipError_t launch_planar_beamform(const BeamformW &W, const double *pre, int B, int T, int Ts, double *y,
-                                  int y_complex, double *partial, hipStream_t stream);
+                                  int y_complex, double *partial, hipStream_t stream, int *nchunks);
 hipError_t launch_power_argmax(const double *partial, int B, int T, int nchunks, int Gp, int G, int complex_pairs,
                                int Ghalf_pad, double *power, int32_t *argmax, hipStream_t stream);
 int beamform_nchunks(int T);

@@ -253,6 +253,22 @@ class Plan:
         )
         return dict(y=y, power=power, argmax=argmax)
 
+    def beamform_c128(self, pre, T, want_y=False, want_power=True, out=None):
+        """The contraction stage of the complex Beamformer alone (micloc_beamform_c128_f64): planar band-passed rows
+        pre [B, 2M, Ts] -> y [B, T, G] complex128 and / or power [B, G], argmax [B].  `out` reuses a previous result dict."""
+        torch = _torch()
+        B, C, Ts = pre.shape
+        G = self.G
+        if out is None:
+            out = dict(y=torch.empty((B, T, G), dtype=torch.complex128, device=self.device) if want_y else None,
+                       power=torch.empty((B, G), dtype=torch.float64, device=self.device) if want_power else None,
+                       argmax=torch.empty((B,), dtype=torch.int32, device=self.device) if want_power else None)
+        nbytes = self.lib.micloc_lif_beamform_workspace_bytes(self.handle, B, T)
+        ws = self.ws.get(nbytes)
+        _lib.check(self.lib.micloc_beamform_c128_f64(self.handle, _ptr(pre), B, T, Ts, _ptr(out["y"]), _ptr(out["power"]), _ptr(out["argmax"]),
+                                                     _ptr(ws), nbytes, _stream(self.device)), "beamform_c128")
+        return out
+
     # ---- single stages (used by tests and by Demo.spike_encoding-style callers) --------------------------
     def stht(self, x):
         torch = _torch()

@@ -352,6 +352,33 @@ def test_many_mic_complex_beamformer(torch):
         assert int(out["argmax"][i]) == ref["argmax"]
 
 
+@pytest.mark.parametrize("M,G,T", [(1, 5, 40), (2, 300, 530), (3, 17, 257), (4, 513, 300), (5, 64, 1000), (6, 100, 33), (7, 449, 700),
+                                   (7, 57, 4799), (8, 360, 512), (7, 256, 255), (7, 257, 17)])
+def test_complex_beamformer_bf_stationary_shapes(torch, M, G, T):
+    """beamform_wsc_kernel (up to 8 microphones): every k-step / vector-tail split (2M = 2 ... 16 channels), one to several DoA passes,
+    ragged recordings, y stored (flat blocks for G <= 256, row segments above) and power only -- vs the oracle's
+    Beamformer.apply_to_signal (micloc/beamformer.py:260-292)."""
+    from haghighatshoarmuir2024_amd.runtime import Plan
+
+    fs = 48_000
+    rng = np.random.RandomState(100 * M + G)
+    ker = O.stht_kernel(fs, 10e-3)
+    b, a = O.bandpass(fs, [1000.0, 2000.0])
+    W = rng.randn(M, G) + 1j * rng.randn(M, G)
+    x = rng.randn(3, T, M)
+    p = Plan(M, ker, b, a, 1, False)
+    p.set_bf_mat(W)
+    xd = p.to_device(x)
+    out = p.beamformer_pipeline(xd, want_y=True)
+    only = p.beamformer_pipeline(xd, want_y=False)
+    assert torch.equal(out["power"], only["power"]) and torch.equal(out["argmax"], only["argmax"])
+    for i in range(3):
+        ref = O.beamformer_chain(x[i], ker, b, a, W)
+        np.testing.assert_allclose(out["y"][i].cpu().numpy(), ref["y"], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(out["power"][i].cpu().numpy(), ref["power"], rtol=1e-12)
+        assert int(out["argmax"][i]) == ref["argmax"]
+
+
 @pytest.mark.parametrize("T", [2, 3, 16, 17, 31, 100, 511, 512, 513, 1025])
 def test_pipeline_short_and_boundary_lengths(plan2, cfg2, T):
     """Ragged lengths around every tile size in the kernels (16-step RZCC tiles, 512-frame beamforming chunks)."""
