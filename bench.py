@@ -948,8 +948,8 @@ def run(args):
             # launch size of beamform_ws_kernel: 256-frame chunks x 512 work-items per trial
             traffic, traffic_src = traffic_from_profiles(KERNEL_SYMBOL[dom], -(-T // 256) * 512 * B, args.pmc_summary)
         sym = KERNEL_SYMBOL.get(dom, dom)
-        if dom == "beamform_kernel" and C > 64:
-            sym = "beamform_slab_kernel"
+        if dom == "beamform_kernel" and C > 16:
+            sym = "beamform_gen_kernel"
         roof = dict(kernel=sym, bound="mfma", achieved=achieved, peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                     frac=achieved / FP64_MFMA_PEAK_TFLOPS, traffic=traffic)
         if dom == "stht_kernel":

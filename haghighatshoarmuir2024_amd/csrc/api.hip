@@ -262,7 +262,7 @@ int micloc_plan_set_neuron_kernel(micloc_plan *p, const double *nir, int n)
 {
     if (!p || !nir || n < 1) return MICLOC_ERR_INVALID;
     const int NK = (n + 15 + 3) / 4;
-    if ((size_t)(BF_CHUNK + 4 * NK) * 16 * pad_ct(p->C) > 96 * 1024) return MICLOC_ERR_INVALID;  // spike tile must fit in LDS
+    if ((size_t)(256 + 4 * NK) * 16 * pad_ct(p->C) > 96 * 1024) return MICLOC_ERR_INVALID;  // the int8 spike tile of a sub-chunk must fit in LDS
     std::vector<double> tab((size_t)4 * NK + 16, 0.0);
     for (int k = 0; k < n; ++k) tab[(size_t)k + 15] = nir[k];
     DeviceGuard guard(p->device);
@@ -304,10 +304,10 @@ int micloc_plan_set_bf_mat(micloc_plan *p, const double *W, int C, int G)
     if (C != p->C) return MICLOC_ERR_SHAPE;
     const int CT = pad_ct(C);
     if (CT > 8) return MICLOC_ERR_INVALID;
-    int GT = (G + 15) / 16;
-    if (CT > 4) GT = (GT + 1) & ~1;  // the many-channel kernel streams bf_mat in slabs of two DoA tiles
+    const int GT = (G + 15) / 16;
     const int Gp = 16 * GT;
-    std::vector<double> Wp((size_t)16 * CT * Gp, 0.0);
+    // (+16: the general kernel streams bf_mat in slabs of two DoA tiles and reads a whole slab even when the last one is half empty)
+    std::vector<double> Wp((size_t)16 * CT * Gp + 16, 0.0);
     for (int c = 0; c < C; ++c)
         for (int g = 0; g < G; ++g) Wp[(size_t)c * Gp + g] = W[(size_t)c * G + g];
     return set_W(p, Wp, CT, GT, C, G, 0, G);
@@ -323,7 +323,7 @@ int micloc_plan_set_bf_mat_c128(micloc_plan *p, const double *Wre, const double 
     const int Ghp = 16 * ((G + 15) / 16);  // Gp / 16 is even by construction
     const int Gp = 2 * Ghp;
     // (hr + j hi)(wr - j wi):  re = [hr hi] . [wr; wi]   im = [hr hi] . [-wi; wr]
-    std::vector<double> Wp((size_t)16 * CT * Gp, 0.0);
+    std::vector<double> Wp((size_t)16 * CT * Gp + 16, 0.0);
     for (int m = 0; m < M; ++m)
         for (int g = 0; g < G; ++g) {
             const double wr = Wre[(size_t)m * G + g], wi = Wim[(size_t)m * G + g];

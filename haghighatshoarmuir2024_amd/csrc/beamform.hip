@@ -21,8 +21,8 @@
 //   beamform_ws_kernel    bf_mat fragments in registers, membrane fragments parked in LDS   (<= 16 channels, <= 512
 //                         DoAs: the sweep; the fastest form, see its header for why; with y stored, the rows leave
 //                         through an LDS block as whole-workgroup contiguous stores)
-//   beamform_kernel       membrane fragments of 4 time tiles in registers, bf_mat in LDS      (<= 64 channels)
-//   beamform_slab_kernel  membrane fragments in registers, bf_mat streamed through LDS slabs  (> 64 channels)
+//   beamform_wsc_kernel   the same ownership for the complex Beamformer's planar source (<= 8 microphones, any DoA count)
+//   beamform_gen_kernel   membrane fragments in registers, bf_mat streamed through LDS slabs  (everything else, <= 128 channels)
 //
 // Summation order (== oracle): LIF over past samples in chronological order (tau ascending),
 // beamforming over channels ascending; both as fused multiply-add chains starting from +0.
@@ -33,6 +33,7 @@
 namespace micloc {
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
+typedef double double2_t __attribute__((ext_vector_type(2)));
 
 constexpr int BF_THREADS = BF_WAVES * 64;
 
@@ -71,264 +72,11 @@ __device__ __forceinline__ void xcd_chunk_order(int &chunk, int &b)
 
 int beamform_nchunks(int T) { return (T + BF_CHUNK - 1) / BF_CHUNK; }
 
-// more than 64 channels: the slab kernel below works on 256-frame chunks
-constexpr int SL_NT = 2;                          // 16-frame tiles per wave
-constexpr int SL_CHUNK = BF_WAVES * SL_NT * 16;   // 256 frames per workgroup
-constexpr int SL_COLS = 32;                       // DoA columns per W slab (two 16-column tiles)
-constexpr int SL_ROW = 48;                        // padded slab row (doubles): 384 B keeps q = 0/1 on disjoint banks
-
-int beamform_nchunks_ct(int T, int CT) { return CT > 4 ? (T + SL_CHUNK - 1) / SL_CHUNK : beamform_nchunks(T); }
-
 size_t beamform_partial_bytes(int B, int T, int Gp)
 {
-    // sized for the finer (256-frame) chunking of the slab kernel, which is an upper bound for both families
-    return ((size_t)B * ((T + SL_CHUNK - 1) / SL_CHUNK) * Gp * sizeof(double) + 255) & ~(size_t)255;
+    // sized for 256-frame chunks, the finest chunking of any kernel here
+    return ((size_t)B * ((T + 255) / 256) * Gp * sizeof(double) + 255) & ~(size_t)255;
 }
-
-template <int CT, bool SRC_SPIKES, bool W_LDS, bool WANT_Y>
-__global__ __launch_bounds__(BF_THREADS) void beamform_kernel(const int8_t *__restrict__ spikes,
-                                                               const double *__restrict__ pre,
-                                                               const double *__restrict__ ntab_g, int NK,
-                                                               const double *__restrict__ Wp, int GT, int C, int G,
-                                                               int T, int Ts, double *__restrict__ y, int y_complex,
-                                                               double *__restrict__ partial, const int *__restrict__ chunk_range)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    if (chunk_range && ((int)blockIdx.x < chunk_range[0] || (int)blockIdx.x >= chunk_range[1])) return;  // (workgroup-uniform)
-    constexpr int Cs = 16 * CT;  // padded spike row (bytes)
-    constexpr int KS = 4 * CT;   // beamforming k-steps
-    const int Gp = 16 * GT;
-    const int tid = threadIdx.x;
-    const int wv = tid >> 6;
-    const int l = tid & 63;
-    const int lc = l & 15;  // MFMA column / A row
-    const int q = l >> 4;   // MFMA k index within a k-step
-    const int chunk = blockIdx.x;
-    const int nchunks = gridDim.x;
-    const int b = blockIdx.y;
-    const int cs = chunk * BF_CHUNK;
-
-    // ---- LDS carve-up -----------------------------------------------------------------------------------
-    // [ W: C rows + one zero row ][ union{ red[8][Gp] , nir table + spike tile } ]
-    // red is only written after every wave has finished stage 1 (barrier below), so it may alias the spike tile.
-    double *Wl = reinterpret_cast<double *>(smem);
-    double *red = Wl + (W_LDS ? (size_t)(C + 1) * Gp : 0);
-    double *ntab = red;
-    const int ntab_len = SRC_SPIKES ? 4 * NK + 16 : 0;
-    int8_t *spk = reinterpret_cast<int8_t *>(ntab + ntab_len);
-    const int R = BF_CHUNK + 4 * NK - 16;  // staged spike rows
-
-    if (W_LDS) {
-        const double2 *src2 = reinterpret_cast<const double2 *>(Wp);
-        double2 *dst2 = reinterpret_cast<double2 *>(Wl);
-        const int n2 = (C * Gp) / 2;
-        for (int e0 = tid; e0 < n2; e0 += BF_THREADS * 4) {
-            double2 v[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int e = e0 + i * BF_THREADS;
-                v[i] = src2[e < n2 ? e : n2 - 1];
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int e = e0 + i * BF_THREADS;
-                if (e < n2) dst2[e] = v[i];
-            }
-        }
-        for (int e = tid; e < Gp; e += BF_THREADS) Wl[(size_t)C * Gp + e] = 0.0;
-    }
-    if (SRC_SPIKES) {
-        for (int e = tid; e < ntab_len; e += BF_THREADS) ntab[e] = ntab_g[e];
-        const int8_t *sb = spikes + (size_t)b * (chunk_range ? chunk_range[3] : T) * C;  // ([3]: frames per trial of a raster window)
-        const int tau0 = cs + 16 - 4 * NK;
-        // all loads of a batch are issued (clamped addresses, hence unconditional) before the first LDS write, so
-        // the workgroup pays the memory latency once per batch instead of once per element
-        for (int e0 = tid; e0 < R * Cs; e0 += BF_THREADS * 8) {
-            int8_t v[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int e = e0 + i * BF_THREADS;
-                const int rho = e / Cs, c = e % Cs;
-                int tau = tau0 + rho;
-                tau = tau < 0 ? 0 : (tau >= T ? T - 1 : tau);
-                v[i] = sb[(size_t)tau * C + (c < C ? c : C - 1)];
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int e = e0 + i * BF_THREADS;
-                const int rho = e / Cs, c = e % Cs;
-                const int tau = tau0 + rho;
-                if (e < R * Cs) spk[e] = (c < C && tau >= 0 && tau < T) ? v[i] : (int8_t)0;
-            }
-        }
-    }
-    __syncthreads();
-
-    // ---- stage 1: membrane fragments Vf[tt][ct] (4 doubles each) ------------------------------------------
-    // The 4 time tiles of the wave are 4 independent accumulation chains; the operands of k-step ks+1
-    // are fetched from LDS while the MFMAs of k-step ks run.
-    const int tb0 = cs + wv * BF_NT * 16;
-    double4_t Vf[BF_NT][CT];
-    if (SRC_SPIKES) {
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-            double4_t acc[BF_NT];
-#pragma unroll
-            for (int tt = 0; tt < BF_NT; ++tt) acc[tt] = double4_t{0.0, 0.0, 0.0, 0.0};
-            if (tb0 < T) {  // wave-uniform
-                const int8_t *sp = spk + (size_t)(tb0 - cs + q) * Cs + 16 * ct + lc;
-                const double *np_ = ntab + (lc - q + 4 * NK - 16 + 15);
-                double bn_n = np_[0];
-                int an[BF_NT];
-#pragma unroll
-                for (int tt = 0; tt < BF_NT; ++tt) an[tt] = sp[(size_t)(16 * tt) * Cs];
-                for (int ks = 0; ks < NK; ++ks) {
-                    const double bn = bn_n;
-                    double a[BF_NT];
-#pragma unroll
-                    for (int tt = 0; tt < BF_NT; ++tt) a[tt] = (double)an[tt];
-                    if (ks + 1 < NK) {
-                        bn_n = np_[-4 * (ks + 1)];
-#pragma unroll
-                        for (int tt = 0; tt < BF_NT; ++tt) an[tt] = sp[(size_t)(16 * tt + 4 * (ks + 1)) * Cs];
-                    }
-#pragma unroll
-                    for (int tt = 0; tt < BF_NT; ++tt)
-                        acc[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tt], bn, acc[tt], 0, 0, 0);
-                }
-            }
-#pragma unroll
-            for (int tt = 0; tt < BF_NT; ++tt) {
-                const bool tvalid = (tb0 + 16 * tt + lc) < T;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[tt][r] = tvalid ? acc[tt][r] : 0.0;
-                Vf[tt][ct] = acc[tt];
-            }
-        }
-    } else {
-#pragma unroll
-        for (int tt = 0; tt < BF_NT; ++tt) {
-            const int tb = tb0 + 16 * tt;
-            const bool tvalid = (tb + lc) < T;
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct) {
-                double4_t acc;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int c = 16 * ct + 4 * r + q;
-                    double v = 0.0;
-                    if (tvalid && c < C) v = pre[((size_t)b * C + c) * Ts + tb + lc];
-                    acc[r] = v;
-                }
-                Vf[tt][ct] = acc;
-            }
-        }
-    }
-
-    __syncthreads();  // all waves are done with the spike tile / nir table: `red` may now overwrite them
-
-    // ---- stage 2: beamforming + power, one 16-column DoA tile at a time ------------------------------------
-    // Two accumulator sets in the source; the compiler folds them and runs MFMAs -> epilogue back to back, which costs
-    // nothing extra: VALU work is not hidden behind MFMAs on a gfx950 SIMD anyway (tools/mfma_valu_overlap.hip).
-    const double *Wsrc = W_LDS ? Wl : Wp;
-    const int Ghp = Gp >> 1;  // complex variant: [0, Ghp) real part, [Ghp, Gp) imaginary part
-
-    // rows >= C of the padded matrix are zero: in LDS they all map to the single zero row stored at index C
-    int woff[KS];
-#pragma unroll
-    for (int k = 0; k < KS; ++k) {
-        const int row = 4 * k + q;
-        woff[k] = (W_LDS ? (row < C ? row : C) : row) * Gp;
-    }
-    auto load_w = [&](int gt, double (&Wf)[KS]) {
-        const double *wp = Wsrc + 16 * gt + lc;
-#pragma unroll
-        for (int k = 0; k < KS; ++k) Wf[k] = wp[woff[k]];
-    };
-    auto issue = [&](const double (&Wf)[KS], double4_t (&acc)[BF_NT]) {
-#pragma unroll
-        for (int tt = 0; tt < BF_NT; ++tt) acc[tt] = double4_t{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int k = 0; k < KS; ++k)
-#pragma unroll
-            for (int tt = 0; tt < BF_NT; ++tt)
-                acc[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(Vf[tt][k >> 2][k & 3], Wf[k], acc[tt], 0, 0, 0);
-    };
-    auto epilogue = [&](int gt, const double4_t (&acc)[BF_NT]) {
-        double sqt[BF_NT];
-#pragma unroll
-        for (int tt = 0; tt < BF_NT; ++tt) {
-            double s_ = acc[tt][0] * acc[tt][0];
-#pragma unroll
-            for (int r = 1; r < 4; ++r) s_ = __builtin_fma(acc[tt][r], acc[tt][r], s_);
-            sqt[tt] = s_;
-        }
-        double sq = (sqt[0] + sqt[1]) + (sqt[2] + sqt[3]);
-        if (WANT_Y) {
-            const int gcol = 16 * gt + lc;
-#pragma unroll
-            for (int tt = 0; tt < BF_NT; ++tt) {
-                const int tb = tb0 + 16 * tt;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int t = tb + q + 4 * r;
-                    if (t < T) {
-                        if (!y_complex) {
-                            if (gcol < G) y[((size_t)b * T + t) * G + gcol] = acc[tt][r];
-                        } else {
-                            const int part = gcol >= Ghp;
-                            const int g = gcol - (part ? Ghp : 0);
-                            if (g < (G >> 1)) y[(((size_t)b * T + t) * (G >> 1) + g) * 2 + part] = acc[tt][r];
-                        }
-                    }
-                }
-            }
-        }
-        sq = row_sum4(sq);  // lanes l, l^16, l^32, l^48 hold the same DoA column
-        if (l < 16) red[(size_t)wv * Gp + 16 * gt + l] = sq;
-    };
-
-    if (tb0 >= T) {
-        // every frame of this wave lies beyond the end of the trial (tail chunk): contribute exact zeros
-        for (int g = l; g < Gp; g += 64) red[(size_t)wv * Gp + g] = 0.0;
-    } else {
-        double WfA[KS], WfB[KS];
-        double4_t accA[BF_NT], accB[BF_NT];
-        // W fragments are fetched one whole DoA tile ahead of the MFMAs that consume them
-        auto load_w_clamped = [&](int gt, double (&Wf)[KS]) { load_w(gt < GT ? gt : GT - 1, Wf); };
-        load_w(0, WfA);
-        load_w_clamped(1, WfB);
-        issue(WfA, accA);
-        int gt = 0;
-        for (; gt + 2 < GT; gt += 2) {
-            issue(WfB, accB);
-            load_w_clamped(gt + 2, WfA);
-            epilogue(gt, accA);
-            issue(WfA, accA);
-            load_w_clamped(gt + 3, WfB);
-            epilogue(gt + 1, accB);
-        }
-        // tail: tile gt sits in A; one or two tiles remain
-        if (gt + 1 < GT) {
-            issue(WfB, accB);
-            epilogue(gt, accA);
-            epilogue(gt + 1, accB);
-        } else {
-            epilogue(gt, accA);
-        }
-    }
-    __syncthreads();
-    if (partial) {
-        double *pout = partial + ((size_t)b * nchunks + chunk) * Gp;
-        for (int g = tid; g < Gp; g += BF_THREADS) {
-            double s = 0.0;
-#pragma unroll
-            for (int w8 = 0; w8 < BF_WAVES; ++w8) s += red[(size_t)w8 * Gp + g];
-            pout[g] = s;
-        }
-    }
-}
-
 
 // ---------------------------------------------------------------------------------------------------------------
 // bf_mat-stationary form for up to 16 channels and power-only output (the sweep configuration, C = 14).
@@ -1077,284 +825,336 @@ static hipError_t launch_wsc(const BeamformW &W, const double *pre, int B, int T
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Many-channel variant (C > 64, e.g. the 64-microphone stress configuration): bf_mat no longer fits in LDS and the
-// membrane fragments of 4 time tiles no longer fit in registers.  Workgroup = 8 waves x 2 time tiles (256 frames);
-// the membrane fragments stay in registers (2 x CT x 4 doubles per lane), bf_mat is streamed through LDS in
-// double-buffered slabs of 32 DoA columns shared by the 8 waves (each byte leaves L2 once per workgroup), and the
-// per-slab column sums are combined across waves right away, so no G-sized reduction buffer is needed.
+// General form (everything the bf_mat-stationary kernels do not cover: more than 16 channels -- up to the 128 of the
+// 64-microphone stress configuration --, more than 512 DoAs, y stored for those shapes, the planar source of the complex
+// Beamformer with more than 8 microphones).  Membrane-stationary: a wave keeps the fragments of its NT time tiles in
+// registers (NT x CT x 8 VGPRs; NT = 1 for 128 channels) and bf_mat is streamed through LDS in double-buffered slabs of
+// 32 DoA columns shared by the 8 waves (every byte leaves L2 once per workgroup and 128-frame sub-chunk), the per-slab
+// column sums are combined across waves right away.  Sized for TWO workgroups per CU (<= 128 VGPRs, <= 80 KB of LDS): one
+// workgroup's staging / LIF / barrier bubbles are the other's MFMA time -- the one-workgroup form of rounds 1-3 (two time
+// tiles per wave, 170 VGPRs + 80 B of scratch, padded 98 KB slabs) sat at 0.72 of the matrix peak with the pipe idle a
+// quarter of the time.  What makes it fit:
+//   * slab rows are 32 doubles (256 B) with the two 16-column halves swapped in odd rows: the B-fragment read of a k-step
+//     (rows 4k + q, 16 columns) touches disjoint banks for q and q + 1 without the 50 % row padding;
+//   * the int8 spike tile of the sub-chunk and the nir table alias slab buffer 1, which is first written after the LIF
+//     phase (one extra barrier);
+//   * a workgroup walks NSUB sub-chunks and keeps the column sums of its chunk in LDS: one row of partial sums per
+//     NSUB x 128 frames instead of one per sub-chunk.
 // ---------------------------------------------------------------------------------------------------------------
+constexpr int GEN_COLS = 32;  // DoA columns per slab (two 16-column tiles)
+constexpr int gen_nt(int CT) { return CT > 4 ? 1 : 2; }
+constexpr int gen_nsub(int CT) { return CT > 4 ? 4 : 1; }
+constexpr int gen_chunk(int CT) { return BF_WAVES * gen_nt(CT) * 16 * gen_nsub(CT); }
+
+int beamform_nchunks_ct(int T, int CT)
+{
+    const int ch = CT > 4 ? gen_chunk(8) : gen_chunk(1);
+    return (T + ch - 1) / ch;
+}
+
+struct GenLds {
+    size_t u_doubles, total_bytes;
+};
+static GenLds gen_lds(int CT, int NK, bool src_spikes, int Gp)
+{
+    const int Kp = 16 * CT, NT = gen_nt(CT), NSUB = gen_nsub(CT);
+    size_t u = (size_t)Kp * GEN_COLS;  // slab buffer 1
+    if (src_spikes) {
+        const size_t tile = (size_t)(4 * NK + 16) + ((size_t)(BF_WAVES * NT * 16 + 4 * NK - 16) * Kp + 7) / 8;
+        u = tile > u ? tile : u;
+    }
+    u = (u + 1) & ~(size_t)1;
+    size_t d = (size_t)Kp * GEN_COLS + u + (size_t)2 * BF_WAVES * GEN_COLS + (NSUB > 1 ? (size_t)Gp + GEN_COLS : 0);
+    return {u, d * sizeof(double)};
+}
+
 template <int CT, bool SRC_SPIKES, bool WANT_Y>
-__global__ __launch_bounds__(BF_THREADS, 2) void beamform_slab_kernel(const int8_t *__restrict__ spikes,
-                                                                      const double *__restrict__ pre,
+__global__ __launch_bounds__(BF_THREADS, 4) void beamform_gen_kernel(const int8_t *__restrict__ spikes, const double *__restrict__ pre,
                                                                       const double *__restrict__ ntab_g, int NK,
-                                                                      const double *__restrict__ Wp, int GT, int C, int G,
-                                                                      int T, int Ts, double *__restrict__ y, int y_complex,
-                                                                      double *__restrict__ partial, const int *__restrict__ chunk_range)
+                                                                      const double *__restrict__ Wp, int GT, int C, int G, int T, int Ts,
+                                                                      double *__restrict__ y, int y_complex, double *__restrict__ partial,
+                                                                      const int *__restrict__ chunk_range, int u_doubles, int vec_stage)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    if (chunk_range && ((int)blockIdx.x < chunk_range[0] || (int)blockIdx.x >= chunk_range[1])) return;  // (workgroup-uniform)
+    constexpr int NT = gen_nt(CT), NSUB = gen_nsub(CT);
     constexpr int Kp = 16 * CT;
     constexpr int Cs = 16 * CT;
     constexpr int KS = 4 * CT;
-    const int Gp = 16 * GT;  // even number of tiles (host pads)
-    const int NSL = GT / 2;
+    constexpr int SUB = BF_WAVES * NT * 16;  // frames per sub-chunk
+    constexpr int CH = SUB * NSUB;           // frames per workgroup = per row of partial sums
+    const int Gp = 16 * GT;
+    const int NSL = (GT + 1) >> 1;
     const int tid = threadIdx.x;
-    const int wv = tid >> 6;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l = tid & 63;
     const int lc = l & 15;
     const int q = l >> 4;
-    const int chunk = blockIdx.x;
+    int chunk = blockIdx.x, b = blockIdx.y;
+    xcd_chunk_order(chunk, b);
+    if (chunk_range && (chunk < chunk_range[0] || chunk >= chunk_range[1])) return;  // (workgroup-uniform)
     const int nchunks = gridDim.x;
-    const int b = blockIdx.y;
-    const int cs = chunk * SL_CHUNK;
 
-    double *slab = reinterpret_cast<double *>(smem);                 // [2][Kp][SL_ROW]
-    double *red = slab + (size_t)2 * Kp * SL_ROW;                    // [2][BF_WAVES][SL_COLS]
-    double *ntab = red + 2 * BF_WAVES * SL_COLS;
+    double *slab0 = reinterpret_cast<double *>(smem);  // [Kp][32], halves swapped in odd rows
+    double *U = slab0 + Kp * GEN_COLS;                 // slab buffer 1 | nir table + int8 spike tile (LIF phase only)
+    double *red = U + u_doubles;                       // [2][BF_WAVES][32]
+    double *accl = red + 2 * BF_WAVES * GEN_COLS;      // [Gp + 32] column sums of the chunk (NSUB > 1)
+    double *ntab = U;
     const int ntab_len = SRC_SPIKES ? 4 * NK + 16 : 0;
-    int8_t *spk = reinterpret_cast<int8_t *>(ntab + ntab_len);
-    const int R = SL_CHUNK + 4 * NK - 16;
+    int8_t *spk = reinterpret_cast<int8_t *>(U + ntab_len);
+    const int R = SUB + 4 * NK - 16;
 
-    // slab loads: Kp rows x 32 columns = Kp * 16 double2; 512 threads -> Kp / 32 double2 each
-    constexpr int NV = (Kp * (SL_COLS / 2) + BF_THREADS - 1) / BF_THREADS;
-    double2 wreg[NV];
-    auto issue_slab = [&](int sl) {
+    // Slab staging by LDS-DMA (global_load_lds_dwordx4: no staging registers -- with 64 VGPRs of membrane fragments at 128
+    // channels there are none to spare -- and no ds_write pass).  One wave-instruction lands 64 x 16 B = 4 slab rows
+    // contiguously; the destination is lane-linear, so the swap of the 16-column halves in odd rows is applied to the SOURCE
+    // address (lane p of an odd row fetches pair p ^ 8) and again by the B-fragment reads below.
+    constexpr int NI = Kp / 4;  // wave-instructions per slab, dealt round-robin over the 8 waves
+    auto stage_slab = [&](int sl, int buf) {
+        double *sb = buf ? U : slab0;
+        const int rq = l >> 4, p = l & 15;
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int e = tid + i * BF_THREADS;  // double2 index: row = e / 16, pair = e % 16
-            const int row = e >> 4, pr = e & 15;
-            const int rr = row < Kp ? row : Kp - 1;
-            wreg[i] = *reinterpret_cast<const double2 *>(Wp + (size_t)rr * Gp + SL_COLS * sl + 2 * pr);
-        }
-    };
-    auto write_slab = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int e = tid + i * BF_THREADS;
-            const int row = e >> 4, pr = e & 15;
-            if (row < Kp) *reinterpret_cast<double2 *>(slab + ((size_t)buf * Kp + row) * SL_ROW + 2 * pr) = wreg[i];
-        }
-    };
-
-    issue_slab(0);
-    if (SRC_SPIKES) {
-        for (int e = tid; e < ntab_len; e += BF_THREADS) ntab[e] = ntab_g[e];
-        const int8_t *sb = spikes + (size_t)b * (chunk_range ? chunk_range[3] : T) * C;  // ([3]: frames per trial of a raster window)
-        const int tau0 = cs + 16 - 4 * NK;
-        for (int e0 = tid; e0 < R * Cs; e0 += BF_THREADS * 8) {
-            int8_t v[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int e = e0 + i * BF_THREADS;
-                const int rho = e / Cs, c = e % Cs;
-                int tau = tau0 + rho;
-                tau = tau < 0 ? 0 : (tau >= T ? T - 1 : tau);
-                v[i] = sb[(size_t)tau * C + (c < C ? c : C - 1)];
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int e = e0 + i * BF_THREADS;
-                const int rho = e / Cs, c = e % Cs;
-                const int tau = tau0 + rho;
-                if (e < R * Cs) spk[e] = (c < C && tau >= 0 && tau < T) ? v[i] : (int8_t)0;
+        for (int j0 = 0; j0 < NI; j0 += BF_WAVES) {
+            const int j = j0 + wv;
+            if (j < NI) {  // (wave-uniform)
+                const int row = 4 * j + rq;
+                // (a last, half-empty slab of an odd tile count reads 16 columns past the row: the next row's head or the
+                //  allocation's 16 doubles of slack -- columns nobody stores)
+                const double *src = Wp + (size_t)row * Gp + GEN_COLS * sl + 2 * (p ^ ((rq & 1) << 3));
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                 (__attribute__((address_space(3))) void *)(sb + (size_t)j * 128), 16, 0, 0);
             }
         }
-    }
-    write_slab(0);
-    if (NSL > 1) issue_slab(1);
-    __syncthreads();
+    };
+    auto slabs_landed = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
 
-    // ---- membrane fragments for the 2 time tiles of this wave ----
-    const int tb0 = cs + wv * SL_NT * 16;
-    double4_t Vf[SL_NT][CT];
-    if (SRC_SPIKES) {
+    const double *pout_chunk = nullptr;
+    double *pout = partial ? partial + ((size_t)b * nchunks + chunk) * Gp : nullptr;
+    (void)pout_chunk;
+    const int Ghp = Gp >> 1;
+
+    for (int s = 0; s < NSUB; ++s) {
+        const int cs = chunk * CH + s * SUB;
+        if (s > 0 && cs >= T) break;  // (workgroup-uniform) the rest of a trial's last chunk is empty
+        stage_slab(0, 0);
+        if (SRC_SPIKES) {
+            for (int e = tid; e < ntab_len; e += BF_THREADS) ntab[e] = ntab_g[e];
+            const int8_t *sb = spikes + (size_t)b * (chunk_range ? chunk_range[3] : T) * C;  // ([3]: frames per trial of a raster window)
+            const int tau0 = cs + 16 - 4 * NK;
+            if (vec_stage && tau0 >= 0 && tau0 + R <= T) {
+                // interior sub-chunk, C == 16 CT, 16-byte aligned raster: the tile is one contiguous range of the trial
+                const uint4 *src = reinterpret_cast<const uint4 *>(sb + (size_t)tau0 * C);
+                uint4 *dst = reinterpret_cast<uint4 *>(spk);
+                const int n16 = R * (Cs / 16);
+                for (int e0 = tid; e0 < n16; e0 += BF_THREADS * 4) {
+                    uint4 v[4];
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-            double4_t acc[SL_NT];
-#pragma unroll
-            for (int tt = 0; tt < SL_NT; ++tt) acc[tt] = double4_t{0.0, 0.0, 0.0, 0.0};
-            if (tb0 < T) {
-                const int8_t *sp = spk + (size_t)(tb0 - cs + q) * Cs + 16 * ct + lc;
-                const double *np_ = ntab + (lc - q + 4 * NK - 16 + 15);
-                double bn_n = np_[0];
-                int an[SL_NT];
-#pragma unroll
-                for (int tt = 0; tt < SL_NT; ++tt) an[tt] = sp[(size_t)(16 * tt) * Cs];
-                for (int ks = 0; ks < NK; ++ks) {
-                    const double bn = bn_n;
-                    double a[SL_NT];
-#pragma unroll
-                    for (int tt = 0; tt < SL_NT; ++tt) a[tt] = (double)an[tt];
-                    if (ks + 1 < NK) {
-                        bn_n = np_[-4 * (ks + 1)];
-#pragma unroll
-                        for (int tt = 0; tt < SL_NT; ++tt) an[tt] = sp[(size_t)(16 * tt + 4 * (ks + 1)) * Cs];
+                    for (int i = 0; i < 4; ++i) {
+                        const int e = e0 + i * BF_THREADS;
+                        v[i] = src[e < n16 ? e : n16 - 1];
                     }
 #pragma unroll
-                    for (int tt = 0; tt < SL_NT; ++tt)
-                        acc[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tt], bn, acc[tt], 0, 0, 0);
+                    for (int i = 0; i < 4; ++i) {
+                        const int e = e0 + i * BF_THREADS;
+                        if (e < n16) dst[e] = v[i];
+                    }
+                }
+            } else {
+                for (int e0 = tid; e0 < R * Cs; e0 += BF_THREADS * 8) {
+                    int8_t v[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int e = e0 + i * BF_THREADS;
+                        const int rho = e / Cs, c = e % Cs;
+                        int tau = tau0 + rho;
+                        tau = tau < 0 ? 0 : (tau >= T ? T - 1 : tau);
+                        v[i] = sb[(size_t)tau * C + (c < C ? c : C - 1)];
+                    }
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int e = e0 + i * BF_THREADS;
+                        const int rho = e / Cs, c = e % Cs;
+                        const int tau = tau0 + rho;
+                        if (e < R * Cs) spk[e] = (c < C && tau >= 0 && tau < T) ? v[i] : (int8_t)0;
+                    }
                 }
             }
-#pragma unroll
-            for (int tt = 0; tt < SL_NT; ++tt) {
-                const bool tvalid = (tb0 + 16 * tt + lc) < T;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[tt][r] = tvalid ? acc[tt][r] : 0.0;
-                Vf[tt][ct] = acc[tt];
-            }
         }
-    } else {
-#pragma unroll
-        for (int tt = 0; tt < SL_NT; ++tt) {
-            const int tb = tb0 + 16 * tt;
-            const bool tvalid = (tb + lc) < T;
+        slabs_landed();
+        __syncthreads();
+
+        // ---- membrane fragments of this wave's NT time tiles ----
+        const int tb0 = cs + wv * NT * 16;
+        double4_t Vf[NT][CT];
+        if (SRC_SPIKES) {
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
-                double4_t acc;
+                double4_t acc[NT];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int c = 16 * ct + 4 * r + q;
-                    double v = 0.0;
-                    if (tvalid && c < C) v = pre[((size_t)b * C + c) * Ts + tb + lc];
-                    acc[r] = v;
+                for (int tt = 0; tt < NT; ++tt) acc[tt] = double4_t{0.0, 0.0, 0.0, 0.0};
+                if (tb0 < T) {  // wave-uniform
+                    const int8_t *sp = spk + (size_t)(tb0 - cs + q) * Cs + 16 * ct + lc;
+                    const double *np_ = ntab + (lc - q + 4 * NK - 16 + 15);
+                    double bn_n = np_[0];
+                    int an[NT];
+#pragma unroll
+                    for (int tt = 0; tt < NT; ++tt) an[tt] = sp[(size_t)(16 * tt) * Cs];
+                    for (int ks = 0; ks < NK; ++ks) {
+                        const double bn = bn_n;
+                        double a[NT];
+#pragma unroll
+                        for (int tt = 0; tt < NT; ++tt) a[tt] = (double)an[tt];
+                        if (ks + 1 < NK) {
+                            bn_n = np_[-4 * (ks + 1)];
+#pragma unroll
+                            for (int tt = 0; tt < NT; ++tt) an[tt] = sp[(size_t)(16 * tt + 4 * (ks + 1)) * Cs];
+                        }
+#pragma unroll
+                        for (int tt = 0; tt < NT; ++tt)
+                            acc[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tt], bn, acc[tt], 0, 0, 0);
+                    }
                 }
-                Vf[tt][ct] = acc;
-            }
-        }
-    }
-
-    const int Ghp = Gp >> 1;
-    double *pout = partial ? partial + ((size_t)b * nchunks + chunk) * Gp : nullptr;
-    for (int sl = 0; sl < NSL; ++sl) {
-        const int buf = sl & 1;
-        const double *sbuf = slab + (size_t)buf * Kp * SL_ROW;
 #pragma unroll
-        for (int gl = 0; gl < 2; ++gl) {
-            const int gt = 2 * sl + gl;
-            double4_t acc[SL_NT];
+                for (int tt = 0; tt < NT; ++tt) {
+                    const bool tvalid = (tb0 + 16 * tt + lc) < T;
 #pragma unroll
-            for (int tt = 0; tt < SL_NT; ++tt) acc[tt] = double4_t{0.0, 0.0, 0.0, 0.0};
-            if (tb0 < T) {
-                const double *wp = sbuf + (size_t)q * SL_ROW + 16 * gl + lc;
-#pragma unroll
-                for (int k = 0; k < KS; ++k) {
-                    const double wk = wp[(size_t)(4 * k) * SL_ROW];
-#pragma unroll
-                    for (int tt = 0; tt < SL_NT; ++tt)
-                        acc[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(Vf[tt][k >> 2][k & 3], wk, acc[tt], 0, 0, 0);
+                    for (int r = 0; r < 4; ++r) acc[tt][r] = tvalid ? acc[tt][r] : 0.0;
+                    Vf[tt][ct] = acc[tt];
                 }
             }
-            double sq = 0.0;
+            __syncthreads();  // every wave is done with the spike tile and the nir table: slab buffer 1 may overwrite them
+        } else {
 #pragma unroll
-            for (int tt = 0; tt < SL_NT; ++tt)
+            for (int tt = 0; tt < NT; ++tt) {
+                const int tb = tb0 + 16 * tt;
+                const bool tvalid = (tb + lc) < T;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) sq = __builtin_fma(acc[tt][r], acc[tt][r], sq);
-            if (WANT_Y) {
-                const int gcol = 16 * gt + lc;
-#pragma unroll
-                for (int tt = 0; tt < SL_NT; ++tt) {
-                    const int tb = tb0 + 16 * tt;
+                for (int ct = 0; ct < CT; ++ct) {
+                    double4_t acc;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int t = tb + q + 4 * r;
-                        if (t < T) {
-                            if (!y_complex) {
-                                if (gcol < G) y[((size_t)b * T + t) * G + gcol] = acc[tt][r];
-                            } else {
-                                const int part = gcol >= Ghp;
-                                const int g = gcol - (part ? Ghp : 0);
-                                if (g < (G >> 1)) y[(((size_t)b * T + t) * (G >> 1) + g) * 2 + part] = acc[tt][r];
+                        const int c = 16 * ct + 4 * r + q;
+                        double v = 0.0;
+                        if (tvalid && c < C) v = pre[((size_t)b * C + c) * Ts + tb + lc];
+                        acc[r] = v;
+                    }
+                    Vf[tt][ct] = acc;
+                }
+            }
+        }
+
+        // ---- the DoA slabs ----
+        // B fragment of k-step k, tile gl: row 4k + q, column 16 gl + lc, halves swapped in odd rows (q & 1)
+        const int boff0 = q * GEN_COLS + (lc ^ ((q & 1) << 4));
+        for (int sl = 0; sl < NSL; ++sl) {
+            const int buf = sl & 1;
+            const double *sbuf = buf ? U : slab0;
+            if (sl + 1 < NSL) stage_slab(sl + 1, buf ^ 1);  // in flight behind this slab's MFMAs (the other buffer was released by the last barrier)
+            double4_t acc[2][NT];
+#pragma unroll
+            for (int gl = 0; gl < 2; ++gl)
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt) acc[gl][tt] = double4_t{0.0, 0.0, 0.0, 0.0};
+            if (tb0 < T) {
+                // B fragments D k-steps ahead of their MFMAs, the order pinned: left alone the scheduler hoists as many of the
+                // 2 KS reads as the register budget holds -- and at 128 channels (64 VGPRs of membrane fragments) then spills
+                const double *w0 = sbuf + boff0, *w1 = sbuf + (boff0 ^ 16);
+                constexpr int D = 3;
+                double wk0[KS], wk1[KS];
+#pragma unroll
+                for (int k = 0; k < D && k < KS; ++k) {
+                    wk0[k] = w0[4 * k * GEN_COLS];
+                    wk1[k] = w1[4 * k * GEN_COLS];
+                }
+                __builtin_amdgcn_sched_group_barrier(0x100, 2 * (D < KS ? D : KS), 0);
+#pragma unroll
+                for (int k = 0; k < KS; ++k) {
+                    if (k + D < KS) {
+                        wk0[k + D] = w0[4 * (k + D) * GEN_COLS];
+                        wk1[k + D] = w1[4 * (k + D) * GEN_COLS];
+                        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    }
+#pragma unroll
+                    for (int tt = 0; tt < NT; ++tt) {
+                        acc[0][tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(Vf[tt][k >> 2][k & 3], wk0[k], acc[0][tt], 0, 0, 0);
+                        acc[1][tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(Vf[tt][k >> 2][k & 3], wk1[k], acc[1][tt], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2 * NT, 0);
+                }
+            }
+#pragma unroll
+            for (int gl = 0; gl < 2; ++gl) {
+                double sq = 0.0;
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sq = __builtin_fma(acc[gl][tt][r], acc[gl][tt][r], sq);
+                if (WANT_Y) {
+                    const int gcol = 16 * (2 * sl + gl) + lc;
+#pragma unroll
+                    for (int tt = 0; tt < NT; ++tt) {
+                        const int tb = tb0 + 16 * tt;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int t = tb + q + 4 * r;
+                            if (t < T) {
+                                if (!y_complex) {
+                                    if (gcol < G) y[((size_t)b * T + t) * G + gcol] = acc[gl][tt][r];
+                                } else {
+                                    const int part = gcol >= Ghp;
+                                    const int g = gcol - (part ? Ghp : 0);
+                                    if (gcol < Gp && g < (G >> 1)) y[(((size_t)b * T + t) * (G >> 1) + g) * 2 + part] = acc[gl][tt][r];
+                                }
                             }
                         }
                     }
                 }
+                sq = row_sum4(sq);
+                if (l < 16) red[(buf * BF_WAVES + wv) * GEN_COLS + 16 * gl + l] = sq;
             }
-            sq = row_sum4(sq);
-            if (l < 16) red[((size_t)buf * BF_WAVES + wv) * SL_COLS + 16 * gl + l] = sq;
-        }
-        if (sl + 1 < NSL) write_slab(buf ^ 1);  // registers hold slab sl+1 (issued one iteration ago)
-        if (sl + 2 < NSL) issue_slab(sl + 2);
-        __syncthreads();
-        if (pout && tid < SL_COLS) {
-            double s = 0.0;
+            slabs_landed();
+            __syncthreads();
+            if (pout && tid < GEN_COLS) {
+                double sm = 0.0;
 #pragma unroll
-            for (int w8 = 0; w8 < BF_WAVES; ++w8) s += red[((size_t)buf * BF_WAVES + w8) * SL_COLS + tid];
-            pout[SL_COLS * sl + tid] = s;
+                for (int w8 = 0; w8 < BF_WAVES; ++w8) sm += red[(buf * BF_WAVES + w8) * GEN_COLS + tid];
+                if (NSUB > 1)
+                    accl[GEN_COLS * sl + tid] = s > 0 ? accl[GEN_COLS * sl + tid] + sm : sm;  // (the same thread every time)
+                else if (GEN_COLS * sl + tid < Gp)
+                    pout[GEN_COLS * sl + tid] = sm;
+            }
         }
+    }
+    if (NSUB > 1 && pout) {
+        __syncthreads();
+        for (int g = tid; g < Gp; g += BF_THREADS) pout[g] = accl[g];
     }
 }
 
 template <int CT, bool SRC_SPIKES>
-static hipError_t launch_slab(const BeamformW &W, const NeuronTab *nt, const int8_t *spikes, const double *pre, int B,
-                              int T, int Ts, double *y, int y_complex, double *partial, hipStream_t stream)
+static hipError_t launch_gen(const BeamformW &W, const NeuronTab *nt, const int8_t *spikes, const double *pre, int B,
+                             int T, int Ts, double *y, int y_complex, double *partial, hipStream_t stream)
 {
-    if (W.GT & 1) return hipErrorInvalidValue;  // the host pads the DoA tiles to an even count for this kernel
     const int NK = SRC_SPIKES ? nt->NK : 0;
-    size_t lds = (size_t)2 * 16 * CT * SL_ROW * sizeof(double) + (size_t)2 * BF_WAVES * SL_COLS * sizeof(double);
-    if (SRC_SPIKES) lds += (size_t)(4 * NK + 16) * sizeof(double) + (size_t)(SL_CHUNK + 4 * NK - 16) * 16 * CT;
-    lds = (lds + 15) & ~(size_t)15;
-    if (lds > 160 * 1024) return hipErrorInvalidValue;
-    dim3 grid((T + SL_CHUNK - 1) / SL_CHUNK, B), block(BF_THREADS);
+    const int Gp = 16 * W.GT;
+    const GenLds L = gen_lds(CT, NK, SRC_SPIKES, Gp);
+    if (L.total_bytes > 160 * 1024) return hipErrorInvalidValue;
+    dim3 grid((T + gen_chunk(CT) - 1) / gen_chunk(CT), B), block(BF_THREADS);
     const double *tab = SRC_SPIKES ? nt->tab : nullptr;
+    const int vec_stage = SRC_SPIKES && W.C == 16 * CT && (reinterpret_cast<uintptr_t>(spikes) & 15) == 0;
     hipError_t e;
-#define SL_LAUNCH(WY)                                                                                               \
+#define GEN_LAUNCH(WY)                                                                                              \
     do {                                                                                                            \
-        auto k = &beamform_slab_kernel<CT, SRC_SPIKES, WY>;                                                         \
+        auto k = &beamform_gen_kernel<CT, SRC_SPIKES, WY>;                                                          \
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,      \
                                 160 * 1024);                                                                        \
         if (e != hipSuccess) return e;                                                                              \
-        hipLaunchKernelGGL(k, grid, block, lds, stream, spikes, pre, tab, NK, W.Wp, W.GT, W.C, W.G, T, Ts, y,       \
-                           y_complex, partial, W.chunk_range);                                                      \
+        hipLaunchKernelGGL(k, grid, block, L.total_bytes, stream, spikes, pre, tab, NK, W.Wp, W.GT, W.C, W.G, T, Ts, y, \
+                           y_complex, partial, W.chunk_range, (int)L.u_doubles, vec_stage);                         \
     } while (0)
     if (y)
-        SL_LAUNCH(true);
+        GEN_LAUNCH(true);
     else
-        SL_LAUNCH(false);
-#undef SL_LAUNCH
-    return hipGetLastError();
-}
-
-template <int CT, bool SRC_SPIKES>
-static hipError_t launch_bf(const BeamformW &W, const NeuronTab *nt, const int8_t *spikes, const double *pre, int B,
-                            int T, int Ts, double *y, int y_complex, double *partial, hipStream_t stream)
-{
-    const int Gp = 16 * W.GT;
-    const int Kp = 16 * CT;
-    const int NK = SRC_SPIKES ? nt->NK : 0;
-    size_t lds = (size_t)BF_WAVES * Gp * sizeof(double);
-    if (SRC_SPIKES) {
-        const size_t tile = (size_t)(4 * NK + 16) * sizeof(double) + (size_t)(BF_CHUNK + 4 * NK - 16) * 16 * CT;
-        lds = lds > tile ? lds : tile;  // red aliases the nir table + spike tile
-    }
-    lds = (lds + 15) & ~(size_t)15;
-    const size_t wbytes = (size_t)(W.C + 1) * Gp * sizeof(double);
-    (void)Kp;
-    const bool w_lds = (lds + wbytes) <= 150 * 1024 && wbytes <= 96 * 1024;
-    if (lds > 160 * 1024) return hipErrorInvalidValue;
-    dim3 grid(beamform_nchunks(T), B), block(BF_THREADS);
-    const double *tab = SRC_SPIKES ? nt->tab : nullptr;
-    hipError_t e;
-#define BF_LAUNCH(WL, WY, LDSB)                                                                                       \
-    do {                                                                                                             \
-        auto k = &beamform_kernel<CT, SRC_SPIKES, WL, WY>;                                                           \
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,       \
-                                160 * 1024);                                                                         \
-        if (e != hipSuccess) return e;                                                                               \
-        hipLaunchKernelGGL(k, grid, block, (LDSB), stream, spikes, pre, tab, NK, W.Wp, W.GT, W.C, W.G, T, Ts, y,      \
-                           y_complex, partial, W.chunk_range);                                                       \
-    } while (0)
-    if (w_lds) {
-        if (y)
-            BF_LAUNCH(true, true, lds + wbytes);
-        else
-            BF_LAUNCH(true, false, lds + wbytes);
-    } else {
-        if (y)
-            BF_LAUNCH(false, true, lds);
-        else
-            BF_LAUNCH(false, false, lds);
-    }
-#undef BF_LAUNCH
+        GEN_LAUNCH(false);
+#undef GEN_LAUNCH
     return hipGetLastError();
 }
 
@@ -1363,14 +1163,15 @@ static hipError_t dispatch_ct(const BeamformW &W, const NeuronTab *nt, const int
                               int T, int Ts, double *y, int y_complex, double *partial, hipStream_t stream)
 {
     switch (W.CT) {
-        case 1: return launch_bf<1, SRC_SPIKES>(W, nt, spikes, pre, B, T, Ts, y, y_complex, partial, stream);
-        case 2: return launch_bf<2, SRC_SPIKES>(W, nt, spikes, pre, B, T, Ts, y, y_complex, partial, stream);
-        case 3: return launch_bf<3, SRC_SPIKES>(W, nt, spikes, pre, B, T, Ts, y, y_complex, partial, stream);
-        case 4: return launch_bf<4, SRC_SPIKES>(W, nt, spikes, pre, B, T, Ts, y, y_complex, partial, stream);
-        case 8: return launch_slab<8, SRC_SPIKES>(W, nt, spikes, pre, B, T, Ts, y, y_complex, partial, stream);
+        case 1: return launch_gen<1, SRC_SPIKES>(W, nt, spikes, pre, B, T, Ts, y, y_complex, partial, stream);
+        case 2: return launch_gen<2, SRC_SPIKES>(W, nt, spikes, pre, B, T, Ts, y, y_complex, partial, stream);
+        case 3: return launch_gen<3, SRC_SPIKES>(W, nt, spikes, pre, B, T, Ts, y, y_complex, partial, stream);
+        case 4: return launch_gen<4, SRC_SPIKES>(W, nt, spikes, pre, B, T, Ts, y, y_complex, partial, stream);
+        case 8: return launch_gen<8, SRC_SPIKES>(W, nt, spikes, pre, B, T, Ts, y, y_complex, partial, stream);
         default: return hipErrorInvalidValue;
     }
 }
+
 
 hipError_t launch_lif_beamform(const BeamformW &W, const NeuronTab &nt, const int8_t *spikes, int B, int T, double *y,
                                double *partial, hipStream_t stream, int *nchunks)
@@ -1383,7 +1184,7 @@ hipError_t launch_lif_beamform(const BeamformW &W, const NeuronTab &nt, const in
 int lif_beamform_chunk_frames(const BeamformW &W, const NeuronTab &nt)
 {
     if (ws_eligible(W, nt, false)) return BF_WAVES * WS_NT * 16;
-    return W.CT > 4 ? SL_CHUNK : BF_CHUNK;
+    return W.CT > 4 ? gen_chunk(8) : gen_chunk(1);
 }
 
 hipError_t launch_planar_beamform(const BeamformW &W, const double *pre, int B, int T, int Ts, double *y,
