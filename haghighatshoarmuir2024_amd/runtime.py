@@ -217,7 +217,7 @@ class Plan:
                    "lif_beamform_f32")
         return dict(spikes=spikes.clone() if want_spikes else None, y=None, power=power, argmax=argmax)
 
-    def snn_pipeline_cov(self, x, t_start=0, want_spikes=False, want_cov=False, want_power=True):
+    def snn_pipeline_cov(self, x, t_start=0, want_spikes=False, want_cov=False, want_power=True, cov_out=None):
         """Covariance-form tail: power = w^T (V^T V / T') w, optionally the membrane covariance itself
         (frames t >= t_start).  Algebraically identical to snn_pipeline's power; supports up to 64 channels."""
         torch = _torch()
@@ -225,7 +225,9 @@ class Plan:
         if M != self.num_mic:
             raise ValueError(f"number of channels in the input siganl {M} should be the same as the number of microphones {self.num_mic}!")
         spikes = torch.empty((B, T, self.C), dtype=torch.int8, device=self.device) if want_spikes else None
-        cov = torch.empty((B, self.C, self.C), dtype=torch.float64, device=self.device) if want_cov else None
+        cov = torch.empty((B, self.C, self.C), dtype=torch.float64, device=self.device) if want_cov and cov_out is None else cov_out
+        if cov is not None and (tuple(cov.shape) != (B, self.C, self.C) or cov.dtype != torch.float64 or not cov.is_contiguous()):
+            raise ValueError("cov_out must be a contiguous float64 [B, 2M, 2M] device tensor")
         power = torch.empty((B, self.G), dtype=torch.float64, device=self.device) if want_power else None
         argmax = torch.empty((B,), dtype=torch.int32, device=self.device) if want_power else None
         ws, nbytes = self.workspace(B, T)

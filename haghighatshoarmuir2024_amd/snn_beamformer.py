@@ -170,14 +170,14 @@ class SNNBeamformer:
             raise ValueError("power_mode must be 'direct' or 'covariance'")
         return plan.snn_pipeline(x, want_spikes=return_spikes, want_power=True)
 
-    def membrane_covariance_batch(self, sig_batch, time_vec=None, t_start=0):
-        """[B, T, M] -> device tensor [B, 2M, 2M]: V^T V / (T - t_start) of the membrane signal over frames >= t_start."""
+    def membrane_covariance_batch(self, sig_batch, time_vec=None, t_start=0, out=None):
+        """[B, T, M] -> device tensor [B, 2M, 2M] (`out`, if given): V^T V / (T - t_start) of the membrane signal over frames >= t_start."""
         B, T, M = sig_batch.shape
         if time_vec is None:
             time_vec = np.arange(T) / self.fs
         plan = self.plan()
         plan.set_neuron_kernel(neuron_impulse_response(time_vec, self.tau_vec))
-        return plan.snn_pipeline_cov(plan.to_device(sig_batch), t_start=t_start, want_cov=True, want_power=False)["cov"]
+        return plan.snn_pipeline_cov(plan.to_device(sig_batch), t_start=t_start, want_cov=True, want_power=False, cov_out=out)["cov"]
 
     def membrane_batch(self, sig_batch, time_vec=None):
         """[B, T, M] -> device tensor [B, T, 2M]: the membrane signal vmem (bf_mat = identity)."""
@@ -218,7 +218,11 @@ class SNNBeamformer:
 
             if 2 * len(self.geometry) > 128:
                 raise ValueError("svd='device' supports up to 64 microphones")
-            bf_dev = torch.empty((2 * len(self.geometry), len(doa_list)), dtype=torch.float64, device=runtime.require_gpu(self.device))
+            dev = runtime.require_gpu(self.device)
+            bf_dev = torch.empty((2 * len(self.geometry), len(doa_list)), dtype=torch.float64, device=dev)
+            # every DoA's covariance stays on the device (config 5: 1440 x 128 x 128 doubles = 189 MB) and ALL decompositions
+            # run in one launch -- they do not depend on the batching of the chain (48 of them fill a fifth of the chip)
+            cov_all = torch.empty((len(doa_list), 2 * len(self.geometry), 2 * len(self.geometry)), dtype=torch.float64, device=dev)
         for start in range(0, len(doa_list), doa_batch):
             doas = doa_list[start : start + doa_batch]
             # delayed, clamped copies of the template, one trial per DoA (reference :141-154)
@@ -232,8 +236,7 @@ class SNNBeamformer:
                 sig = np.interp(time_delayed.ravel(), time_temp, sig_temp).reshape(time_delayed.shape)
                 sig = np.ascontiguousarray(np.transpose(sig, (0, 2, 1)))  # [n, T, M]
             if svd == "device":
-                cov_d = self.membrane_covariance_batch(sig, time_vec=time_temp, t_start=sig.shape[1] // 4)
-                runtime.design_vectors(cov_d, self.spk_encoder.bipolar, bf_dev, start, rel_prec=0.00000001)
+                self.membrane_covariance_batch(sig, time_vec=time_temp, t_start=sig.shape[1] // 4, out=cov_all[start : start + len(doas)])
                 continue
             # membrane covariance over the last 3/4 on the device (MFMA Gram kernels: lif_cov_kernel up to 64 channels,
             # lif_cov_wide_kernel up to 128 -- the plan's limit)
@@ -247,6 +250,7 @@ class SNNBeamformer:
                     U, _, _ = np.linalg.svd(C_comp)
                     bf_mat.append(np.concatenate([np.real(U[:, 0]), np.imag(U[:, 0])]))
         if svd == "device":
+            runtime.design_vectors(cov_all, self.spk_encoder.bipolar, bf_dev, 0, rel_prec=0.00000001)
             return bf_dev.cpu().numpy()
         return np.asarray(bf_mat).T
 

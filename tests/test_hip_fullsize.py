@@ -155,3 +155,55 @@ def test_config5_shape_vs_oracle():
         np.testing.assert_array_equal(full["spikes"][i].cpu().numpy(), ref["spikes"])
         np.testing.assert_allclose(full["power"][i].cpu().numpy(), ref["power"], rtol=1e-12, atol=0)
         assert int(full["argmax"][i]) == ref["argmax"]
+
+
+def test_config5_designed_bf_mat_end_to_end():
+    """BASELINE config 5 with a DESIGNED beamforming matrix (micloc/snn_beamformer.py:183-203 for 64 microphones): the whole
+    1440-DoA design on the device (chain, 128 x 128 membrane covariances, ONE launch of the one-sided Jacobi kernel) against
+    the host decomposition (LAPACK, the reference's route) on a handful of DoAs -- columns equal up to the singular vector's
+    unit phase, same beam pattern |W^H W| -- and the fused pipeline with that matrix against the oracle."""
+    import torch
+
+    from haghighatshoarmuir2024_amd.array_geometry import Random2DArray
+    from haghighatshoarmuir2024_amd.snn_beamformer import SNNBeamformer, neuron_impulse_response
+
+    fs, M5, G5 = 96_000, 64, 1440
+    np.random.seed(1)
+    geometry = Random2DArray(radius=0.2, num_mic=M5)
+    tau = 1 / (2 * np.pi * 2000.0)
+    beamf = SNNBeamformer(geometry, 10e-3, [1000.0, 2000.0], np.asarray([tau, tau]), bipolar_spikes=True, fs=fs)
+    t = np.arange(0, 1.0, step=1 / fs)
+    chirp = np.sin(2 * np.pi * np.cumsum(1000.0 + 1000.0 * (t % t[-1]) / t[-1]) / fs)  # target_snn_localization.py:345-356
+    doa_list = np.linspace(-np.pi, np.pi, G5)
+    Wd = beamf.design_from_template((t, chirp), doa_list, svd="device", doa_batch=48)
+    assert Wd.shape == (2 * M5, G5) and np.all(np.isfinite(Wd))
+    np.testing.assert_allclose(np.linalg.norm(Wd, axis=0), 1.0, rtol=0, atol=1e-12)
+    pick = np.arange(0, G5, 131)  # 11 DoAs across the grid
+    Wh = beamf.design_from_template((t, chirp), doa_list[pick], svd="host", device_synthesis=True, doa_batch=11)
+    wd = Wd[:M5, pick] + 1j * Wd[M5:, pick]
+    wh = Wh[:M5] + 1j * Wh[M5:]
+    np.testing.assert_allclose(np.abs(np.sum(np.conj(wh) * wd, axis=0)), 1.0, rtol=0, atol=1e-8)
+    np.testing.assert_allclose(np.abs(wd.conj().T @ wd), np.abs(wh.conj().T @ wh), rtol=0, atol=1e-7)
+    assert np.all(wd[0].real < 0) and np.max(np.abs(wd[0].imag)) < 1e-12  # LAPACK's phase convention (DESIGN.md 4.6)
+
+    rng = np.random.RandomState(6)
+    time_test = np.arange(0, 100e-3, step=1 / fs)
+    doa = rng.rand(2) * 2 * np.pi
+    time_in, clean = beamf.synthesize_batch((time_test, np.sin(2 * np.pi * 2000 * time_test)), doa)
+    gen = torch.Generator(device=clean.device)
+    gen.manual_seed(8)
+    x = (clean + 0.5 * torch.randn(clean.shape, generator=gen, device=clean.device, dtype=torch.float64)).contiguous()
+    plan = beamf.plan()
+    nir = neuron_impulse_response(time_in, beamf.tau_vec)
+    plan.set_neuron_kernel(nir)
+    plan.set_bf_mat(Wd)
+    full = plan.snn_pipeline(x, want_spikes=True, want_power=True)
+    b, a = beamf.bandpass_filter
+    err = []
+    for i in range(2):
+        ref = O.snn_chain(x[i].cpu().numpy(), beamf.kernel, b, a, 24, True, nir, Wd, want=("spikes", "power"))
+        np.testing.assert_array_equal(full["spikes"][i].cpu().numpy(), ref["spikes"])
+        np.testing.assert_allclose(full["power"][i].cpu().numpy(), ref["power"], rtol=1e-12, atol=0)
+        assert int(full["argmax"][i]) == ref["argmax"]
+        err.append(abs(np.arcsin(abs(np.sin(doa_list[ref["argmax"]] - doa[i])))))
+    assert max(err) < np.deg2rad(3.0)  # the designed matrix localises (the pi-periodic error of the script, :466)
