@@ -26,8 +26,6 @@
 //
 // Summation order (== oracle): LIF over past samples in chronological order (tau ascending),
 // beamforming over channels ascending; both as fused multiply-add chains starting from +0.
-#include <cstdlib>
-
 #include "micloc_internal.h"
 
 namespace micloc {
@@ -540,9 +538,8 @@ static hipError_t launch_ws_n(const BeamformW &W, const NeuronTab &nt, const int
 {
     if constexpr (!WANT_Y && KM == 4) {
         // only the k-steps that hold channels; 6 / 10 / 14 channels: the last two on the vector ALU instead of a half-empty
-        // k-step (MICLOC_WS_K4=1 keeps four k-steps: ablation only, same results)
-        static const bool four_ksteps = getenv("MICLOC_WS_K4") != nullptr;  // read once per process
-        if (!four_ksteps) {
+        // k-step (the ws_k4 variant build keeps four k-steps: ablation only, same results)
+        if (!VARIANT_WS_FOUR_KSTEPS) {
 #define WS_K(KM_, KV_) return launch_ws_n<NGW, NT, false, KM_, KV_>(W, nt, spikes, B, T, partial, y, stream)
             switch (W.C) {  // (the plan's channel count is 2 x microphones: always even)
                 case 1: case 2: case 3: case 4: WS_K(1, 0);

@@ -8,6 +8,13 @@
 
 namespace micloc {
 
+// ---- measurement variants -------------------------------------------------------------------------------------------
+// The shipped library is built with both `false`: what runs never depends on the environment.  tools/dev/make_variant.py builds
+// tools/_variants/libmicloc_hip_<name>.so from a copy of this header with ONE of them flipped (A/B runs on one box and
+// tests/test_hip_parity.py::test_stht_vector_form_still_exact); results are identical in every variant.
+constexpr bool VARIANT_WS_FOUR_KSTEPS = false;    // ws_k4: beamform_ws_kernel multiplies four k-steps whatever the channel count
+constexpr bool VARIANT_STHT_VECTOR_FORM = false;  // stht_valu: stride-2 STHT kernels on the vector ALU instead of the matrix cores
+
 // ---- STHT ---------------------------------------------------------------------------------------
 constexpr int STHT_R = 8;                // consecutive output samples per lane (register window; groups of STHT_R delays)
 constexpr int STHT_TILE = 64 * STHT_R;   // outputs per wave-task

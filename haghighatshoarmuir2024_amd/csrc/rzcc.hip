@@ -33,7 +33,6 @@
 //     cheap serial scan stored at its boundary (see "Time chunking" below): bit-exact by construction.
 #include "micloc_internal.h"
 
-#include <stdlib.h>
 
 #include <type_traits>
 
@@ -1348,20 +1347,11 @@ size_t rzcc_scratch_bytes(int nlanes, int T, int w, int chunk_frames)
 
 int rzcc_chunks(int nlanes, int T, int w, int chunk_frames) { return rz_geom(nlanes, T, w, chunk_frames).P; }
 
-// Streams per workgroup of the spikes-only launches: 64, or 32 with MICLOC_RZ_SW=32 (measurement only; identical spikes).
-// A workgroup is a serial chain whose pace does not depend on its live lanes, so halving the streams per workgroup doubles
-// the workgroups but not the speed of a launch that is resident in one round anyway (config 2 / config 4: 241 -> 482
-// workgroups, 0.32 -> 0.31-0.36 ms / 9.0 -> 8.5 ms, profiles/r3/rz_sw_sweep.txt); what a CU can hold is bounded by
-// registers and LDS per stream, which do not shrink.  The lever for long streams is time chunking (rz_geom).
-static int rz_pick_sw()
-{
-    static const int forced = [] {
-        const char *e = getenv("MICLOC_RZ_SW");
-        return (e && atoi(e) == 32) ? 32 : 64;
-    }();
-    return forced;
-}
-
+// Streams per workgroup of the spikes-only launches: 64.  (The kernel is templated on it; 32 and 16 were measured in round 3 --
+// profiles/r3/rz_sw_sweep.txt -- and are not instantiated: a workgroup is a serial chain whose pace does not depend on its live
+// lanes, so halving the streams per workgroup doubles the workgroups but not the speed of a launch that is resident in one round
+// anyway, and what a CU can hold is bounded by registers and LDS per stream, which do not shrink.  The lever for long streams is
+// time chunking, rz_geom.)
 template <int N, int SW>
 static void launch_rz_spikes(const IirCoef &coef, const double *h, int nlanes, int C, int T, int Ts, int w, int bipolar,
                              int8_t *spikes, int *flag_count, int *flag_list, const RzGeom &g, const double *ckd, const int *cki,
@@ -1397,12 +1387,7 @@ static void launch_rz(const IirCoef &coef, const double *h, int nlanes, int C, i
         hipLaunchKernelGGL((bandpass_rzcc_fast_kernel<N, true, true>), grid, block, 0, stream, h, pre, spikes,
                            flag_count, flag_list, coef, nlanes, C, T, Ts, w, bipolar, xin, M, shift, g, nblk, ckd, cki, RzStream{});
     else if (spikes) {
-        if (rz_pick_sw() == 32)
-            launch_rz_spikes<N, 32>(coef, h, nlanes, C, T, Ts, w, bipolar, spikes, flag_count, flag_list, g, ckd, cki, xin, M,
-                                    shift, stream);
-        else
-            launch_rz_spikes<N, 64>(coef, h, nlanes, C, T, Ts, w, bipolar, spikes, flag_count, flag_list, g, ckd, cki, xin, M,
-                                    shift, stream);
+        launch_rz_spikes<N, 64>(coef, h, nlanes, C, T, Ts, w, bipolar, spikes, flag_count, flag_list, g, ckd, cki, xin, M, shift, stream);
     } else
         hipLaunchKernelGGL((bandpass_rzcc_fast_kernel<N, true, false>), grid, block, 0, stream, h, pre, spikes,
                            flag_count, flag_list, coef, nlanes, C, T, Ts, w, bipolar, xin, M, shift, g, nblk, ckd, cki, RzStream{});

@@ -17,7 +17,6 @@
 // Arithmetic contract (== oracle/micloc_oracle.c oracle_stht): acc = +0; for taps k ascending:
 // acc = fma(ker[k], x[t-k], acc); exact-zero taps contribute nothing (skipped when every second tap
 // is zero, which is the case for every even-length Hilbert kernel).
-#include <cstdlib>
 
 #include "micloc_internal.h"
 
@@ -451,12 +450,8 @@ size_t stht_lds_bytes(const SthtTaps &tp, int M)
 hipError_t launch_stht(const SthtTaps &tp, const double *x, double *h, int B, int T, int M, int Ts,
                        hipStream_t stream, bool write_re)
 {
-    // every second tap zero: the matrix-core form, if its tile fits LDS (MICLOC_STHT_VALU=1: never), in-phase rows by a copy kernel
-    static const bool force_valu = [] {
-        const char *e = getenv("MICLOC_STHT_VALU");
-        return e && e[0] == '1';
-    }();
-    if (tp.kstep == 2 && tp.ngroups > 0 && !force_valu && ((size_t)B * M + 15) / 16 <= 65535 && B <= 65535) {
+    // every second tap zero: the matrix-core form, if its tile fits LDS (never in the stht_valu variant build), in-phase rows by a copy kernel
+    if (tp.kstep == 2 && tp.ngroups > 0 && !VARIANT_STHT_VECTOR_FORM && ((size_t)B * M + 15) / 16 <= 65535 && B <= 65535) {
         const int J = tp.ngroups * (STHT_R / tp.kstep);  // compact taps incl. the zero padding of the last group
         const int NK = (J + 15 + 3) / 4;
         // two workgroups per CU if the tile allows it

@@ -21,6 +21,12 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_build", "libmicloc_oracle.so")
+# sanitizer run of the CPU suite (tests/test_oracle_sanitized.py): MICLOC_ORACLE_SO selects the AddressSanitizer + UBSan build
+# (oracle/Makefile: _build/libmicloc_oracle_asan.so); the process must then be started with LD_PRELOAD=libasan.so
+_SO_NAME = os.path.basename(os.environ.get("MICLOC_ORACLE_SO", "")) or "libmicloc_oracle.so"
+if _SO_NAME not in ("libmicloc_oracle.so", "libmicloc_oracle_asan.so"):
+    raise ImportError(f"MICLOC_ORACLE_SO must name libmicloc_oracle.so or libmicloc_oracle_asan.so, got {_SO_NAME}")
+_SO = os.path.join(_HERE, "_build", _SO_NAME)
 _lib = None
 
 _dp = ctypes.POINTER(ctypes.c_double)
@@ -33,7 +39,7 @@ def build(force=False):
     """Compile oracle/_build/libmicloc_oracle.so with gcc (a few hundred ms)."""
     src = os.path.join(_HERE, "micloc_oracle.c")
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-s", "-C", _HERE, "_build/libmicloc_oracle.so"])
+        subprocess.check_call(["make", "-s", "-C", _HERE, "_build/" + _SO_NAME])
     return _SO
 
 

@@ -604,14 +604,21 @@ def test_planar_gram_against_numpy(torch):
 
 
 def test_stht_vector_form_still_exact():
-    """MICLOC_STHT_VALU=1 (the A/B switch of tools/dev/ab_headline.sh) sends stride-2 kernels through the vector-ALU STHT again:
-    a fresh child process (the switch is read once per process) checks it against the oracle like test_stht_bit_exact does."""
+    """The vector-ALU STHT (stht_kernel) serves dense and very long kernels in the product; for the stride-2 Hilbert kernels it is the A/B
+    partner of the matrix-core form.  The `stht_valu` variant library (tools/dev/make_variant.py: the same sources with
+    VARIANT_STHT_VECTOR_FORM flipped, built by __graft_entry__.build()) sends them through it: a fresh child process loads that
+    library and checks it against the oracle like test_stht_bit_exact does.  (The shipped library has no run-time switch.)"""
     import subprocess
     import sys
 
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    variant = os.path.join(root, "tools", "_variants", "libmicloc_hip_stht_valu.so")
+    assert os.path.exists(variant), "tools/_variants/libmicloc_hip_stht_valu.so missing: run __graft_entry__.build() (tools/dev/make_variant.py stht_valu)"
     code = r"""
 import numpy as np, sys
 sys.path.insert(0, %r); sys.path.insert(0, %r)
+from haghighatshoarmuir2024_amd import _lib
+_lib.LIB_PATH = %r
 from oracle import oracle as O
 from haghighatshoarmuir2024_amd.runtime import Plan
 fs = 48000
@@ -626,7 +633,7 @@ for T in (33, 700, 1500):
         re, im = O.stht(x[i], ker)
         assert np.array_equal(h[i][:, :7], re) and np.array_equal(h[i][:, 7:], im), T
 print("ok")
-""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, MICLOC_STHT_VALU="1")
+""" % (root, os.path.dirname(os.path.abspath(__file__)), variant)
+    env = dict(os.environ)
     r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert r.returncode == 0 and b"ok" in r.stdout, r.stderr.decode()[-2000:]

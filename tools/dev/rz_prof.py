@@ -55,7 +55,7 @@ lib.micloc_debug_rz_prof(buf, 1)
 v = np.array(list(buf), dtype=np.float64).reshape(3, 8)
 P = plan.encoder_chunks(B, T)
 ntile = (T + 15) // 16
-print(f"{cfg} B={B} T={T} chunk={chunk} P={P} SW={os.environ.get('MICLOC_RZ_SW', 'auto')}: stage {e0.elapsed_time(e1):.3f} ms (incl. zero fill, scan, fallback)")
+print(f"{cfg} B={B} T={T} chunk={chunk} P={P}: stage {e0.elapsed_time(e1):.3f} ms (incl. zero fill, scan, fallback)")
 names = ["loader0", "loader1", "filter", "detect", "select+", "select-", "writer", "-"]
 for w in range(8):
     if v[2, w] == 0:

@@ -1,8 +1,8 @@
 #!/bin/bash
-# Round profiling recipe (run on the GPU box from the repo root: gpurun -- 'bash tools/profile_round.sh r3').
+# Round profiling recipe (run on the GPU box from the repo root: gpurun -- 'bash tools/profile_round.sh r4').
 # Writes raw rocprofv3 output and bench JSONs under gpurun_out/<tag>/; copy the summaries into profiles/<tag>/.
 set -u
-TAG=${1:-r3}
+TAG=${1:-r4}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -21,32 +21,11 @@ rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace_xylo -o run -
 # API-faithful mode (y stored) and the store-pattern microbenchmark behind its design
 (python3 tools/k3_time.py 360 1100 1; python3 tools/k3_time.py 449 1100 1; python3 tools/k3_time.py 360 1100 0; python3 tools/k3_time.py 449 1100 0) > $OUT/y_store.txt 2>/dev/null
 hipcc -O3 --offload-arch=gfx950 -o /tmp/store_bw tools/store_bw.hip > /dev/null 2>&1 && /tmp/store_bw > $OUT/store_bw.txt 2>&1
-# ablation: four MFMA k-steps for 14 channels instead of 3 + 2 channels on the vector ALU (same box, alternating)
-for i in 1 2; do
-  python3 bench.py --steps 40 --warmup 4 --no-cpu-baseline --no-other-configs | tail -1 > $OUT/ab_kv_$i.json 2>/dev/null
-  MICLOC_WS_K4=1 python3 bench.py --steps 40 --warmup 4 --no-cpu-baseline --no-other-configs | tail -1 > $OUT/ab_k4_$i.json 2>/dev/null
-done
-python3 - <<PY > $OUT/ablation_kstep.txt
-import json
-for tag in ("kv", "k4"):
-    for i in (1, 2):
-        d = json.load(open("$OUT/ab_%s_%d.json" % (tag, i)))
-        print(tag, i, "ms_per_step %.4f" % d["ms_per_step"], "value %.4g" % d["value"], "beamform launch %.4f ms" % d["roofline"]["avg_launch_ms"], "frac %.3f" % d["roofline"]["frac"])
-PY
-rm -f $OUT/ab_kv_*.json $OUT/ab_k4_*.json
-# ablation: the STHT on the vector ALU (round 2's kernel) instead of the matrix cores (same box, alternating)
-for i in 1 2; do
-  python3 bench.py --steps 40 --warmup 4 --no-cpu-baseline --no-other-configs | tail -1 > $OUT/ab_mfma_$i.json 2>/dev/null
-  MICLOC_STHT_VALU=1 python3 bench.py --steps 40 --warmup 4 --no-cpu-baseline --no-other-configs | tail -1 > $OUT/ab_valu_$i.json 2>/dev/null
-done
-python3 - <<PY > $OUT/ablation_stht.txt
-import json
-for tag in ("mfma", "valu"):
-    for i in (1, 2):
-        d = json.load(open("$OUT/ab_%s_%d.json" % (tag, i)))
-        print("stht", tag, i, "ms_per_step %.4f" % d["ms_per_step"], "value %.4g" % d["value"], "e2e ms_per_step %.4f" % d["e2e"]["ms_per_step"])
-PY
-rm -f $OUT/ab_mfma_*.json $OUT/ab_valu_*.json
+# ablations on the same box, alternating the in-tree library with a variant build (tools/dev/make_variant.py; no run-time switches):
+#   ws_k4      four MFMA k-steps for 14 channels instead of 3 + 2 channels on the vector ALU
+#   stht_valu  the STHT on the vector ALU (round 2's kernel) instead of the matrix cores
+bash tools/dev/ab_lib.sh tools/_variants/libmicloc_hip_ws_k4.so "--steps 40 --warmup 4" > $OUT/ablation_kstep.txt 2>&1
+bash tools/dev/ab_lib.sh tools/_variants/libmicloc_hip_stht_valu.so "--steps 40 --warmup 4" > $OUT/ablation_stht.txt 2>&1
 # counters: separate passes, nothing but --pmc (+ kernel trace)
 for cfg in noisy stress speech xylo; do
   steps=6; [ $cfg = speech ] && steps=2; [ $cfg = xylo ] && steps=2

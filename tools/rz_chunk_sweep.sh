@@ -3,14 +3,14 @@
 set -u
 OUT=gpurun_out/${1:-rzchunk}
 mkdir -p $OUT
-for sw in 64 32 16; do
+for sw in 64; do
 for ch in -1 24000 12000 6000 3000; do
-  MICLOC_RZ_SW=$sw python3 bench.py --config xylo --steps 4 --warmup 1 --encoder-chunk $ch 2> $OUT/xylo_${sw}_$ch.err | tail -1 > $OUT/xylo_${sw}_$ch.json
+  python3 bench.py --config xylo --steps 4 --warmup 1 --encoder-chunk $ch 2> $OUT/xylo_${sw}_$ch.err | tail -1 > $OUT/xylo_${sw}_$ch.json
 done
 done
 python3 - <<PY > $OUT/summary.txt
 import json
-for sw in (64, 32, 16):
+for sw in (64,):
     for ch in (-1, 24000, 12000, 6000, 3000):
         try:
             d = json.load(open("$OUT/xylo_%d_%d.json" % (sw, ch)))
