@@ -56,6 +56,10 @@ def parse(argv=None):
     ap.add_argument("--repeats", type=int, default=5, help="the K-step timed region is run this many times; ms_per_step / value are the median")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the speech / xylo / stress child runs and the reference-MAE / per-call blocks")
     ap.add_argument("--streams", type=int, default=3, help="HIP streams consecutive steps are pipelined over (1 = serial)")
+    ap.add_argument("--cpu-cores", type=int, default=None, help="pin every rank to this many host cores (its own slice of the allowed set) before "
+                    "anything touches the GPU: 2 = a rank's share of a 16-core cgroup at 8 ranks")
+    ap.add_argument("--baseline-total", action="store_true", help="speech / stress: split BASELINE's sweep totals (1000 / 16384 trials) over the "
+                    "ranks (strong scaling: total work fixed) instead of a fixed batch per rank")
     ap.add_argument("--encoder-chunk", type=int, default=None, help="frames per time chunk of the band-pass / RZCC stage (default: the library's automatic choice; < 0: never chunk)")
     ap.add_argument("--traffic-bytes", type=float, default=None, help="override roofline.traffic (HBM bytes per dominant-kernel launch)")
     ap.add_argument("--pmc-summary", default=None, help="committed rocprofv3 PMC summary to read roofline.traffic from (default: newest profiles/r*/pmc_summary.csv)")
@@ -152,12 +156,12 @@ def build_workload(args, rank, device):
         np.random.seed(1)  # Random2DArray draws from the global NumPy stream (array_geometry.py:126-127)
         geometry = Random2DArray(radius=0.2, num_mic=num_mic)
         G = args.grid or 1440
-        B = args.trials or 256
+        B = args.trials or (-(-16384 // max(1, args.world)) if args.baseline_total else 256)
     else:
         fs, num_mic = 48_000, 7
         geometry = CenterCircularArray(radius=4.5e-2, num_mic=num_mic)
         G = args.grid or 360
-        B = args.trials or (125 if cfg == "speech" else 1100)
+        B = args.trials or ((-(-1000 // max(1, args.world)) if args.baseline_total else 125) if cfg == "speech" else 1100)
     beamf = SNNBeamformer(geometry=geometry, kernel_duration=10.0e-3, tau_vec=np.asarray([tau, tau]), freq_range=freq_range, fs=fs,
                           bipolar_spikes=True, device=device)
     doa_list = np.linspace(-np.pi, np.pi, G)
@@ -180,15 +184,21 @@ def build_workload(args, rank, device):
         time_test = np.arange(0, 100e-3, step=1 / fs)
         sig_test = np.sin(2 * np.pi * freq_design * time_test)
         snr_gain = (fs / 2) / (freq_range[1] - freq_range[0])
-    rng = np.random.RandomState(1000 + rank)
-    doa = rng.rand(B) * 2 * np.pi
     snr_db_vec = np.linspace(-10, 20, 11)
     groups = len(snr_db_vec) if B % len(snr_db_vec) == 0 else 1
     snr_db = snr_db_vec[(np.arange(B) * len(snr_db_vec)) // B] - 10 * np.log10(snr_gain)
     from haghighatshoarmuir2024_amd import synthesis
 
-    time_in, x = beamf.synthesize_batch((time_test, sig_test), doa)  # device synthesis, bit-exact with np.interp
-    synthesis.add_noise_(x, snr_db, seed=1234, first_trial=rank * B)   # Philox-4x32-10 + Box-Muller kernel, in place
+    def make_batch(i):
+        """Batch i of this rank: its own DoAs and its own noise (Philox substream i; trials numbered globally) -- consecutive
+        steps of the timed loop are INDEPENDENT batches, one resident input tensor per HIP stream."""
+        rng = np.random.RandomState(1000 + rank + 7919 * i)
+        doa_i = rng.rand(B) * 2 * np.pi
+        t_in, x_i = beamf.synthesize_batch((time_test, sig_test), doa_i)  # device synthesis, bit-exact with np.interp
+        synthesis.add_noise_(x_i, snr_db, seed=1234, substream=i, first_trial=rank * B)  # Philox-4x32-10 + Box-Muller kernel, in place
+        return t_in, x_i, doa_i
+
+    time_in, x, doa = make_batch(0)
 
     plan = beamf.plan()
     nir = neuron_impulse_response(time_in[: min(len(time_in), 48_000)], beamf.tau_vec)
@@ -198,7 +208,8 @@ def build_workload(args, rank, device):
         plan.set_encoder_chunk(args.encoder_chunk)
     return dict(beamf=beamf, plan=plan, x=x, doa=torch.from_numpy(doa).to(device), doa_list=torch.from_numpy(doa_list).to(device),
                 bf_mat=bf_mat, nir=nir, snr_groups=groups, fs=fs, encoder_chunk=args.encoder_chunk,
-                template=(time_test, sig_test), snr_db=snr_db, rank=rank, design_seconds=t_design, freq_range=freq_range)
+                template=(time_test, sig_test), snr_db=snr_db, rank=rank, design_seconds=t_design, freq_range=freq_range,
+                make_batch=make_batch)
 
 
 def make_step(wl, nstreams, variants=True):
@@ -209,24 +220,32 @@ def make_step(wl, nstreams, variants=True):
     from haghighatshoarmuir2024_amd import runtime
     from haghighatshoarmuir2024_amd.runtime import StreamPipeline
 
+    import torch as _torch
+
     x, doa, doa_list, S = wl["x"], wl["doa"], wl["doa_list"], wl["snr_groups"]
     plans = [wl["plan"]]
-    for _ in range(nstreams - 1):
+    # one resident batch per stream: stream 0 replays wl["x"] (the batch the CPU baseline and the stage timers see), the others their
+    # own trials -- three readers of ONE tensor would share L2 / Infinity-Cache hits a real sweep does not get
+    inputs = {id(wl["plan"]): (x, doa)}
+    for i in range(1, nstreams):
         p = wl["beamf"].new_plan()
         p.set_neuron_kernel(wl["nir"])
         p.set_bf_mat(wl["bf_mat"])
         if wl.get("encoder_chunk") is not None:
             p.set_encoder_chunk(wl["encoder_chunk"])
         plans.append(p)
+        _, x_i, doa_i = wl["make_batch"](i)
+        inputs[id(p)] = (x_i, _torch.from_numpy(doa_i).to(x.device))
     pipe = StreamPipeline(plans)
 
     def body(plan, cov=False):
+        xs, doas = inputs[id(plan)]
         if cov == "f32":
-            out = plan.snn_pipeline_f32bf(x)
+            out = plan.snn_pipeline_f32bf(xs)
         else:
-            out = plan.snn_pipeline_cov(x, want_power=True) if cov else plan.snn_pipeline(x, want_power=True)
+            out = plan.snn_pipeline_cov(xs, want_power=True) if cov else plan.snn_pipeline(xs, want_power=True)
         # DoA error per trial + MAE per SNR on the device (micloc_doa_error_f64): the graph holds micloc kernels only
-        _, mae = runtime.doa_error(out["argmax"], doa_list, doa, groups=S, want_err=False)
+        _, mae = runtime.doa_error(out["argmax"], doa_list, doas, groups=S, want_err=False)
         return out, mae
 
     # one HIP graph per stream (pipeline kernels + the DoA-error / MAE kernel), replayed round-robin
@@ -270,15 +289,16 @@ def make_step(wl, nstreams, variants=True):
 
     replay_e2e = pipe.capture(body_e2e)
 
-    def step(cov=False):
+    def step(cov=False, index=None):
+        # index: replay a given stream's graph (the comparisons between variants read stream 0's batch, wl["x"])
         if cov == "e2e":
-            return replay_e2e()
+            return replay_e2e(index)
         if cov == "f32":
-            return replay_f32()
-        return replay_cov() if cov else replay_direct()
+            return replay_f32(index)
+        return replay_cov(index) if cov else replay_direct(index)
 
     # every tensor a captured graph reads must outlive it: the replay closures hold the graphs and their outputs only
-    step.keepalive = (e2e_state, tpl, geo, snr_dev, x, doa, doa_list, plans)
+    step.keepalive = (e2e_state, tpl, geo, snr_dev, x, doa, doa_list, plans, inputs)
     return step, pipe
 
 
@@ -519,25 +539,31 @@ def api_per_call_block(device, calls=40):
 
     def one():
         doa = np.random.rand(1)[0] * 2 * np.pi
-        y = beamf.apply_to_template(bf_mat=bf_mat, template=(time_test, sig_test, doa), snr_db=snr_db)
-        power = np.mean(np.abs(y) ** 2, axis=0)
-        return y, int(np.argmax(power))
+        t0 = time.perf_counter()
+        y = beamf.apply_to_template(bf_mat=bf_mat, template=(time_test, sig_test, doa), snr_db=snr_db)  # the library call
+        t1 = time.perf_counter()
+        power = np.mean(np.abs(y) ** 2, axis=0)  # the script's own lines :462-464
+        am = int(np.argmax(power))
+        return y, am, t1 - t0, time.perf_counter() - t1
 
     for _ in range(3):
-        y, _ = one()
+        y = one()[0]
     torch.cuda.synchronize()
-    ts = []
+    ts, tp = [], []
     for _ in range(calls):
-        t0 = time.perf_counter()
-        one()
-        ts.append(time.perf_counter() - t0)
+        r = one()
+        ts.append(r[2])
+        tp.append(r[3])
     ts = np.asarray(ts) * 1e3
+    tp = np.asarray(tp) * 1e3
     return {"apply_to_template_ms": float(np.median(ts)), "min_ms": float(ts.min()), "max_ms": float(ts.max()), "calls": calls,
-            "returns": f"numpy float64 [{y.shape[0]} x {y.shape[1]}] on the host ({y.nbytes / 1e6:.1f} MB D2H per call)",
-            "frames_per_s": float(y.shape[0] / (np.median(ts) * 1e-3)),
+            "script_power_argmax_ms": float(np.median(tp)), "trial_ms": float(np.median(ts + tp)),
+            "returns": f"numpy float64 [{y.shape[0]} x {y.shape[1]}] on the host ({y.nbytes / 1e6:.1f} MB D2H per call into a page-locked block)",
+            "frames_per_s": float(y.shape[0] / (np.median(ts + tp) * 1e-3)),
             "reference_ms_per_trial": "24.7-27.5 (8 vCPU Xeon 2.1 GHz, SURVEY 6)",
-            "note": "one trial per call exactly as the script's loop does it: host synthesis + host MT19937 noise (reference draw order), H2D, "
-                    "STHT -> RZCC -> LIF -> beamforming with y stored, D2H of T x G, power / arg-max in NumPy; PCIe- and host-bound, never `value`"}
+            "note": "one trial per call exactly as the script's loop does it.  apply_to_template_ms = the library call: host synthesis + host MT19937 noise "
+                    "(reference draw order), H2D, STHT -> RZCC -> LIF -> beamforming with y stored, D2H of T x G; script_power_argmax_ms = the caller's "
+                    "own np.mean(np.abs(y)**2) / np.argmax on the returned array; trial_ms = both.  PCIe- and host-bound, never `value`"}
 
 
 def beamformer_c128_block(wl, args):
@@ -631,6 +657,17 @@ def other_configs_block(args):
     """The other BASELINE configs on the same box, a few steps each, as CHILD processes of this (GPU-initialised) process --
     started, never exec'ed; one at a time."""
     out = {}
+    # the headline once more with this process's children pinned to TWO host cores: at 8 ranks a 16-core cgroup leaves each rank two,
+    # and 3 streams of graph replays per rank must not become host bound there
+    try:
+        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-cores", "2", "--steps", str(args.steps), "--warmup", str(args.warmup), "--repeats", "3",
+               "--no-cpu-baseline", "--no-other-configs", "--streams", str(args.streams)]
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
+        d = json.loads([ln for ln in p.stdout.decode(errors="replace").splitlines() if ln.startswith("{")][-1])
+        out["noisy_on_2_host_cores"] = {"ms_per_step": d["ms_per_step"], "value": d["value"], "cpu_cores": d["cpu_cores_per_rank"],
+                                        "note": "the default workload with the process pinned to 2 host cores (--cpu-cores 2): a rank's share at 8 ranks per 16-core cgroup"}
+    except Exception as e:
+        out["noisy_on_2_host_cores"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     # (enough steps per timed region for the three streams to drift out of step: with one step per stream they start together and
     #  finish together, which is not the steady state -- xylo 18.0 ms/step at 3 steps, 17.0 at 12)
     for cfg, steps in (("speech", 9), ("xylo", 12), ("stress", 9)):
@@ -731,6 +768,7 @@ def run_xylo(args, rank, local_rank, world):
     for _ in range(args.warmup):
         replay()
     dt_all = []
+    per_rank = []
     for _ in range(max(1, args.repeats)):
         barrier()
         t0 = time.perf_counter()
@@ -739,7 +777,12 @@ def run_xylo(args, rank, local_rank, world):
         barrier()
         dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
         if use_dist:
+            every = [torch.empty_like(dt) for _ in range(world)]
+            dist.all_gather(every, dt)
+            per_rank.append([float(v.item()) for v in every])
             dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        else:
+            per_rank.append([float(dt.item())])
         dt_all.append(float(dt.item()))
     if use_dist:
         gathered = [torch.empty_like(mae) for _ in range(world)]
@@ -797,6 +840,8 @@ def run_xylo(args, rank, local_rank, world):
             "value": value, "unit": "frames/s (one frame = one audio sample instant across all mics)",
             "n_gpus": group_size, "rccl_ranks": group_size if use_dist else 0, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "ms_per_step_repeats": [t / args.steps * 1e3 for t in dt_all],
+            "ms_per_step_per_rank": (np.median(np.asarray(per_rank), axis=0) / args.steps * 1e3).tolist(),
+            "cpu_cores_per_rank": args.cpu_cores or usable_cores(),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64 encoder + int16 LIF state / int8 weights", "data": "synthetic",
             "parity": "UNPINNED for the integer-LIF stage (rockpool / XyloSim absent); spike encoding and peak finding pinned",
@@ -828,6 +873,7 @@ def run(args):
 
     if world != args.gpus and world > 1:
         args.gpus = world
+    args.world = world
     if local_rank >= torch.cuda.device_count():
         print(f"bench.py: rank {rank} has no device (LOCAL_RANK {local_rank}, {torch.cuda.device_count()} visible)", file=sys.stderr)
         return 2
@@ -859,6 +905,8 @@ def run(args):
             dist.barrier()
         torch.cuda.synchronize()
 
+    per_rank = []  # one list per timed region (headline regions first)
+
     def timed_steps(fn, repeats=1):
         """W warm-up steps, then `repeats` timed regions of EXACTLY K steps, each bracketed by barrier + synchronize on both
         sides and reduced with MAX over ranks.  Returns (median seconds per region, all regions, last result)."""
@@ -874,11 +922,17 @@ def run(args):
             barrier()
             t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
             if use_dist:
+                every = [torch.empty_like(t) for _ in range(world)]
+                dist.all_gather(every, t)  # every rank's own clock: a straggler shows up by name, not only in the MAX
+                per_rank.append([float(v.item()) for v in every])
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            else:
+                per_rank.append([float(t.item())])
             times.append(float(t.item()))
         return float(np.median(times)), times, res
 
     dt, dt_all, (out, mae) = timed_steps(step, args.repeats)
+    ms_per_rank = (np.median(np.asarray(per_rank[: len(dt_all)]), axis=0) / args.steps * 1e3).tolist()
     if use_dist:
         # the sweep's one exchange step: gather the per-rank MAE curves (RCCL)
         gathered = [torch.empty_like(mae) for _ in range(world)]
@@ -886,6 +940,9 @@ def run(args):
         mae = torch.stack(gathered).mean(dim=0)
     frames = group_size * B * T * args.steps
     value = frames / dt
+    # comparisons between the variants and with the CPU baseline use stream 0's batch (wl["x"]): every stream has its own trials
+    out, _ = step(index=0)
+    pipe.synchronize()
     argmax_direct = out["argmax"].clone()  # graph outputs are static buffers: keep a copy for the comparisons below
     power_direct = out["power"].clone()
 
@@ -904,14 +961,18 @@ def run(args):
     cov_variant = f32_variant = None
     if M * 2 <= 128:
         # separately reported algorithmic variant: covariance-form power, same K steps, same inputs
-        dtc, _, (out_c, _) = timed_steps(lambda: step(cov=True))
+        dtc, _, _ = timed_steps(lambda: step(cov=True))
+        out_c, _ = step(cov=True, index=0)
+        pipe.synchronize()
         cov_variant = {"value": frames / dtc, "unit": "frames/s", "ms_per_step": dtc / args.steps * 1e3,
                        "argmax_equal_to_direct": bool(torch.equal(out_c["argmax"], argmax_direct)),
                        "max_rel_power_diff_vs_direct": float((out_c["power"] / power_direct - 1).abs().max().item()),
                        "note": "power = w^T (V^T V / T) w instead of mean_t (V w)^2: algebraically identical, 2C^2 instead of 2CG flops per frame; not the headline"}
     if noisy and M * 2 <= 64:
         # second separately reported variant: fp32-MFMA beamforming tail (fp64 up to the spikes)
-        dtf, _, (out_f, _) = timed_steps(lambda: step(cov="f32"))
+        dtf, _, _ = timed_steps(lambda: step(cov="f32"))
+        out_f, _ = step(cov="f32", index=0)
+        pipe.synchronize()
         relerr = float((out_f["power"] / power_direct - 1).abs().max().item())
         f32_variant = {"value": frames / dtf, "unit": "frames/s", "ms_per_step": dtf / args.steps * 1e3,
                        "argmax_equal_to_f64": int((out_f["argmax"] == argmax_direct).sum().item()), "trials": int(B),
@@ -971,9 +1032,11 @@ def run(args):
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "ms_per_step_repeats": [t / args.steps * 1e3 for t in dt_all],
+            "ms_per_step_per_rank": ms_per_rank,
+            "cpu_cores_per_rank": args.cpu_cores or usable_cores(),
             "timing_note": f"median of {len(dt_all)} timed regions of exactly {args.steps} steps each (barrier + synchronize on both sides, max over ranks)",
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if (args.baseline_total and args.config in ("speech", "stress")) else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
@@ -1023,9 +1086,21 @@ def run(args):
     return 0
 
 
+def pin_cpu_cores(n, slot):
+    """Restrict this process to `n` of the host cores it may use: slice number `slot` of the allowed set (ranks get disjoint
+    slices while they last).  Called before any GPU call, so the HIP runtime's helper threads inherit the mask."""
+    allowed = sorted(os.sched_getaffinity(0))
+    n = max(1, min(int(n), len(allowed)))
+    lo = (slot * n) % max(1, len(allowed) - n + 1)
+    os.sched_setaffinity(0, set(allowed[lo : lo + n]))
+    return n
+
+
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else list(argv)
     args = parse(argv)
+    if args.cpu_cores and "WORLD_SIZE" in os.environ or (args.cpu_cores and args.gpus == 1):
+        args.cpu_cores = pin_cpu_cores(args.cpu_cores, int(os.environ.get("LOCAL_RANK", 0)))
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # still GPU-free here: nothing above imported torch.cuda state or loaded libmicloc_hip.so
         return launch_ranks(args, argv)

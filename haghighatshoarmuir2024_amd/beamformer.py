@@ -59,7 +59,7 @@ class Beamformer:
         plan = self.plan()
         plan.set_bf_mat(np.asarray(bf_mat, dtype=np.complex128))
         x = plan.to_device(np.asarray(sig_in, dtype=np.float64)[None])
-        return plan.beamformer_pipeline(x, want_y=True, want_power=False)["y"][0].cpu().numpy()
+        return runtime.to_host(plan.beamformer_pipeline(x, want_y=True, want_power=False)["y"][0])
 
     def localize_batch(self, bf_mat, sig_batch):
         B, T, M = sig_batch.shape

@@ -30,6 +30,17 @@ def require_gpu(device=None):
     return device
 
 
+def to_host(t):
+    """Device tensor -> NumPy array owned by the caller, through page-locked memory: the array is backed by a pinned block of
+    torch's caching host allocator (one DMA, no staging copy; the block goes back to the cache when the caller drops the array --
+    the script's loop, paper_plots/target_snn_localization.py:455-464, recycles it every trial).  Synchronises the current stream."""
+    torch = _torch()
+    host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    host.copy_(t, non_blocking=True)
+    torch.cuda.current_stream(t.device).synchronize()
+    return host.numpy()
+
+
 def _dptr(a):
     return a.ctypes.data_as(_lib.c_double_p)
 
@@ -657,9 +668,13 @@ class StreamPipeline:
         state = {"next": 0}
         plans = self.plans
 
-        def replay():
-            i = state["next"] % len(graphs)
-            state["next"] += 1
+        def replay(index=None):
+            """Launch the next stream's graph (round-robin), or stream `index`'s without advancing the rotation."""
+            if index is None:
+                i = state["next"] % len(graphs)
+                state["next"] += 1
+            else:
+                i = int(index) % len(graphs)
             if plans[i].generation != graphs[i][2]:
                 # the graph holds raw device pointers of tables / workspace that have been re-allocated since
                 raise _lib.MiclocError("stale HIP graph: the plan's tables or workspace were re-allocated, or a table changed its "

@@ -127,7 +127,7 @@ class SNNBeamformer:
         plan.set_bf_mat(np.asarray(bf_mat, dtype=np.float64))
         x = plan.to_device(np.asarray(sig_in_vec, dtype=np.float64)[None])
         out = plan.snn_pipeline(x, want_y=True, want_power=False)
-        return out["y"][0].cpu().numpy()
+        return runtime.to_host(out["y"][0])
 
     def apply_to_template(self, bf_mat, template, snr_db):
         try:
