@@ -56,6 +56,8 @@ def parse(argv=None):
     ap.add_argument("--repeats", type=int, default=5, help="the K-step timed region is run this many times; ms_per_step / value are the median")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the speech / xylo / stress child runs and the reference-MAE / per-call blocks")
     ap.add_argument("--streams", type=int, default=3, help="HIP streams consecutive steps are pipelined over (1 = serial)")
+    ap.add_argument("--xylo-lif", default="static", help="xylo: 'static' (one workgroup per trial: what the three-stream step runs best with) or "
+                    "'queue' / 'queue:<workgroups per CU>' (persistent workgroups on the ticket queue: the faster launch when it runs alone)")
     ap.add_argument("--cpu-cores", type=int, default=None, help="pin every rank to this many host cores (its own slice of the allowed set) before "
                     "anything touches the GPU: 2 = a rank's share of a 16-core cgroup at 8 ranks")
     ap.add_argument("--baseline-total", action="store_true", help="speech / stress: split BASELINE's sweep totals (1000 / 16384 trials) over the "
@@ -747,11 +749,13 @@ def run_xylo(args, rank, local_rank, world):
             pl.set_encoder_chunk(args.encoder_chunk)
     pipe = runtime.StreamPipeline(plans)
 
+    lif_kw = dict(queued=False) if args.xylo_lif == "static" else dict(queued=True, workers_per_cu=int((args.xylo_lif.split(":") + ["0"])[1]))
+
     def body(pl):
         # STHT + band-pass + RZCC of the fused pipeline (Demo.raster_device): only the quadrature rows go through HBM, the encoder reads
         # the in-phase ones -- the rolled input frames -- from x itself
         raster = pl.snn_pipeline(x, want_spikes=True, want_power=False, stages=3)["spikes"]
-        counts = net.run(raster, ternary=True)[1]  # the +/- split of spike_encoding happens in the kernel's staging loop
+        counts = net.run(raster, ternary=True, **lif_kw)[1]  # the +/- split of spike_encoding happens in the kernel's staging loop
         idx = runtime.peak_location(counts, G, win)
         _, mae = runtime.doa_error(idx, d_list, d_doa, groups=groups, want_err=False)
         return counts, idx, mae
@@ -808,9 +812,10 @@ def run_xylo(args, rank, local_rank, world):
         raster = stage_out["spikes"]
         st = {"stht_kernel": timed(lambda: plan.snn_pipeline(x, want_spikes=True, want_power=False, stages=1, out=stage_out)),
               "bandpass_rzcc_kernel": timed(lambda: plan.snn_pipeline(x, want_spikes=True, want_power=False, stages=2, out=stage_out)),
-              "xylo_lif_kernel": timed(lambda: net.run(raster, ternary=True)),
+              "xylo_lif_kernel": timed(lambda: net.run(raster, ternary=True, **lif_kw)),
+              "xylo_lif_queue_alone": timed(lambda: net.run(raster, ternary=True, queued=True)),
               "peak_location_kernel": timed(lambda: runtime.peak_location(counts, G, win))}
-        dom = max(st, key=st.get)
+        dom = max((k for k in st if k != "xylo_lif_queue_alone"), key=st.get)
         N = net.N
         nblocks = -(-N // 512)
         waves_per_trial = 4 * nblocks if nblocks > 1 else -(-N // 128)

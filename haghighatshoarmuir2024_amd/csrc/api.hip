@@ -947,6 +947,24 @@ int micloc_xylo_lif_resident_i16(const void *spikes_in, int ternary_channels, in
     return MICLOC_OK;
 }
 
+size_t micloc_xylo_sweep_scratch_bytes(int B)
+{
+    if (bad_batch(B)) return 0;
+    return xylo_sweep_scratch_bytes(B);
+}
+
+int micloc_xylo_lif_sweep_i16(const int8_t *raster, int ternary_channels, int B, int T, int Cin, int N, int max_spikes, int32_t *rate,
+                              void *ws, size_t ws_bytes, void *scratch, size_t scratch_bytes, int workers_per_cu, void *stream)
+{
+    if (!raster || !rate || bad_batch(B) || T < 1 || Cin < 1 || N < 1 || max_spikes < 1 || workers_per_cu < 0 || workers_per_cu > 8) return MICLOC_ERR_INVALID;
+    if (Cin > 64 || ternary_channels < 1 || Cin != 2 * ternary_channels) return MICLOC_ERR_SHAPE;
+    if (bad_ws(ws, ws_bytes, xylo_ws_bytes(Cin, N))) return MICLOC_ERR_WORKSPACE;
+    if (bad_ws(scratch, scratch_bytes, xylo_sweep_scratch_bytes(B))) return MICLOC_ERR_WORKSPACE;
+    DeviceGuard guard(device_of(ws));
+    HIP_TRY(launch_xylo_sweep(raster, ternary_channels, B, T, Cin, N, max_spikes, rate, ws, scratch, workers_per_cu, (hipStream_t)stream));
+    return MICLOC_OK;
+}
+
 int micloc_design_vectors_f64(const double *cov, int n_doa, int C, int bipolar, double rel_prec, double *bf_mat, int G, int g0,
                               void *stream)
 {
@@ -954,6 +972,24 @@ int micloc_design_vectors_f64(const double *cov, int n_doa, int C, int bipolar, 
     if (C > 128 || (C > 32 && (C & 1)) || (bipolar && (C & 1))) return MICLOC_ERR_SHAPE;  // (the one-sided kernel pairs all columns: even C)
     DeviceGuard guard(device_of(bf_mat));
     HIP_TRY(launch_design_vec(cov, n_doa, C, bipolar ? 1 : 0, rel_prec, bf_mat, G, g0, (hipStream_t)stream));
+    return MICLOC_OK;
+}
+
+int micloc_pack_events_u8(const int8_t *raster, int B, int T, int C, int band, int bands, int mode, uint8_t *out, void *stream)
+{
+    if (!raster || !out || bad_batch(B) || T < 1 || C < 1 || bands < 1 || band < 0 || band >= bands) return MICLOC_ERR_INVALID;
+    if (mode != MICLOC_PACK_TERNARY && mode != MICLOC_PACK_UNIPOLAR && mode != MICLOC_PACK_BIPOLAR) return MICLOC_ERR_INVALID;
+    DeviceGuard guard(device_of(out));
+    const int stride = bands * C * (mode == MICLOC_PACK_BIPOLAR ? 2 : 1);
+    HIP_TRY(launch_pack_events(raster, (size_t)B * T, C, out, stride, band * C, bands * C + band * C, mode, (hipStream_t)stream));
+    return MICLOC_OK;
+}
+
+int micloc_rate_from_counts_f64(const int32_t *counts, int B, int G, int bands, int T, double fs, double *rate, void *stream)
+{
+    if (!counts || !rate || bad_batch(B) || G < 1 || bands < 1 || T < 1 || !(fs > 0.0) || (long long)B * G > 0x7fffffffll) return MICLOC_ERR_INVALID;
+    DeviceGuard guard(device_of(rate));
+    HIP_TRY(launch_rate_from_counts(counts, B, G, bands, T, fs, rate, (hipStream_t)stream));
     return MICLOC_OK;
 }
 

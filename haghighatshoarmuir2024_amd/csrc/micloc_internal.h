@@ -131,6 +131,11 @@ hipError_t xylo_upload(int Cin, const int8_t *W_in_host, int N, const uint8_t *d
 hipError_t launch_xylo_resident(const void *spikes_in, int ternary_C, int B, int T, int Cin, int N, int w_rec, int max_spikes,
                                 uint8_t *spikes_out, int32_t *rate, void *ws, hipStream_t stream);
 
+// counts-only sweep form (ternary raster, no recurrence): persistent workgroups on a (trial, time chunk) ticket queue
+size_t xylo_sweep_scratch_bytes(int B);
+hipError_t launch_xylo_sweep(const int8_t *raster, int ternary_C, int B, int T, int Cin, int N, int max_spikes, int32_t *rate, void *ws,
+                             void *scratch, int workers_per_cu, hipStream_t stream);
+
 // ---- array-signal synthesis ---------------------------------------------------------------------------------
 hipError_t launch_synth(const double *xp, const double *fp, const double *slopes, int T, const double *delays, int B,
                         int M, double inv_step, double *out, hipStream_t stream);
@@ -171,6 +176,9 @@ hipError_t launch_doa_error(const int32_t *argmax, const double *doa_list, int G
 
 hipError_t launch_design_vec(const double *cov, int n_doa, int C, int bipolar, double rel_prec, double *bf, int G, int g0,
                              hipStream_t stream);
+hipError_t launch_pack_events(const int8_t *raster, size_t rows, int C, uint8_t *out, int stride, int pos_off, int neg_off, int mode,
+                              hipStream_t stream);
+hipError_t launch_rate_from_counts(const int32_t *counts, int B, int G, int F, int T, double fs, double *rate, hipStream_t stream);
 hipError_t launch_peak_location(const int32_t *rate, int B, int G, int F, int win, int32_t *index, hipStream_t stream);
 
 }  // namespace micloc

@@ -106,4 +106,56 @@ hipError_t launch_peak_location(const int32_t *rate, int B, int G, int F, int wi
     return hipGetLastError();
 }
 
+// ---- Demo.spike_encoding's channel bookkeeping (xylo_snn_localization.py:339-354) and extract_rate (:379-398) -----------------
+// One band's int8 raster [rows][C] -> its channel block of the assembled tensor [rows][stride]:
+//   mode 0  the ternary value itself          out[row][pos_off + c] = s            (bands concatenated on the channel axis)
+//   mode 1  unipolar events                   out[row][pos_off + c] = s > 0
+//   mode 2  bipolar events, the +/- split     out[row][pos_off + c] = s > 0,  out[row][neg_off + c] = s < 0
+// (the reference: np.hstack over bands, astype(int64), then [spikes > 0, spikes < 0] side by side)
+__global__ __launch_bounds__(256) void pack_events_kernel(const int8_t *__restrict__ raster, size_t rows, int C, uint8_t *__restrict__ out,
+                                                           int stride, int pos_off, int neg_off, int mode)
+{
+    const size_t n = rows * (size_t)C;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
+        const size_t row = e / C;
+        const int c = (int)(e - row * C);
+        const int8_t s = raster[e];
+        uint8_t *o = out + row * stride;
+        if (mode == 0) {
+            o[pos_off + c] = (uint8_t)s;
+        } else {
+            o[pos_off + c] = (uint8_t)(s > 0);
+            if (mode == 2) o[neg_off + c] = (uint8_t)(s < 0);
+        }
+    }
+}
+
+hipError_t launch_pack_events(const int8_t *raster, size_t rows, int C, uint8_t *out, int stride, int pos_off, int neg_off, int mode,
+                              hipStream_t stream)
+{
+    const size_t n = rows * (size_t)C;
+    const unsigned grid = (unsigned)((n + 255) / 256 > 65535 * 4 ? 65535 * 4 : (n + 255) / 256);
+    hipLaunchKernelGGL(pack_events_kernel, dim3(grid ? grid : 1), dim3(256), 0, stream, raster, rows, C, out, stride, pos_off, neg_off, mode);
+    return hipGetLastError();
+}
+
+// rate[b][g] = mean over the F bands of (counts[b][f G + g] / T) * fs -- np.mean(spikes_out, 0) * fs, then .reshape(-1, G).mean(0),
+// in that order of operations (the counts are exact integers, so the time mean is one division)
+__global__ __launch_bounds__(256) void rate_from_counts_kernel(const int32_t *__restrict__ counts, int B, int G, int F, double T, double fs,
+                                                                double *__restrict__ rate)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * G) return;
+    const int b = i / G, g = i - b * G;
+    double s = 0.0;
+    for (int f = 0; f < F; ++f) s += (double)counts[((size_t)b * F + f) * G + g] / T * fs;
+    rate[i] = s / (double)F;
+}
+
+hipError_t launch_rate_from_counts(const int32_t *counts, int B, int G, int F, int T, double fs, double *rate, hipStream_t stream)
+{
+    hipLaunchKernelGGL(rate_from_counts_kernel, dim3((B * G + 255) / 256), dim3(256), 0, stream, counts, B, G, F, (double)T, fs, rate);
+    return hipGetLastError();
+}
+
 }  // namespace micloc

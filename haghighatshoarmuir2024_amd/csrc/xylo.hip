@@ -170,13 +170,26 @@ __device__ __forceinline__ short2_t xp_decay(short2_t v, short2_t dash)
     return v - __builtin_elementwise_max(v >> dash, __builtin_elementwise_min(v, one));
 }
 
-template <int KQ, bool WANT_OUT>
+// QUEUE (the sweep: counts only): the launch is a fixed set of PERSISTENT workgroups -- four per CU, twelve waves on four SIMDs --
+// that take (trial, time chunk) tickets from a device counter, trial fastest, so that every trial advances chunk by chunk and the
+// integer state of a trial (two packed words and two counts per lane) is handed from one workgroup to the next through memory.
+// A trial is a serial chain of T steps and all chains are equally long: launched as one workgroup per trial, 1100 x 3 waves land
+// on 1024 SIMDs as three waves here and four there, and the launch lasts as long as the SIMDs that got four (80 % balance,
+// tools/wave_placement.hip).  With tickets every SIMD holds the same three waves from start to end and the chip as a whole works
+// off ceil(chunks x trials / 1024) rounds.  A ticket's predecessor (same trial, previous chunk) was handed out `trials` tickets
+// earlier to a workgroup that is RUNNING (tickets are only taken by resident workgroups), so the wait for it always ends; it is
+// bounded all the same (a worker that gives up sets the error word and the launch drains).
+constexpr int XQ_CTL = 64;         // control ints in front of the per-trial chunk counters: [0] ticket, [1] error
+constexpr int XQ_SPIN_MAX = 1 << 18;  // x (s_sleep 8 + one coherent load): a fraction of a second
+
+template <int KQ, bool WANT_OUT, bool QUEUE = false>
 __global__ __launch_bounds__(XP_WAVES * 64) void xylo_lif_pk_kernel(const int8_t *__restrict__ raster, int tc, int T, int Cin,
                                                                      const long *__restrict__ Wb /*[Npad][4 KQ]*/, int N,
                                                                      const uint8_t *__restrict__ dash_syn,
                                                                      const uint8_t *__restrict__ dash_mem,
                                                                      const short *__restrict__ thr, int max_spikes,
-                                                                     uint8_t *__restrict__ spikes_out, int *__restrict__ rate)
+                                                                     uint8_t *__restrict__ spikes_out, int *__restrict__ rate,
+                                                                     int *__restrict__ qctl, int4_t *__restrict__ qstate, int Lc, int ntrials)
 {
     __shared__ __attribute__((aligned(16))) unsigned char tile[XP_TT][32 * KQ];
     extern __shared__ __attribute__((aligned(16))) int cur_dyn[];  // [waves][4][64][4]: only the waves that hold neurons
@@ -185,8 +198,8 @@ __global__ __launch_bounds__(XP_WAVES * 64) void xylo_lif_pk_kernel(const int8_t
     const int tid = threadIdx.x;
     const int nthreads = blockDim.x;
     const int wv = tid >> 6, l = tid & 63, lc = l & 15, q = l >> 4;
-    const int b = blockIdx.y;
-    const int nbase = blockIdx.x * XP_NEUR + wv * 128;
+    int b = QUEUE ? 0 : blockIdx.y;
+    const int nbase = (QUEUE ? 0 : blockIdx.x * XP_NEUR) + wv * 128;  // (QUEUE: one neuron block, N <= 512)
 
     // weight fragments of the wave's 8 column tiles: lane (q, lc) holds channels 8 q .. 8 q + 7 (+ 32 kq) of neuron 16 j + lc
     long Bw[8][KQ];
@@ -207,6 +220,7 @@ __global__ __launch_bounds__(XP_WAVES * 64) void xylo_lif_pk_kernel(const int8_t
 
     const int8_t *sb = raster + (size_t)b * T * tc;
     uint8_t *ob = WANT_OUT ? spikes_out + (size_t)b * T * N : nullptr;
+    const int nraster_trials = QUEUE ? ntrials : (int)gridDim.y;
 
     // currents of 16 steps (tile16 `i` of the staged rows) -> the wave's LDS slice.  ONE slice per wave (4 KB): the 16 steps of
     // a tile are read into registers before the next tile's currents overwrite them (LDS operations of a wave execute in
@@ -295,8 +309,9 @@ __global__ __launch_bounds__(XP_WAVES * 64) void xylo_lif_pk_kernel(const int8_t
         vmem = xp_s2(vw);
     };
 
-    for (int t0 = 0; t0 < T; t0 += XP_TT) {
-        const int steps = (T - t0) < XP_TT ? (T - t0) : XP_TT;
+    auto run_range = [&](int t_lo, int t_hi) {
+    for (int t0 = t_lo; t0 < t_hi; t0 += XP_TT) {
+        const int steps = (t_hi - t0) < XP_TT ? (t_hi - t0) : XP_TT;
         __syncthreads();  // every wave is done with the previous tile and with its slice of `cur`
         // the 128 x tc raster bytes of this tile are contiguous: one 16-byte load per thread into LDS (the slices of `cur`
         // are idle between these barriers), then the +1 / -1 split from there (channel c < tc: +1 events, tc + c: -1
@@ -307,7 +322,7 @@ __global__ __launch_bounds__(XP_WAVES * 64) void xylo_lif_pk_kernel(const int8_t
             const int off = (int)(reinterpret_cast<uintptr_t>(src) - a0);
             const int nvec = (off + steps * tc + 15) >> 4;
             const uint4 *vsrc = reinterpret_cast<const uint4 *>(a0);
-            const int8_t *rend = raster + (size_t)gridDim.y * T * tc;
+            const int8_t *rend = raster + (size_t)nraster_trials * T * tc;
             for (int e = tid; e < nvec; e += nthreads) {
                 uint4 v;
                 if (reinterpret_cast<const int8_t *>(vsrc + e + 1) <= rend) {
@@ -384,10 +399,72 @@ __global__ __launch_bounds__(XP_WAVES * 64) void xylo_lif_pk_kernel(const int8_t
         total0 += steps + cnt.x;
         total1 += steps + cnt.y;
     }
-    if (rate) {
-        if (act0) rate[(size_t)b * N + n0] = total0;
-        if (act1) rate[(size_t)b * N + n1] = total1;
+    };
+    if constexpr (!QUEUE) {
+        run_range(0, T);
+        if (rate) {
+            if (act0) rate[(size_t)b * N + n0] = total0;
+            if (act1) rate[(size_t)b * N + n1] = total1;
+        }
+    } else {
+        __shared__ int s_ticket;
+        const int nchunks = (T + Lc - 1) / Lc;
+        const int nitems = nchunks * ntrials;
+        // (one barrier in front of the write keeps the previous ticket's readers ahead of it, one behind publishes the new one;
+        //  the value is made a scalar: every branch on it is a scalar branch, no lane can leave a wave early)
+        auto next_ticket = [&]() {
+            __syncthreads();
+            if (tid == 0) s_ticket = atomicAdd(&qctl[0], 1);
+            __syncthreads();
+            return __builtin_amdgcn_readfirstlane(s_ticket);
+        };
+        for (int ticket = next_ticket(); ticket < nitems; ticket = next_ticket()) {  // (the counter only grows: every worker leaves)
+            const int chunk = ticket / ntrials;
+            b = ticket - chunk * ntrials;
+            sb = raster + (size_t)b * T * tc;
+            int4_t *st = qstate + ((size_t)b * XP_WAVES + wv) * 64 + l;
+            if (chunk > 0) {
+                if (tid == 0) {
+                    int spins = 0;
+                    while (__hip_atomic_load(&qctl[XQ_CTL + b], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < chunk) {
+                        __builtin_amdgcn_s_sleep(8);
+                        if (++spins > XQ_SPIN_MAX) {  // never seen; keeps a broken launch from hanging the device
+                            atomicExch(&qctl[1], 1);
+                            break;
+                        }
+                    }
+                }
+                __syncthreads();
+                __threadfence();  // acquire for every lane: the state below was written by another workgroup, maybe on another XCD
+                const int4_t v = *st;
+                isyn = xp_s2(v[0]);
+                vmem = xp_s2(v[1]);
+                total0 = v[2];
+                total1 = v[3];
+            } else {
+                isyn = short2_t{0, 0};
+                vmem = short2_t{0, 0};
+                total0 = total1 = 0;
+            }
+            const int t_lo = chunk * Lc;
+            const int t_hi = t_lo + Lc < T ? t_lo + Lc : T;
+            run_range(t_lo, t_hi);
+            if (chunk + 1 < nchunks) {
+                *st = int4_t{xp_i(isyn), xp_i(vmem), total0, total1};
+                __threadfence();  // release: the state is visible device-wide before the chunk counter says so
+                __syncthreads();
+                if (tid == 0) __hip_atomic_store(&qctl[XQ_CTL + b], chunk + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                if (act0) rate[(size_t)b * N + n0] = total0;
+                if (act1) rate[(size_t)b * N + n1] = total1;
+            }
+        }
     }
+}
+
+__global__ void xylo_queue_reset_kernel(int *qctl, int n)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) qctl[i] = 0;
 }
 
 static int xp_npad(int N) { return ((N + XP_NEUR - 1) / XP_NEUR) * XP_NEUR; }
@@ -478,7 +555,7 @@ hipError_t launch_xylo_resident(const void *spikes_in, int ternary_C, int B, int
         const int8_t *rs = reinterpret_cast<const int8_t *>(spikes_in);
 #define XP_LAUNCH(KQ, WO)                                                                                                      \
     hipLaunchKernelGGL((xylo_lif_pk_kernel<KQ, WO>), pgrid, pblock, plds, stream, rs, ternary_C, T, Cin, dWb, N, dds, ddm, dth,       \
-                       max_spikes, spikes_out, rate)
+                       max_spikes, spikes_out, rate, nullptr, nullptr, 0, B)
         if (xp_kq(Cin) == 1) {
             if (spikes_out)
                 XP_LAUNCH(1, true);
@@ -518,6 +595,63 @@ hipError_t launch_xylo_resident(const void *spikes_in, int ternary_C, int B, int
     else
         XY_LAUNCH(16);
 #undef XY_LAUNCH
+    return hipGetLastError();
+}
+
+// ---- the sweep's form: counts only, ternary raster, no recurrence -> persistent workgroups on a ticket queue -----------------
+static bool xylo_sweep_queued(const void *raster, int Cin, int N)
+{
+    return Cin <= 64 && N <= XP_NEUR && (reinterpret_cast<uintptr_t>(raster) & 15) == 0;
+}
+
+size_t xylo_sweep_scratch_bytes(int B)
+{
+    // [XQ_CTL control ints][B chunk counters] | [B][XP_WAVES][64] int4 hand-over state
+    return (((size_t)(XQ_CTL + B) * sizeof(int) + 255) & ~(size_t)255) + (size_t)B * XP_WAVES * 64 * sizeof(int4_t);
+}
+
+constexpr int XQ_CHUNK = 2048;  // steps per ticket (16 staged tiles): ~0.3 ms of work against a few microseconds of hand-over
+
+hipError_t launch_xylo_sweep(const int8_t *raster, int ternary_C, int B, int T, int Cin, int N, int max_spikes, int32_t *rate, void *ws,
+                             void *scratch, int workers_per_cu, hipStream_t stream)
+{
+    if (!xylo_sweep_queued(raster, Cin, N) || max_spikes < 1)
+        return launch_xylo_resident(raster, ternary_C, B, T, Cin, N, 0, max_spikes, nullptr, rate, ws, stream);
+    unsigned char *base = reinterpret_cast<unsigned char *>(ws);
+    const int nq = (Cin + 3) / 4;
+    size_t off = ((size_t)nq * N * sizeof(int) + 255) & ~(size_t)255;
+    const size_t seg = ((size_t)N * 2 + 255) & ~(size_t)255;
+    uint8_t *dds = base + off;
+    uint8_t *ddm = base + off + seg;
+    short *dth = reinterpret_cast<short *>(base + off + 2 * seg);
+    const long *dWb = reinterpret_cast<const long *>(base + xylo_ws_base_bytes(Cin, N));
+    int *qctl = reinterpret_cast<int *>(scratch);
+    int4_t *qstate = reinterpret_cast<int4_t *>(reinterpret_cast<unsigned char *>(scratch) + (((size_t)(XQ_CTL + B) * sizeof(int) + 255) & ~(size_t)255));
+    static int num_cu = 0;  // (one device model per process: the library's code objects are gfx950 only)
+    if (num_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorInvalidDevice;
+        num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const int waves = (N + 127) / 128;
+    const int nchunks = (T + XQ_CHUNK - 1) / XQ_CHUNK;
+    const long long nitems = (long long)nchunks * B;
+    // four workgroups per CU: with three waves each every SIMD holds three; never more workers than trials (a worker beyond that
+    // could only wait for a predecessor)
+    int workers = (workers_per_cu > 0 ? workers_per_cu : 4) * num_cu;
+    workers = workers > B ? B : workers;
+    workers = (long long)workers > nitems ? (int)nitems : workers;
+    size_t plds = (size_t)waves * 4 * 64 * 4 * sizeof(int);
+    const size_t rawb = (size_t)XP_TT * ternary_C + 48;
+    plds = plds > rawb ? plds : rawb;
+    hipLaunchKernelGGL(xylo_queue_reset_kernel, dim3((XQ_CTL + B + 255) / 256), dim3(256), 0, stream, qctl, XQ_CTL + B);
+    if (xp_kq(Cin) == 1)
+        hipLaunchKernelGGL((xylo_lif_pk_kernel<1, false, true>), dim3(workers), dim3(waves * 64), plds, stream, raster, ternary_C, T, Cin, dWb, N,
+                           dds, ddm, dth, max_spikes, nullptr, rate, qctl, qstate, XQ_CHUNK, B);
+    else
+        hipLaunchKernelGGL((xylo_lif_pk_kernel<2, false, true>), dim3(workers), dim3(waves * 64), plds, stream, raster, ternary_C, T, Cin, dWb, N,
+                           dds, ddm, dth, max_spikes, nullptr, rate, qctl, qstate, XQ_CHUNK, B);
     return hipGetLastError();
 }
 

@@ -129,9 +129,10 @@ class XyloNetwork:
         _lib.check(self.lib.micloc_xylo_upload(self.Cin, vp(W.ctypes.data), self.N, vp(ds.ctypes.data), vp(dm.ctypes.data), vp(th.ctypes.data),
                                                runtime._ptr(self.ws), self.nbytes, runtime._stream(self.device)), "xylo_upload")
 
-    def run(self, spikes, ternary=False, want_spikes=False, max_spikes=31):
+    def run(self, spikes, ternary=False, want_spikes=False, max_spikes=31, queued=True, workers_per_cu=0):
         """spikes: uint8 events [B, T, Cin], or (ternary=True) the encoder's int8 raster [B, T, Cin / 2] in {-1, 0, +1}.
-        Returns (spikes_out uint8 [B, T, N] or None, rate int32 [B, N]) as device tensors."""
+        Returns (spikes_out uint8 [B, T, N] or None, rate int32 [B, N]) as device tensors.  queued=False: counts-only calls also take the
+        one-workgroup-per-trial launch (micloc_xylo_lif_resident_i16) instead of the ticket queue -- same counts (tests, A/B timing)."""
         import torch
 
         B, T, C = spikes.shape
@@ -141,6 +142,15 @@ class XyloNetwork:
             raise ValueError("spikes must be a contiguous int8 (ternary) / uint8 (events) device tensor")
         out = torch.empty((B, T, self.N), dtype=torch.uint8, device=self.device) if want_spikes else None
         rate = torch.empty((B, self.N), dtype=torch.int32, device=self.device)
+        if ternary and not want_spikes and self.w_rec == 0 and queued:
+            # the sweep's call: counts only -> persistent workgroups on a (trial, time chunk) ticket queue (micloc_xylo_lif_sweep_i16)
+            nb = self.lib.micloc_xylo_sweep_scratch_bytes(B)
+            scratch = torch.empty(int(nb), dtype=torch.uint8, device=self.device)  # one per call: calls of several streams run side by side
+            _lib.check(self.lib.micloc_xylo_lif_sweep_i16(runtime._ptr(spikes), C, B, T, self.Cin, self.N, int(max_spikes), runtime._ptr(rate),
+                                                          runtime._ptr(self.ws), self.nbytes, runtime._ptr(scratch), nb, int(workers_per_cu), runtime._stream(self.device)),
+                       "xylo_lif_sweep")
+            self.last_scratch = scratch  # (tests read the queue's control words: int32[0] tickets handed out, [1] a worker gave up waiting)
+            return None, rate
         _lib.check(self.lib.micloc_xylo_lif_resident_i16(runtime._ptr(spikes), C if ternary else 0, B, T, self.Cin, self.N, self.w_rec, int(max_spikes),
                                                          runtime._ptr(out), runtime._ptr(rate), runtime._ptr(self.ws), self.nbytes,
                                                          runtime._stream(self.device)), "xylo_lif_resident")
@@ -190,20 +200,32 @@ class Demo:
                                              device=self.device) for (b, a) in self.filterbank.ba_list]
         return self._band_plans
 
-    def spike_encoding_device(self, sig_batch):
-        """[B, T, M] -> uint8 device tensor [B, T, 2M * F * (2 if bipolar else 1)] of 0/1 events."""
-        import torch
-
-        per_band = []
+    def _band_rasters(self, sig_batch):
+        """The encoder's int8 raster of every band: STHT + order-1 band-pass + RZCC of the fused pipeline (only the quadrature channels
+        go through HBM, the encoder reads the in-phase ones -- the rolled input frames -- from x itself)."""
+        out = []
         for plan in self._plans():
             x = plan.to_device(sig_batch)
-            # STHT + band-pass + RZCC of the fused pipeline: only the quadrature channels go through HBM, the encoder reads
-            # the in-phase ones (rolled input frames) from x itself
-            per_band.append(plan.snn_pipeline(x, want_spikes=True, want_power=False, stages=3)["spikes"])
-        s = torch.cat(per_band, dim=2)
-        if self.bipolar_spikes:
-            s = torch.cat([(s > 0), (s < 0)], dim=2)
-        return s.to(torch.uint8)
+            out.append(plan.snn_pipeline(x, want_spikes=True, want_power=False, stages=3)["spikes"])
+        return out
+
+    def _pack(self, rasters, mode):
+        """micloc_pack_events_u8 per band: the channel bookkeeping of spike_encoding (:339-354) in one kernel per band -- torch only
+        allocates the result."""
+        import torch
+
+        B, T, C = rasters[0].shape
+        F = len(rasters)
+        width = F * C * (2 if mode == 2 else 1)
+        out = torch.empty((B, T, width), dtype=torch.uint8 if mode else torch.int8, device=rasters[0].device)
+        for f, r in enumerate(rasters):
+            _lib.check(_lib.load().micloc_pack_events_u8(runtime._ptr(r), B, T, C, f, F, mode, runtime._ptr(out), runtime._stream(r.device)),
+                       "pack_events")
+        return out
+
+    def spike_encoding_device(self, sig_batch):
+        """[B, T, M] -> uint8 device tensor [B, T, 2M * F * (2 if bipolar else 1)] of 0/1 events."""
+        return self._pack(self._band_rasters(sig_batch), 2 if self.bipolar_spikes else 1)
 
     def spike_encoding(self, sig_in):
         sig_in = np.ascontiguousarray(sig_in, dtype=np.float64)
@@ -222,15 +244,8 @@ class Demo:
     def raster_device(self, sig_batch):
         """[B, T, M] -> the encoder's int8 raster [B, T, 2M * F] in {-1, 0, +1} (bands concatenated on the channel axis);
         the +/- split of spike_encoding happens inside the LIF kernel's staging loop."""
-        import torch
-
-        per_band = []
-        for plan in self._plans():
-            x = plan.to_device(sig_batch)
-            # STHT + band-pass + RZCC of the fused pipeline: only the quadrature channels go through HBM, the encoder reads
-            # the in-phase ones (rolled input frames) from x itself
-            per_band.append(plan.snn_pipeline(x, want_spikes=True, want_power=False, stages=3)["spikes"])
-        return per_band[0] if len(per_band) == 1 else torch.cat(per_band, dim=2).contiguous()
+        per_band = self._band_rasters(sig_batch)
+        return per_band[0] if len(per_band) == 1 else self._pack(per_band, 0)
 
     def counts_batch(self, sig_batch):
         """[B, T, M] noisy array signals -> output spike counts per hidden neuron, int32 device tensor [B, F * G]; nothing of
@@ -238,17 +253,21 @@ class Demo:
         import torch
 
         raster = self.raster_device(sig_batch)
-        if not self.bipolar_spikes:  # unipolar encoder: the raster holds 0 / +1 only and IS the event tensor
+        if not self.bipolar_spikes:  # unipolar encoder: the raster holds 0 / +1 only and IS the event tensor (same bytes, read as uint8)
             return self.network().run(raster.view(dtype=torch.uint8), ternary=False)[1]
         return self.network().run(raster, ternary=True)[1]
 
     def rate_batch(self, sig_batch):
         """[B, T, M] noisy array signals -> spike rate per DoA [B, G] (device tensor): mean(spikes_out) * fs averaged over
         the bands (extract_rate, xylo_snn_localization.py:379-398)."""
+        import torch
+
         counts = self.counts_batch(sig_batch)
-        T = sig_batch.shape[1]
-        rate_channels = counts.double() / T * self.fs
-        return rate_channels.reshape(counts.shape[0], -1, len(self.doa_list)).mean(dim=1)
+        B, G = counts.shape[0], len(self.doa_list)
+        rate = torch.empty((B, G), dtype=torch.float64, device=counts.device)
+        _lib.check(_lib.load().micloc_rate_from_counts_f64(runtime._ptr(counts), B, G, counts.shape[1] // G, int(sig_batch.shape[1]), float(self.fs),
+                                                           runtime._ptr(rate), runtime._stream(counts.device)), "rate_from_counts")
+        return rate
 
     def peak_batch(self, sig_batch, win_size):
         """[B, T, M] -> find_peak_location(rate / rate.max(), win_size) per trial on the device (int32 tensor [B]):

@@ -350,6 +350,27 @@ int micloc_xylo_upload(int Cin, const int8_t *W_in, int N, const uint8_t *dash_s
                        void *ws, size_t ws_bytes, void *stream);
 int micloc_xylo_lif_resident_i16(const void *spikes_in, int ternary_channels, int B, int T, int Cin, int N, int w_rec,
                                  int max_spikes, uint8_t *spikes_out, int32_t *rate, void *ws, size_t ws_bytes, void *stream);
+/* The sweep's form of the same call (paper_plots/target_xylo_localization.py:590-594 needs only rec["Spikes"].mean(0): the spike
+ * COUNTS): ternary raster [B][T][ternary_channels] in, rate [B][N] out, w_rec == 0.  The launch is a set of persistent workgroups
+ * that take (trial, time chunk) tickets from a device counter and hand a trial's integer state on through `scratch`
+ * (micloc_xylo_sweep_scratch_bytes(B) bytes, 256-byte aligned, contents irrelevant on entry; one buffer per concurrent call) --
+ * every SIMD carries the same number of chains from start to end.  Same counts as micloc_xylo_lif_resident_i16; shapes the queue does
+ * not serve (N > 512, Cin > 64, unaligned raster) take that call's kernels.  workers_per_cu: persistent workgroups per CU, 0 = 4 (three
+ * waves each: three per SIMD); fewer leave room for the kernels of other streams.  No host access, no synchronisation (graph-capturable). */
+size_t micloc_xylo_sweep_scratch_bytes(int B);
+int micloc_xylo_lif_sweep_i16(const int8_t *raster, int ternary_channels, int B, int T, int Cin, int N, int max_spikes, int32_t *rate,
+                              void *ws, size_t ws_bytes, void *scratch, size_t scratch_bytes, int workers_per_cu, void *stream);
+/* Demo.spike_encoding's channel bookkeeping (micloc/xylo_snn_localization.py:339-354: the per-band rasters side by side,
+ * astype(int64), then [spikes > 0 | spikes < 0]) for ONE band of `bands`: raster int8 [B][T][C] in {-1, 0, +1} -> its channel block
+ * of out [B][T][bands * C * (2 if BIPOLAR else 1)].  TERNARY: the value itself at channel band*C + c (the concatenated raster the
+ * sweep kernel reads); UNIPOLAR: (s > 0) there; BIPOLAR: (s > 0) there and (s < 0) at bands*C + band*C + c. */
+#define MICLOC_PACK_TERNARY 0
+#define MICLOC_PACK_UNIPOLAR 1
+#define MICLOC_PACK_BIPOLAR 2
+int micloc_pack_events_u8(const int8_t *raster, int B, int T, int C, int band, int bands, int mode, uint8_t *out, void *stream);
+/* Demo.extract_rate (micloc/xylo_snn_localization.py:379-398) from the spike COUNTS of the hidden layer: rate[b][g] = mean over bands of
+ * (counts[b][f * G + g] / T) * fs.  counts int32 [B][bands * G], rate double [B][G] (device). */
+int micloc_rate_from_counts_f64(const int32_t *counts, int B, int G, int bands, int T, double fs, double *rate, void *stream);
 /* index[b] = find_peak_location(power_b, win_size) (micloc/utils.py:84-121; paper_plots/target_xylo_localization.py:594-604)
  * with power_b[g] = sum over `bands` of rate[b][f * G + g] (the per-DoA spike counts; the reference's positive scale
  * factors T / fs and 1 / max do not move the arg-max): box-car of win_size samples, FULL non-circular convolution, first

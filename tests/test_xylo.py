@@ -218,3 +218,39 @@ def test_resident_network_ternary_input_and_peak_location(cfg2):
         assert idx2[b] == find_peak_location((two[b, :G] + two[b, G:]).astype(np.float64), 15)
     with pytest.raises(ValueError):
         runtime.peak_location(torch.from_numpy(counts).cuda(), G, 14)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T,C,N", [(5, 5000, 14, 449), (1300, 4500, 14, 360), (40, 2048, 7, 100), (3, 2049, 20, 512), (2, 100, 14, 449)])
+def test_queued_sweep_equals_one_workgroup_per_trial(B, T, C, N):
+    """micloc_xylo_lif_sweep_i16: persistent workgroups on the (trial, time chunk) ticket queue -- a trial's integer state handed
+    from workgroup to workgroup at every 2048-step boundary, more trials than workers (1300 > 4 x 256), a chunk boundary one step
+    before the end, two 32-channel k-steps -- gives the counts of the one-workgroup-per-trial kernel bit for bit (which
+    test_packed_xylo_kernel_equals_oracle pins to the oracle), and the oracle's on the first trials."""
+    import torch
+
+    from haghighatshoarmuir2024_amd.xylo_snn_localization import XyloNetwork
+
+    rng = np.random.RandomState(B + T + N)
+    Cin = 2 * C
+    spec = dict(W_in=rng.randint(-127, 128, size=(Cin, N)).astype(np.int8), w_rec=0,
+                dash_syn=rng.randint(0, 5, size=N).astype(np.uint8), dash_mem=rng.randint(0, 5, size=N).astype(np.uint8),
+                threshold=rng.randint(40, 3000, size=N).astype(np.int16))
+    raster = torch.from_numpy(rng.choice([-1, 0, 1], size=(B, T, C), p=[0.1, 0.8, 0.1]).astype(np.int8)).cuda()
+    net = XyloNetwork(spec)
+    _, rate_q = net.run(raster, ternary=True, want_spikes=False)          # the queue
+    Bs = min(B, 64)
+    _, rate_w = net.run(raster[:Bs].contiguous(), ternary=True, want_spikes=True)  # one workgroup per trial (also stores the raster)
+    assert torch.equal(rate_q[:Bs], rate_w)
+    for _ in range(2):  # the scratch of a call is reset by the call itself: again, same result
+        assert torch.equal(net.run(raster, ternary=True, want_spikes=False)[1], rate_q)
+    r = raster[:2].cpu().numpy()
+    events = np.concatenate([r > 0, r < 0], axis=2).astype(np.uint8)
+    for b in range(2):
+        _, er = O.xylo_lif(events[b], spec["W_in"], 0, spec["dash_syn"], spec["dash_mem"], spec["threshold"], 31)
+        np.testing.assert_array_equal(rate_q[b].cpu().numpy(), er)
+    if B > 64:
+        # every trial, against the general kernel (lane = neuron, 32-bit arithmetic)
+        ev = torch.cat([(raster > 0), (raster < 0)], dim=2).to(torch.uint8).contiguous()
+        _, rate_g = net.run(ev, ternary=False, want_spikes=False)
+        assert torch.equal(rate_q, rate_g)
