@@ -377,8 +377,11 @@ __device__ __forceinline__ void rz_loader_np(XT &X, const double *__restrict__ h
         const int tc = t < Ts ? t : Ts - 1;
         int tr = (t < T ? t : T - 1) - sh;
         tr = tr < 0 ? tr + T : tr;
+        // one 32-bit element index per stream (T * M and Ts are far below 2^31): selecting between two 64-bit offsets per stream
+        // costs a register pair each and pushed this wave role over the 128-VGPR budget of four waves per SIMD (32 B of scratch)
+        const unsigned i_roll = (unsigned)tr * (unsigned)M, i_lin = (unsigned)tc;
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) v[S][j] = rolled[j] ? pb[j][(size_t)tr * M] : pb[j][tc];
+        for (int j = 0; j < NJ; ++j) v[S][j] = pb[j][rolled[j] ? i_roll : i_lin];
     };
     auto write_tile = [&](int buf, auto set) {
         constexpr int S = decltype(set)::value;
@@ -592,7 +595,7 @@ struct RzStream {
 // launches: speech 13.1 -> 12.2 ms for scan + chunks) and costs where one workgroup per CU runs at the pace of its slowest
 // wave (sweep shape: 0.417 -> 0.445 ms), so only chunked launches carry it.
 template <int N, bool WANT_PRE, bool WANT_SPIKES, int RING = RZ_RING, bool WRITER = false, int SW = 64>
-__global__ __launch_bounds__(448, SW == 64 ? 4 : 6) void bandpass_rzcc_fast_kernel(const double *__restrict__ h,
+__global__ __launch_bounds__(448, (WANT_PRE && WANT_SPIKES) ? 2 : 4) void bandpass_rzcc_fast_kernel(const double *__restrict__ h,
                                                                   double *__restrict__ pre,
                                                                   int8_t *__restrict__ spikes,
                                                                   int *__restrict__ flag_count,
@@ -1403,6 +1406,7 @@ hipError_t launch_bandpass_rzcc(const IirCoef &coef, const double *h, int nlanes
                                 hipStream_t stream, const double *xin, int M, int shift, int chunk_frames)
 {
     if (!pre && !spikes) return hipErrorInvalidValue;
+    if ((unsigned long long)T * (unsigned long long)(M > 0 ? M : 1) > 0xffffffffull) return hipErrorInvalidValue;  // (the loaders index a trial with 32 bits)
     // launches that also store the filtered signal walk each stream once (the loader stores tile by tile)
     const RzGeom g = rz_geom(nlanes, T, robust_width, (pre || !spikes) ? -1 : chunk_frames);
     const RzScratch sc = rz_scratch(nlanes, T, g.P);
