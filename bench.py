@@ -170,7 +170,7 @@ def build_workload(args, rank, device):
     # the whole design on the device: delayed templates, chain, membrane covariance (lif_cov_kernel / lif_cov_wide_kernel), batched
     # Jacobi decompositions (micloc_design_vectors_f64: two-sided up to 16 microphones, one-sided up to 64 -- config 5's 128 x 128
     # matrices); a one-off cost outside the timed region
-    kw = dict(svd="device", doa_batch=48) if cfg == "stress" else dict(svd="device")
+    kw = dict(svd="device", doa_batch=240) if cfg == "stress" else dict(svd="device")
     beamf.design_from_template(chirp_template(fs, freq_range), doa_list[:8], **kw)  # warm-up (allocations, module load)
     torch.cuda.synchronize()
     t_design = time.perf_counter()

@@ -1,11 +1,14 @@
 #!/bin/bash
 # Round profiling recipe (run on the GPU box from the repo root: gpurun -- 'bash tools/profile_round.sh r4').
 # Writes raw rocprofv3 output and bench JSONs under gpurun_out/<tag>/; copy the summaries into profiles/<tag>/.
+# usage: bash tools/profile_round.sh <tag> [bench|pmc|all]   (two gpurun calls of <= 20 minutes: `bench`, then `pmc`)
 set -u
 TAG=${1:-r4}
+PART=${2:-all}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
+if [ $PART != pmc ]; then
 python3 bench.py --steps 20 --warmup 5 > $OUT/bench_n1.json 2> $OUT/bench_n1.err   # the driver's command: all blocks (other configs as child runs)
 python3 bench.py --steps 40 --warmup 4 --streams 1 --no-cpu-baseline --no-other-configs > $OUT/bench_n1_streams1.json 2> $OUT/bench_n1_streams1.err
 python3 bench.py --steps 40 --warmup 4 --grid 449 --no-cpu-baseline --no-other-configs > $OUT/bench_n1_grid449.json 2> $OUT/bench_n1_grid449.err
@@ -26,6 +29,20 @@ hipcc -O3 --offload-arch=gfx950 -o /tmp/store_bw tools/store_bw.hip > /dev/null 
 #   stht_valu  the STHT on the vector ALU (round 2's kernel) instead of the matrix cores
 bash tools/dev/ab_lib.sh tools/_variants/libmicloc_hip_ws_k4.so "--steps 40 --warmup 4" > $OUT/ablation_kstep.txt 2>&1
 bash tools/dev/ab_lib.sh tools/_variants/libmicloc_hip_stht_valu.so "--steps 40 --warmup 4" > $OUT/ablation_stht.txt 2>&1
+# round 4: the complex Beamformer's contraction alone, the Xylo LIF launch forms, config 5's design
+(python3 tools/c128_time.py 360 1100 0; python3 tools/c128_time.py 449 1100 0; python3 tools/c128_time.py 360 1100 1; python3 tools/c128_time.py 57 1100 1) > $OUT/c128_time.txt 2>/dev/null
+python3 tools/dev/xylo_lif_bench.py > $OUT/xylo_lif_forms.txt 2>/dev/null
+bash tools/dev/xylo_lif_modes.sh static queue:4 static queue:4 > $OUT/xylo_step_lif_forms.txt 2>/dev/null
+python3 tools/dev/design_cfg5_time.py 48 240 > $OUT/design_config5.txt 2>/dev/null
+python3 tools/summarize_profiles.py trace $OUT/trace $OUT/kernel_trace_summary_by_shape.csv
+python3 tools/summarize_profiles.py trace $OUT/trace_g449 $OUT/kernel_trace_summary_grid449.csv
+python3 tools/summarize_profiles.py trace $OUT/trace_speech $OUT/kernel_trace_summary_speech.csv
+python3 tools/summarize_profiles.py trace $OUT/trace_stress $OUT/kernel_trace_summary_stress.csv
+python3 tools/summarize_profiles.py trace $OUT/trace_xylo $OUT/kernel_trace_summary_xylo.csv
+find $OUT/trace -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats_bench_steps40_streams1.csv \;
+rm -rf $OUT/trace $OUT/trace_g449 $OUT/trace_speech $OUT/trace_stress $OUT/trace_xylo
+fi
+if [ $PART != bench ]; then
 # counters: separate passes, nothing but --pmc (+ kernel trace)
 for cfg in noisy stress speech xylo; do
   steps=6; [ $cfg = speech ] && steps=2; [ $cfg = xylo ] && steps=2
@@ -34,16 +51,11 @@ for cfg in noisy stress speech xylo; do
   rocprofv3 --output-format csv --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write_$cfg -o run -- python3 bench.py $extra > $OUT/pmc_write_$cfg.log 2>&1
   rocprofv3 --output-format csv --kernel-trace --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE -d $OUT/pmc_sq_$cfg -o run -- python3 bench.py $extra > $OUT/pmc_sq_$cfg.log 2>&1
 done
-python3 tools/summarize_profiles.py trace $OUT/trace $OUT/kernel_trace_summary_by_shape.csv
-python3 tools/summarize_profiles.py trace $OUT/trace_g449 $OUT/kernel_trace_summary_grid449.csv
-python3 tools/summarize_profiles.py trace $OUT/trace_speech $OUT/kernel_trace_summary_speech.csv
-python3 tools/summarize_profiles.py trace $OUT/trace_stress $OUT/kernel_trace_summary_stress.csv
-python3 tools/summarize_profiles.py trace $OUT/trace_xylo $OUT/kernel_trace_summary_xylo.csv
 python3 tools/summarize_profiles.py pmc $OUT/pmc_summary.csv pmc_fetch=$OUT/pmc_fetch_noisy pmc_write=$OUT/pmc_write_noisy pmc_sq=$OUT/pmc_sq_noisy
 python3 tools/summarize_profiles.py pmc $OUT/pmc_summary_stress.csv pmc_fetch=$OUT/pmc_fetch_stress pmc_write=$OUT/pmc_write_stress pmc_sq=$OUT/pmc_sq_stress
 python3 tools/summarize_profiles.py pmc $OUT/pmc_summary_speech.csv pmc_fetch=$OUT/pmc_fetch_speech pmc_write=$OUT/pmc_write_speech pmc_sq=$OUT/pmc_sq_speech
 python3 tools/summarize_profiles.py pmc $OUT/pmc_summary_xylo.csv pmc_fetch=$OUT/pmc_fetch_xylo pmc_write=$OUT/pmc_write_xylo pmc_sq=$OUT/pmc_sq_xylo
-find $OUT/trace -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats_bench_steps40_streams1.csv \;
 # keep the merge-back small: drop the raw per-dispatch traces
-rm -rf $OUT/trace $OUT/trace_g449 $OUT/trace_speech $OUT/trace_stress $OUT/trace_xylo $OUT/pmc_fetch_* $OUT/pmc_write_* $OUT/pmc_sq_*
+rm -rf $OUT/pmc_fetch_* $OUT/pmc_write_* $OUT/pmc_sq_*
+fi
 ls -la $OUT
