@@ -106,17 +106,16 @@ SYMBOLS = {
     "micloc_xylo_lif_sweep_i16": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_int, c_void_p]),
     "micloc_lif_beamform_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),
     "micloc_stream_state_bytes": (c_size_t, [c_void_p, c_int]),
-    "micloc_stream_encode_f64": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, ctypes.c_longlong, c_int, c_int, c_void_p, c_int, c_void_p, c_size_t,
-                                         c_void_p]),
     "micloc_stream_overflow": (c_int, [c_void_p, ctypes.POINTER(c_int), c_void_p]),
     "micloc_stream_localize_state_bytes": (c_size_t, [c_void_p, c_int]),
     "micloc_stream_chunk_frames": (c_int, [c_void_p]),
     "micloc_stream_localize_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),
-    "micloc_stream_encode_window_f64": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, ctypes.c_longlong, c_int, c_int, c_void_p, c_int, ctypes.c_longlong,
-                                                c_void_p, c_size_t, c_void_p]),
-    "micloc_stream_localize_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_int, c_int, ctypes.c_longlong, ctypes.c_longlong, c_int, c_int,
-                                           c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
-    "micloc_stream_window_shift": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, ctypes.c_longlong, ctypes.c_longlong, c_void_p]),
+    "micloc_stream_reset": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_int, c_void_p]),
+    "micloc_stream_begin_tile": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "micloc_stream_wrap_rows_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "micloc_stream_encode_tile_f64": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "micloc_stream_localize_tile_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                                c_size_t, c_void_p]),
     "micloc_stream_localize_status": (c_int, [c_void_p, ctypes.POINTER(c_int), c_void_p]),
     "micloc_design_vectors_f64": (c_int, [c_void_p, c_int, c_int, c_int, ctypes.c_double, c_void_p, c_int, c_int, c_void_p]),
     "micloc_peak_location_i32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),

@@ -494,21 +494,6 @@ size_t micloc_stream_state_bytes(const micloc_plan *p, int B)
     return rzcc_stream_state_bytes(B * p->C);
 }
 
-int micloc_stream_encode_f64(const micloc_plan *p, const double *h, int B, int T_tile, int row_stride, long long t_base, int first_tile,
-                             int final_tile, int8_t *spikes, int T_total, void *state, size_t state_bytes, void *stream)
-{
-    if (!p || !h || !spikes || bad_batch(B) || T_tile < 1 || T_total < 1 || t_base < 0 || row_stride < T_tile) return MICLOC_ERR_INVALID;
-    DeviceGuard guard(p->device);
-    if (t_base % 16 != 0 || (!final_tile && T_tile % 16 != 0) || t_base + T_tile > T_total || (first_tile && t_base != 0))
-        return MICLOC_ERR_SHAPE;
-    if (bad_ws(state, state_bytes, rzcc_stream_state_bytes(B * p->C))) return MICLOC_ERR_WORKSPACE;
-    hipStream_t st = (hipStream_t)stream;
-    if (first_tile) HIP_TRY(launch_zero_fill(spikes, (size_t)B * T_total * p->C, st));
-    HIP_TRY(launch_stream_encode(p->iir, h, B * p->C, p->C, T_tile, row_stride, p->robust_width, p->bipolar, spikes, T_total, t_base,
-                                 first_tile, final_tile, state, st));
-    return MICLOC_OK;
-}
-
 int micloc_stream_overflow(const void *state, int *count, void *stream)
 {
     if (!state || !count) return MICLOC_ERR_INVALID;
@@ -537,68 +522,84 @@ size_t micloc_stream_localize_workspace_bytes(const micloc_plan *p, int B, int w
     return align256(beamform_partial_bytes(B, window_frames, 16 * p->W.GT));
 }
 
-int micloc_stream_encode_window_f64(const micloc_plan *p, const double *h, int B, int T_tile, int row_stride, long long t_base,
-                                    int first_tile, int final_tile, int8_t *window, int window_frames, long long window_base,
-                                    void *state, size_t state_bytes, void *stream)
+// ---- clocked streaming: the same stages with the absolute time in a device word ----------------------------------------------
+// One tile = begin_tile (clock + window slide) -> STHT of [history | tile] (micloc_stht_f64) -> wrap_rows -> encode_tile ->
+// localize_tile (which ends with the clock's tick).  No call takes an absolute time: every launch of a tile of n frames has the
+// same arguments, so the sequence can be captured into ONE hipGraph and replayed per tile (StreamingLocalizer.capture).
+int micloc_stream_reset(const micloc_plan *p, int B, void *enc_state, size_t enc_bytes, void *loc_state, size_t loc_bytes, int8_t *window,
+                        int window_frames, void *stream)
 {
-    if (!p || !h || !window || bad_batch(B) || T_tile < 1 || window_frames < 1 || t_base < 0 || window_base < 0 || row_stride < T_tile)
-        return MICLOC_ERR_INVALID;
+    if (!p || !enc_state || !loc_state || !window || bad_batch(B) || window_frames < 1) return MICLOC_ERR_INVALID;
     DeviceGuard guard(p->device);
-    if (t_base % 16 != 0 || (!final_tile && T_tile % 16 != 0) || t_base + T_tile > window_base + window_frames || window_base > t_base ||
-        (first_tile && t_base != 0) || t_base + T_tile > 0x7fffffffll)
-        return MICLOC_ERR_SHAPE;
-    if (bad_ws(state, state_bytes, rzcc_stream_state_bytes(B * p->C))) return MICLOC_ERR_WORKSPACE;
+    if (bad_ws(enc_state, enc_bytes, rzcc_stream_state_bytes(B * p->C))) return MICLOC_ERR_WORKSPACE;
+    if (bad_ws(loc_state, loc_bytes, micloc_stream_localize_state_bytes(p, B))) return MICLOC_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    if (first_tile) HIP_TRY(launch_zero_fill(window, (size_t)B * window_frames * p->C, st));
-    HIP_TRY(launch_stream_encode(p->iir, h, B * p->C, p->C, T_tile, row_stride, p->robust_width, p->bipolar, window, window_frames, t_base,
-                                 first_tile, final_tile, state, st, (int)window_base));
+    HIP_TRY(launch_zero_fill(enc_state, 256, st));  // overflow counter (the encoder's own state is written by the first tile)
+    HIP_TRY(launch_zero_fill(loc_state, micloc_stream_localize_state_bytes(p, B), st));  // control words, clock, accumulators
+    HIP_TRY(launch_zero_fill(window, (size_t)B * window_frames * p->C, st));
     return MICLOC_OK;
 }
 
-int micloc_stream_localize_f64(const micloc_plan *p, const void *enc_state, void *loc_state, size_t loc_state_bytes, const int8_t *window,
-                               int B, int window_frames, long long window_base, long long t_end, int first_tile, int final_tile,
-                               double *power, int32_t *argmax, void *ws, size_t ws_bytes, void *stream)
+int micloc_stream_begin_tile(const micloc_plan *p, void *loc_state, int8_t *window, int8_t *scratch_window, int B, int n, int window_frames,
+                             void *stream)
 {
-    if (!p || !enc_state || !loc_state || !window || bad_batch(B) || window_frames < 1 || window_base < 0 || t_end < 1) return MICLOC_ERR_INVALID;
+    if (!p || !loc_state || !window || !scratch_window || window == scratch_window || bad_batch(B) || n < 1 || window_frames < 1) return MICLOC_ERR_INVALID;
+    DeviceGuard guard(p->device);
+    if (!p->d_ntab || !p->d_W) return MICLOC_ERR_NOT_SET;
+    const int CH = lif_beamform_chunk_frames(p->W, p->ntab);
+    if (window_frames % CH != 0 || n > window_frames) return MICLOC_ERR_SHAPE;
+    HIP_TRY(launch_stream_begin_tile(reinterpret_cast<int *>(loc_state), window, scratch_window, B, (size_t)window_frames * p->C, p->C, n, window_frames,
+                                     CH, (hipStream_t)stream));
+    return MICLOC_OK;
+}
+
+int micloc_stream_wrap_rows_f64(const micloc_plan *p, const void *loc_state, double *h, int B, int Ts, int first_col, int n, const double *wrap_tail,
+                                void *stream)
+{
+    if (!p || !loc_state || !h || bad_batch(B) || n < 1 || first_col < 0 || first_col + n > Ts) return MICLOC_ERR_INVALID;
+    DeviceGuard guard(p->device);
+    HIP_TRY(launch_stht_wrap_rows(h, wrap_tail, B, p->M, Ts, first_col, n, p->L / 2, reinterpret_cast<const int *>(loc_state), (hipStream_t)stream));
+    return MICLOC_OK;
+}
+
+int micloc_stream_encode_tile_f64(const micloc_plan *p, const double *h, int B, int T_tile, int row_stride, int final_tile, int8_t *window,
+                                  int window_frames, void *enc_state, size_t enc_bytes, const void *loc_state, void *stream)
+{
+    if (!p || !h || !window || !loc_state || bad_batch(B) || T_tile < 1 || window_frames < T_tile || row_stride < T_tile) return MICLOC_ERR_INVALID;
+    DeviceGuard guard(p->device);
+    if (!final_tile && T_tile % 16 != 0) return MICLOC_ERR_SHAPE;
+    if (bad_ws(enc_state, enc_bytes, rzcc_stream_state_bytes(B * p->C))) return MICLOC_ERR_WORKSPACE;
+    HIP_TRY(launch_stream_encode(p->iir, h, B * p->C, p->C, T_tile, row_stride, p->robust_width, p->bipolar, window, window_frames, 0, 0,
+                                 final_tile, enc_state, (hipStream_t)stream, 0, reinterpret_cast<const int *>(loc_state)));
+    return MICLOC_OK;
+}
+
+int micloc_stream_localize_tile_f64(const micloc_plan *p, const void *enc_state, void *loc_state, size_t loc_bytes, const int8_t *window, int B,
+                                    int window_frames, int final_tile, double *power, int32_t *argmax, void *ws, size_t ws_bytes, void *stream)
+{
+    if (!p || !enc_state || !loc_state || !window || bad_batch(B) || window_frames < 1) return MICLOC_ERR_INVALID;
     DeviceGuard guard(p->device);
     if (!p->d_ntab || !p->d_W) return MICLOC_ERR_NOT_SET;
     if (p->W_is_complex) return MICLOC_ERR_SHAPE;
     const int CH = lif_beamform_chunk_frames(p->W, p->ntab);
-    if (window_base % CH != 0 || window_frames % CH != 0 || t_end > window_base + window_frames || t_end <= window_base ||
-        t_end > 0x7fffffffll)
-        return MICLOC_ERR_SHAPE;
+    if (window_frames % CH != 0) return MICLOC_ERR_SHAPE;
     const int G = p->G_out, Gp = 16 * p->W.GT;
-    if (bad_ws(loc_state, loc_state_bytes, micloc_stream_localize_state_bytes(p, B))) return MICLOC_ERR_WORKSPACE;
+    if (bad_ws(loc_state, loc_bytes, micloc_stream_localize_state_bytes(p, B))) return MICLOC_ERR_WORKSPACE;
     if (bad_ws(ws, ws_bytes, beamform_partial_bytes(B, window_frames, Gp))) return MICLOC_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     int *ctl = reinterpret_cast<int *>(loc_state);
     double *acc = reinterpret_cast<double *>(reinterpret_cast<unsigned char *>(loc_state) + 256);
-    if (first_tile) HIP_TRY(launch_zero_fill(loc_state, 256 + (size_t)B * 2 * G * sizeof(double), st));
     const int nwin = window_frames / CH;
-    HIP_TRY(launch_stream_horizon(enc_state, B * p->C, p->bipolar, (int)t_end, final_tile ? 1 : 0, CH, (int)(window_base / CH), nwin, ctl, st));
-    // the window as a recording of (t_end - window_base) frames: the chunks in ctl's range, everything else left alone
+    HIP_TRY(launch_stream_horizon(enc_state, B * p->C, p->bipolar, 0, final_tile ? 1 : 0, CH, 0, nwin, ctl, st, 1));
     BeamformW W = p->W;
     W.chunk_range = ctl + 4;
     double *partial = reinterpret_cast<double *>(ws);
     int nch = 0;
-    HIP_TRY(launch_lif_beamform(W, p->ntab, window, B, (int)(t_end - window_base), nullptr, partial, st, &nch));
+    // the whole window as the launch shape; the kernel takes the frames that exist from the control words
+    HIP_TRY(launch_lif_beamform(W, p->ntab, window, B, window_frames, nullptr, partial, st, &nch));
     HIP_TRY(launch_stream_accumulate(partial, B, nch, Gp, G, ctl + 4, ctl, acc, ctl + 8, power, argmax, st));
     HIP_TRY(launch_stream_commit(ctl, STREAM_BLOCK_CHUNKS, st));
-    return MICLOC_OK;
-}
-
-int micloc_stream_window_shift(const micloc_plan *p, void *loc_state, const int8_t *src, int8_t *dst, int B, int window_frames,
-                               long long base_old, long long base_new, void *stream)
-{
-    if (!p || !loc_state || !src || !dst || src == dst || bad_batch(B) || window_frames < 1 || base_new < base_old || base_old < 0)
-        return MICLOC_ERR_INVALID;
-    DeviceGuard guard(p->device);
-    if (!p->d_ntab || !p->d_W) return MICLOC_ERR_NOT_SET;
-    const int CH = lif_beamform_chunk_frames(p->W, p->ntab);
-    if (base_new % CH != 0 || base_old % CH != 0 || base_new - base_old > window_frames) return MICLOC_ERR_SHAPE;
-    const size_t row = (size_t)window_frames * p->C;
-    HIP_TRY(launch_window_shift(src, dst, B, row, (size_t)(base_new - base_old) * p->C, reinterpret_cast<int *>(loc_state), (int)(base_new / CH),
-                                (hipStream_t)stream));
+    HIP_TRY(launch_stream_tick(ctl, st));
     return MICLOC_OK;
 }
 

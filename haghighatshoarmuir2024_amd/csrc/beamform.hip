@@ -374,6 +374,7 @@ __global__ __launch_bounds__(BF_THREADS, WANT_Y ? 2 : (KV ? WS_KV_WAVES : (NT ==
     int chunk = blockIdx.x, b = blockIdx.y;
     xcd_chunk_order(chunk, b);
     if (chunk_range && (chunk < chunk_range[0] || chunk >= chunk_range[1])) return;  // (workgroup-uniform)
+    if (chunk_range) T = chunk_range[6];  // streaming: the frames of the window that exist so far (decided on the device)
     const int nchunks = gridDim.x;
     constexpr int CH = BF_WAVES * NT * 16;  // frames per workgroup
     constexpr int TILES = CH / 16;
@@ -889,6 +890,7 @@ __global__ __launch_bounds__(BF_THREADS, 4) void beamform_gen_kernel(const int8_
     int chunk = blockIdx.x, b = blockIdx.y;
     xcd_chunk_order(chunk, b);
     if (chunk_range && (chunk < chunk_range[0] || chunk >= chunk_range[1])) return;  // (workgroup-uniform)
+    if (chunk_range) T = chunk_range[6];  // streaming: the frames of the window that exist so far (decided on the device)
     const int nchunks = gridDim.x;
 
     double *slab0 = reinterpret_cast<double *>(smem);  // [Kp][32], halves swapped in odd rows

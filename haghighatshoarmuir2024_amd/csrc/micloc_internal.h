@@ -53,13 +53,22 @@ hipError_t launch_bandpass_rzcc(const IirCoef &coef, const double *h, int nlanes
 size_t rzcc_stream_state_bytes(int nlanes);
 hipError_t launch_stream_encode(const IirCoef &coef, const double *h, int nlanes, int C, int T, int Ts, int robust_width,
                                 int bipolar, int8_t *spikes, int Ttot, long long t_base, int first_tile, int final_tile,
-                                void *state, hipStream_t stream, int pos_lo = 0);
+                                void *state, hipStream_t stream, int pos_lo = 0, const int *clk = nullptr);
 // streaming localisation (rzcc.hip "which frames of the spike raster are final"); ctl: 64 device ints
 hipError_t launch_stream_horizon(const void *enc_state, int nlanes, int bipolar, int t_end, int final_, int chunk_frames, int base_chunk,
-                                 int nwin, int *ctl, hipStream_t stream);
+                                 int nwin, int *ctl, hipStream_t stream, int clocked = 0);
+// the device clock of a stream: control words of loc_state (ints).  [0] chunks done, [1] chunks of the open block, [4..7] + [10] chunk
+// range / window length of the beamforming launch, [8] frames beamformed, [12..15] status -- and the clock:
+constexpr int STREAM_CLK_T = 16;      // frames pushed so far (absolute time of the next tile's first frame)
+constexpr int STREAM_CLK_BASE = 17;   // absolute frame of the raster window's row 0
+constexpr int STREAM_CLK_SHIFT = 18;  // frames the window slides in front of the current tile
+constexpr int STREAM_CLK_TEND = 19;   // t + n of the current tile
+hipError_t launch_stream_begin_tile(int *ctl, int8_t *win, int8_t *tmp, int B, size_t row_bytes, int C, int n, int cap, int chunk_frames,
+                                    hipStream_t stream);
+hipError_t launch_stream_tick(int *ctl, hipStream_t stream);
+hipError_t launch_stht_wrap_rows(double *h, const double *wrap, int B, int M, int Ts, int col0, int n, int half, const int *ctl,
+                                 hipStream_t stream);
 hipError_t launch_stream_commit(int *ctl, int block_chunks, hipStream_t stream);
-hipError_t launch_window_shift(const int8_t *src, int8_t *dst, int B, size_t row_bytes, size_t shift_bytes, int *ctl, int new_base_chunk,
-                               hipStream_t stream);
 hipError_t launch_stream_accumulate(const double *partial, int B, int nwin, int Gp, int G, const int *range, const int *ctl,
                                     double *acc, const int *frames_ptr, double *power, int32_t *argmax, hipStream_t stream);
 constexpr int STREAM_BLOCK_CHUNKS = 32;  // == PA_BLOCK of the one-shot time reduction (beamform.hip)

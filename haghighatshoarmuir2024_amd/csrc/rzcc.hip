@@ -586,6 +586,8 @@ struct RzStream {
     int Ttot;        // frames per trial of the spike raster (row stride of the scatter)
     int on;
     int pos_lo;      // the raster starts at this absolute frame (a sliding window over the recording; 0: the whole recording)
+    const int *clk;  // device clock of a clocked stream (loc_state control words, STREAM_CLK_*) or nullptr: t_base / pos_lo / resume
+                     // are read from it, so the launch carries no absolute time by value and a captured graph of it can be replayed
 };
 
 // RING: candidate ring entries per stream (power of two).  A whole tile of appends (RZ_MT) is reserved before every tile, so
@@ -605,6 +607,11 @@ __global__ __launch_bounds__(448, (WANT_PRE && WANT_SPIKES) ? 2 : 4) void bandpa
                                                                   RzGeom g, int nblk, const double *__restrict__ ckd,
                                                                   const int *__restrict__ cki, RzStream ss)
 {
+    if (ss.on && ss.clk) {  // (scalar loads, workgroup-uniform)
+        ss.t_base = ss.clk[STREAM_CLK_T];
+        ss.pos_lo = ss.clk[STREAM_CLK_BASE];
+        ss.resume = ss.clk[STREAM_CLK_T] != 0;
+    }
     static_assert(SW == 64 || SW == 32, "streams per workgroup");
     constexpr int ROW = SW + 1;    // padded row of the transposed input tile (doubles)
     __shared__ __attribute__((aligned(16))) double X[3][RZ_MT][ROW];
@@ -1465,9 +1472,11 @@ static void launch_rz_stream(const IirCoef &coef, const double *h, int nlanes, i
 // start t_base; spikes = the full-length raster [B][Ttot][C] (zeroed by the caller before the first tile).
 hipError_t launch_stream_encode(const IirCoef &coef, const double *h, int nlanes, int C, int T, int Ts, int robust_width,
                                 int bipolar, int8_t *spikes, int Ttot, long long t_base, int first_tile, int final_tile,
-                                void *state, hipStream_t stream, int pos_lo)
+                                void *state, hipStream_t stream, int pos_lo, const int *clk)
 {
-    if (t_base % RZ_MT != 0 || (!final_tile && T % RZ_MT != 0) || t_base + T > (long long)pos_lo + Ttot) return hipErrorInvalidValue;
+    // (clocked: t_base / pos_lo / first_tile live in the device clock; the caller's schedule keeps the tile inside the window)
+    if (!clk && (t_base % RZ_MT != 0 || t_base + T > (long long)pos_lo + Ttot)) return hipErrorInvalidValue;
+    if (!final_tile && T % RZ_MT != 0) return hipErrorInvalidValue;
     const size_t nblk = (nlanes + 63) / 64;
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
     unsigned char *base = reinterpret_cast<unsigned char *>(state);
@@ -1487,7 +1496,8 @@ hipError_t launch_stream_encode(const IirCoef &coef, const double *h, int nlanes
     ss.Ttot = Ttot;
     ss.on = 1;
     ss.pos_lo = pos_lo;
-    if (first_tile) {
+    ss.clk = clk;
+    if (first_tile && !clk) {
         hipError_t e = zero_fill(base, 256, stream);
         if (e != hipSuccess) return e;
     }
@@ -1525,9 +1535,13 @@ hipError_t launch_stream_encode(const IirCoef &coef, const double *h, int nlanes
 __global__ __launch_bounds__(256) void rz_stream_horizon_kernel(const int *__restrict__ si, const int *__restrict__ ringP, int nlanes,
                                                                  int bipolar, int t_end, int final_, int chunk_frames, int base_chunk,
                                                                  int nwin, const int *__restrict__ ctl, int *__restrict__ range,
-                                                                 int *__restrict__ frames, int *__restrict__ status)
+                                                                 int *__restrict__ frames, int *__restrict__ status, int clocked)
 {
     __shared__ int red[256];
+    if (clocked) {  // the device clock instead of times by value (ctl is the head of loc_state)
+        t_end = ctl[STREAM_CLK_TEND];
+        base_chunk = ctl[STREAM_CLK_BASE] / chunk_frames;
+    }
     int f = 0x7fffffff;
     for (int g = threadIdx.x; g < nlanes; g += 256) {
         const int blk = g >> 6, l = g & 63;
@@ -1565,6 +1579,7 @@ __global__ __launch_bounds__(256) void rz_stream_horizon_kernel(const int *__res
         range[1] = hi;
         range[2] = ready;  // absolute, for the commit
         range[3] = nwin * chunk_frames;  // frames per trial of the window (trial stride of the beamforming kernels)
+        range[6] = t_end - base_chunk * chunk_frames;  // frames of the window that exist: the `T` of the beamforming launch
         frames[0] = ready * chunk_frames >= t_end ? t_end : ready * chunk_frames;  // (the last chunk of a recording may be ragged)
     }
 }
@@ -1577,7 +1592,7 @@ __global__ void rz_stream_commit_kernel(int *__restrict__ ctl, const int *__rest
 }
 
 hipError_t launch_stream_horizon(const void *enc_state, int nlanes, int bipolar, int t_end, int final_, int chunk_frames, int base_chunk,
-                                 int nwin, int *ctl, hipStream_t stream)
+                                 int nwin, int *ctl, hipStream_t stream, int clocked)
 {
     const size_t nblk = (nlanes + 63) / 64;
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
@@ -1589,43 +1604,99 @@ hipError_t launch_stream_horizon(const void *enc_state, int nlanes, int bipolar,
     const int *ringP = reinterpret_cast<const int *>(base + off);
     // ctl words: [0] done, [1] open, [4..6] range lo / hi / ready, [8] frames, [12..] status
     hipLaunchKernelGGL(rz_stream_horizon_kernel, dim3(1), dim3(256), 0, stream, si, ringP, nlanes, bipolar, t_end, final_, chunk_frames,
-                       base_chunk, nwin, ctl, ctl + 4, ctl + 8, ctl + 12);
+                       base_chunk, nwin, ctl, ctl + 4, ctl + 8, ctl + 12, clocked);
+    return hipGetLastError();
+}
+
+// ---- the device clock of a stream (loc_state control words STREAM_CLK_*) ------------------------------------------------------
+// begin: t frames have been pushed, the next tile brings n more; the raster window [base, base + cap) must cover [.., t + n): it
+// slides forward by whole chunks when it does not -- the schedule depends on the tile sizes only, the host can mirror it.
+__global__ void rz_stream_clock_begin_kernel(int *__restrict__ ctl, int n, int cap, int chunk_frames)
+{
+    const int t = ctl[STREAM_CLK_T], base = ctl[STREAM_CLK_BASE];
+    int nb = base;
+    if (t + n > base + cap) nb = (t + n - cap + chunk_frames - 1) / chunk_frames * chunk_frames;
+    ctl[STREAM_CLK_SHIFT] = nb - base;
+    ctl[STREAM_CLK_BASE] = nb;
+    ctl[STREAM_CLK_TEND] = t + n;
+}
+
+__global__ void rz_stream_clock_tick_kernel(int *__restrict__ ctl) { ctl[STREAM_CLK_T] = ctl[STREAM_CLK_TEND]; }
+
+// the slide itself, by the clock's shift: pass 0 copies the surviving rows of every trial to `tmp`, pass 1 back to the front of the
+// window and zeroes the rows behind them (a launch with shift == 0 returns at once: both passes are part of every tile's graph)
+__global__ __launch_bounds__(256) void rz_window_slide_kernel(int8_t *__restrict__ win, int8_t *__restrict__ tmp, size_t row_bytes, int C,
+                                                               const int *__restrict__ ctl, int chunk_frames, int pass, int *__restrict__ status)
+{
+    const size_t shift_bytes = (size_t)ctl[STREAM_CLK_SHIFT] * C;
+    if (shift_bytes == 0) return;
+    const int b = blockIdx.y;
+    int8_t *w = win + (size_t)b * row_bytes, *t = tmp + (size_t)b * row_bytes;
+    const size_t keep = shift_bytes < row_bytes ? row_bytes - shift_bytes : 0;
+    for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 16; i < row_bytes; i += (size_t)gridDim.x * 256 * 16) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const size_t e = i + u;
+            if (e >= row_bytes) break;
+            if (pass == 0) {
+                if (e < keep) t[e] = w[e + shift_bytes];
+            } else {
+                w[e] = e < keep ? t[e] : (int8_t)0;
+            }
+        }
+    }
+    // ctl[0] chunks are done: the window must keep chunk (done - 1) for the LIF history
+    const int new_base_chunk = ctl[STREAM_CLK_BASE] / chunk_frames;
+    if (pass == 0 && b == 0 && blockIdx.x == 0 && threadIdx.x == 0 && new_base_chunk > 0 && ctl[0] - 1 < new_base_chunk) atomicAdd(&status[1], 1);
+}
+
+hipError_t launch_stream_begin_tile(int *ctl, int8_t *win, int8_t *tmp, int B, size_t row_bytes, int C, int n, int cap, int chunk_frames,
+                                    hipStream_t stream)
+{
+    hipLaunchKernelGGL(rz_stream_clock_begin_kernel, dim3(1), dim3(1), 0, stream, ctl, n, cap, chunk_frames);
+    size_t gx = (row_bytes / 16 + 255) / 256;
+    gx = gx < 1 ? 1 : (gx > 256 ? 256 : gx);
+    for (int pass = 0; pass < 2; ++pass)
+        hipLaunchKernelGGL(rz_window_slide_kernel, dim3((unsigned)gx, B), dim3(256), 0, stream, win, tmp, row_bytes, C, ctl, chunk_frames, pass,
+                           ctl + 12);
+    return hipGetLastError();
+}
+
+hipError_t launch_stream_tick(int *ctl, hipStream_t stream)
+{
+    hipLaunchKernelGGL(rz_stream_clock_tick_kernel, dim3(1), dim3(1), 0, stream, ctl);
+    return hipGetLastError();
+}
+
+// np.roll's wrap-around inside the in-phase rows of a tile's STHT output: in-phase[t] = x[T - L/2 + t] for absolute t < L/2 (rows a
+// live source cannot know: zeros without `wrap`).  h planar [B][2M][Ts]; the tile's frame i (absolute t = clock + i) sits at column
+// col0 + i.  One launch per tile, a no-op once the clock has passed L/2.
+__global__ __launch_bounds__(256) void stht_wrap_rows_kernel(double *__restrict__ h, const double *__restrict__ wrap, int B, int M, int Ts,
+                                                              int col0, int n, int half, const int *__restrict__ ctl)
+{
+    const int t = ctl[STREAM_CLK_T];
+    if (t >= half) return;
+    const int k = half - t < n ? half - t : n;
+    const int total = B * M * k;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+        const int i = e % k, bm = e / k;
+        const int b = bm / M, m = bm - b * M;
+        h[((size_t)b * 2 * M + m) * Ts + col0 + i] = wrap ? wrap[((size_t)b * half + t + i) * M + m] : 0.0;
+    }
+}
+
+hipError_t launch_stht_wrap_rows(double *h, const double *wrap, int B, int M, int Ts, int col0, int n, int half, const int *ctl,
+                                 hipStream_t stream)
+{
+    const int total = B * M * (half < n ? half : n);
+    const int grid = total > 0 ? (total + 255) / 256 : 1;
+    hipLaunchKernelGGL(stht_wrap_rows_kernel, dim3(grid > 1024 ? 1024 : grid), dim3(256), 0, stream, h, wrap, B, M, Ts, col0, n, half, ctl);
     return hipGetLastError();
 }
 
 hipError_t launch_stream_commit(int *ctl, int block_chunks, hipStream_t stream)
 {
     hipLaunchKernelGGL(rz_stream_commit_kernel, dim3(1), dim3(1), 0, stream, ctl, ctl + 4, block_chunks);
-    return hipGetLastError();
-}
-
-// dst[b][r] = src[b][r + shift] while r + shift < cap, 0 beyond: the raster window slides forward by `shift` frames.
-// ctl[0] chunks are done: the window must keep chunk (done - 1) for the LIF history, or status[1] is raised.
-__global__ __launch_bounds__(256) void rz_window_shift_kernel(const int8_t *__restrict__ src, int8_t *__restrict__ dst, size_t row_bytes,
-                                                               size_t shift_bytes, const int *__restrict__ ctl, int new_base_chunk,
-                                                               int *__restrict__ status)
-{
-    const int b = blockIdx.y;
-    const int8_t *s = src + (size_t)b * row_bytes;
-    int8_t *d = dst + (size_t)b * row_bytes;
-    const size_t keep = row_bytes - shift_bytes;
-    for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 16; i < row_bytes; i += (size_t)gridDim.x * 256 * 16) {
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const size_t e = i + u;
-            if (e < row_bytes) d[e] = e < keep ? s[e + shift_bytes] : (int8_t)0;
-        }
-    }
-    if (b == 0 && blockIdx.x == 0 && threadIdx.x == 0 && new_base_chunk > 0 && ctl[0] - 1 < new_base_chunk) atomicAdd(&status[1], 1);
-}
-
-hipError_t launch_window_shift(const int8_t *src, int8_t *dst, int B, size_t row_bytes, size_t shift_bytes, int *ctl, int new_base_chunk,
-                               hipStream_t stream)
-{
-    size_t gx = (row_bytes / 16 + 255) / 256;
-    gx = gx < 1 ? 1 : (gx > 256 ? 256 : gx);
-    hipLaunchKernelGGL(rz_window_shift_kernel, dim3((unsigned)gx, B), dim3(256), 0, stream, src, dst, row_bytes, shift_bytes, ctl,
-                       new_base_chunk, ctl + 12);
     return hipGetLastError();
 }
 

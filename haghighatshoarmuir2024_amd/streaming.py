@@ -13,11 +13,15 @@ stream but arrives in tiles, and the result is bit-identical to the one-shot cal
   band-pass   DF2T state carried in the device-side stream state;
   RZCC        running sum, detector state, open clusters (candidate ring) and selection cursors carried as well
               (csrc/rzcc.hip "streaming"); spikes of a cluster are emitted when it closes, into a sliding WINDOW of the int8
-              raster (micloc_stream_encode_window_f64);
+              raster (micloc_stream_encode_tile_f64);
   LIF / beamforming / power   after every tile the device decides which frames can no longer receive a spike, filters and
               beamforms the 256-frame chunks that became final and adds their sum of y^2 to a persistent [B, G] accumulator in
-              the order of the one-shot call's time reduction (micloc_stream_localize_f64): power and arg-max after the last
+              the order of the one-shot call's time reduction (micloc_stream_localize_tile_f64): power and arg-max after the last
               tile equal the one-shot call bit for bit; in between they are the running estimate the live loop wants.
+
+The stream's CLOCK (frames pushed so far, base of the raster window) lives on the device as well: no launch of a tile carries an
+absolute time, so a tile of a given length is one replayable hipGraph -- push_replay(), the reference's live loop
+(micloc/localization_demo_snn.py:125-193) as one graph launch per 0.25 s frame.
 
 Memory: the window (default: tile + 4096 frames, 14 B per frame and trial, twice), one tile of fp64 intermediates, 2 x G doubles per
 trial.  push() allocates nothing and never synchronises (the ready range lives on the device); finish() / status() do.
@@ -68,10 +72,10 @@ class StreamingLocalizer:
         self.loc = torch.empty(int(self.nloc), dtype=torch.uint8, device=dev)
         self.nws = self.lib.micloc_stream_localize_workspace_bytes(self.plan.handle, self.B, self.cap)
         self.ws = torch.empty(int(self.nws), dtype=torch.uint8, device=dev)
-        self.win = [torch.empty((self.B, self.cap, self.C), dtype=torch.int8, device=dev) for _ in range(2)]
-        self.cur = 0
-        self.base = 0
-        # tile workspace, allocated once: [history | tile] frames and their planar STHT output (+ one spare row, see push)
+        self.win = torch.empty((self.B, self.cap, self.C), dtype=torch.int8, device=dev)
+        self.win_tmp = torch.empty_like(self.win)  # the slide's staging copy
+        self.base = 0  # host mirror of the device clock's window base (the schedule depends on the tile sizes only)
+        # tile workspace, allocated once: [history | tile] frames and their planar STHT output (+ one spare row, see _tile)
         self.hist = torch.zeros((self.B, self.halo, self.M), dtype=torch.float64, device=dev)  # zero history (lfilter's zero state)
         self.ext = torch.empty(self.B * (self.halo + self.max_tile) * self.M, dtype=torch.float64, device=dev)
         self.h = torch.empty((self.B * self.C + 1) * self.plan.padded_T(self.halo + self.max_tile), dtype=torch.float64, device=dev)
@@ -90,34 +94,33 @@ class StreamingLocalizer:
             self.raster = torch.zeros((self.B, self.T, self.C), dtype=torch.int8, device=dev)
         self.t = 0
         self.done = False
+        self._seen, self._graphs = set(), {}
+        # the stream's clock (frames pushed, window base) lives on the device: zeroed here with the states and the window
+        _lib.check(self.lib.micloc_stream_reset(self.plan.handle, self.B, runtime._ptr(self.state), self.nstate, runtime._ptr(self.loc), self.nloc,
+                                                runtime._ptr(self.win), self.cap, runtime._stream(dev)), "stream_reset")
 
     # ---- one tile -------------------------------------------------------------------------------------------------------
-    def push(self, x_tile, final=None):
-        """x_tile [batch, n, M] (numpy or device tensor); n a multiple of 16 except for the last tile, n <= max_tile.
-        final: this is the last tile (default: inferred from total_frames).  Returns the running (power, argmax) device
-        tensors (overwritten by the next push; over the frames beamformed so far)."""
+    def _check_tile(self, B, n, M, final):
         if self.done:
             raise _lib.MiclocError("the stream has ended")
-        x = self.plan.to_device(x_tile)
-        B, n, M = x.shape
         if B != self.B or M != self.M:
             raise ValueError(f"number of channels in the input siganl {M} should be the same as the number of microphones {self.M}!")
         if final is None:
             final = self.T is not None and self.t + n == self.T
         if n < 1 or n > self.max_tile or (not final and n % 16 != 0) or (self.T is not None and (self.t + n > self.T or (final and self.t + n != self.T))):
             raise ValueError("tiles must be multiples of 16 frames (except the last), at most max_tile long, and add up to total_frames")
+        if self.t + n > 0x7FFFFFFF:
+            raise ValueError("the stream's clock is a 32-bit frame counter")
+        return bool(final)
+
+    def _tile(self, x, n, final):
+        """The launches of one tile (nothing else: no allocation, no synchronisation, no absolute time by value -- the clock is a
+        device word), so that a tile of a given length is ONE replayable hipGraph (push_replay)."""
+        lib, plan, B, M = self.lib, self.plan, self.B, self.M
         st = runtime._stream(self.device)
-        lib, plan = self.lib, self.plan
-        # the window must cover [.., t + n): slide it forward (whole chunks) if it does not
-        if self.t + n > self.base + self.cap:
-            new_base = -(-(self.t + n - self.cap) // self.CH) * self.CH
-            if self.raster is not None:
-                self._save_window(self.t)
-            src, dst = self.win[self.cur], self.win[1 - self.cur]
-            _lib.check(lib.micloc_stream_window_shift(plan.handle, runtime._ptr(self.loc), runtime._ptr(src), runtime._ptr(dst), B, self.cap, self.base,
-                                                      new_base, st), "stream_window_shift")
-            self.cur = 1 - self.cur
-            self.base = new_base
+        # clock: t_end = t + n; the window slides forward (whole chunks) if it does not cover [.., t + n)
+        _lib.check(lib.micloc_stream_begin_tile(plan.handle, runtime._ptr(self.loc), runtime._ptr(self.win), runtime._ptr(self.win_tmp), B, n, self.cap, st),
+                   "stream_begin_tile")
         ext = self.ext[: B * (self.halo + n) * M].view(B, self.halo + n, M)  # contiguous [history | tile] of this tile length
         ext[:, : self.halo, :].copy_(self.hist)
         ext[:, self.halo :, :].copy_(x)
@@ -125,30 +128,73 @@ class StreamingLocalizer:
         Ts = plan.padded_T(Text)
         h = self.h[: (B * self.C + 1) * Ts]  # one spare row: the encoder's loader may read up to `halo` elements past its last row
         _lib.check(lib.micloc_stht_f64(plan.handle, runtime._ptr(ext), B, Text, runtime._ptr(h), Ts, st), "stht")
-        hv = h[: B * self.C * Ts].view(B, self.C, Ts)
-        if self.t < self.L // 2:
-            # np.roll's wrap-around: in-phase[t] = x[T - L/2 + t] for t < L/2 (zeros if the caller could not know them)
-            k = min(self.L // 2 - self.t, n)
-            hv[:, :M, self.halo : self.halo + k] = self.wrap[:, self.t : self.t + k, :].transpose(1, 2) if self.wrap is not None else 0.0
+        # np.roll's wrap-around: in-phase[t] = x[T - L/2 + t] for t < L/2 (zeros if the caller could not know them); a no-op later
+        _lib.check(lib.micloc_stream_wrap_rows_f64(plan.handle, runtime._ptr(self.loc), runtime._ptr(h), B, Ts, self.halo, n, runtime._ptr(self.wrap), st),
+                   "stream_wrap_rows")
         h_tile = ctypes.c_void_p(h.data_ptr() + 8 * self.halo)
-        win = self.win[self.cur]
-        first = int(self.t == 0)
-        _lib.check(lib.micloc_stream_encode_window_f64(plan.handle, h_tile, B, n, Ts, self.t, first, int(final), runtime._ptr(win), self.cap, self.base,
-                                                       runtime._ptr(self.state), self.nstate, st), "stream_encode_window")
-        _lib.check(lib.micloc_stream_localize_f64(plan.handle, runtime._ptr(self.state), runtime._ptr(self.loc), self.nloc, runtime._ptr(win), B, self.cap,
-                                                  self.base, self.t + n, first, int(final), runtime._ptr(self.power), runtime._ptr(self.argmax),
-                                                  runtime._ptr(self.ws), self.nws, st), "stream_localize")
+        _lib.check(lib.micloc_stream_encode_tile_f64(plan.handle, h_tile, B, n, Ts, int(final), runtime._ptr(self.win), self.cap, runtime._ptr(self.state),
+                                                     self.nstate, runtime._ptr(self.loc), st), "stream_encode_tile")
+        _lib.check(lib.micloc_stream_localize_tile_f64(plan.handle, runtime._ptr(self.state), runtime._ptr(self.loc), self.nloc, runtime._ptr(self.win), B,
+                                                       self.cap, int(final), runtime._ptr(self.power), runtime._ptr(self.argmax), runtime._ptr(self.ws),
+                                                       self.nws, st), "stream_localize_tile")
         # history for the next tile's quadrature FIR: the last `halo` frames of [history | tile]
         self.hist.copy_(ext[:, Text - self.halo :, :])
+
+    def _advance(self, n, final):
+        """Host mirror of the device clock (rz_stream_clock_begin_kernel's schedule) and the end-of-stream bookkeeping."""
+        if self.t + n > self.base + self.cap:
+            self.base = -(-(self.t + n - self.cap) // self.CH) * self.CH
         self.t += n
         self.done = bool(final)
+
+    def _before_slide(self, n):
+        if self.raster is not None and self.t + n > self.base + self.cap:
+            self._save_window(self.t)  # (keep_raster) the rows about to leave the window
+
+    def push(self, x_tile, final=None):
+        """x_tile [batch, n, M] (numpy or device tensor); n a multiple of 16 except for the last tile, n <= max_tile.
+        final: this is the last tile (default: inferred from total_frames).  Returns the running (power, argmax) device
+        tensors (overwritten by the next push; over the frames beamformed so far)."""
+        x = self.plan.to_device(x_tile)
+        B, n, M = x.shape
+        final = self._check_tile(B, n, M, final)
+        self._before_slide(n)
+        self._tile(x, n, final)
+        self._seen.add(n)
+        self._advance(n, final)
+        return self.power, self.argmax
+
+    def push_replay(self, x_tile):
+        """push() for the steady state of a live source (micloc/localization_demo_snn.py:125-193: one 0.25 s frame after the other):
+        a non-final tile whose length has been pushed before is ONE hipGraph launch -- captured on its second occurrence, replayed from
+        then on; the tile is copied into the graph's input buffer first.  Same results as push()."""
+        torch = runtime._torch()
+        x = self.plan.to_device(x_tile)
+        B, n, M = x.shape
+        if n not in self._seen or (self.T is not None and self.t + n == self.T):
+            return self.push(x)  # first tile of this length (lazy kernel set-up must not happen inside a capture) / the final tile
+        self._check_tile(B, n, M, False)
+        g = self._graphs.get(n)
+        if g is None:
+            x_in = torch.empty((B, n, M), dtype=torch.float64, device=self.device)
+            graph = torch.cuda.CUDAGraph()
+            s = torch.cuda.Stream(device=self.device)
+            s.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.graph(graph, stream=s, capture_error_mode="thread_local"):
+                self._tile(x_in, n, False)
+            torch.cuda.current_stream(self.device).wait_stream(s)
+            g = self._graphs[n] = (graph, x_in)
+        self._before_slide(n)
+        g[1].copy_(x)
+        g[0].replay()
+        self._advance(n, False)
         return self.power, self.argmax
 
     def _save_window(self, t_end):
         """(keep_raster) copy the window's frames [base, t_end) into the full raster: later copies carry more final data."""
         n = min(t_end, self.base + self.cap) - self.base
         if n > 0:
-            self.raster[:, self.base : self.base + n, :].copy_(self.win[self.cur][:, :n, :])
+            self.raster[:, self.base : self.base + n, :].copy_(self.win[:, :n, :])
 
     # ---- results ----------------------------------------------------------------------------------------------------------
     def status(self):

@@ -189,53 +189,52 @@ int micloc_planar_gram_f64(const double *planar, int B, int C, int T, int Ts, in
 int micloc_snn_pipeline_cov_f64(const micloc_plan *plan, const double *x, int B, int T, int t_start, int8_t *spikes,
                                 double *cov, double *power, int32_t *argmax, void *ws, size_t ws_bytes, void *stream);
 
-/* ---- streaming: a recording delivered tile by tile ------------------------------------------------- */
-/* The band-pass / RZCC stage as a resumable machine: micloc_stream_encode_f64 consumes T_tile frames of every stream
- * (h: planar [B][2M][row_stride] STHT output of the tile, local time) starting at absolute frame t_base and scatters the
- * spikes of every cluster that CLOSED into the full-length raster spikes [B][T_total][2M] (zeroed by the first_tile call);
- * DF2T state, running sum, detector state, candidate ring (open clusters) and selection cursors live in `state`
- * (micloc_stream_state_bytes, 256-B aligned) between calls, so that the tiles together perform exactly the operations of
- * one micloc_bandpass_rzcc_f64 launch over the whole recording -- bit-identical spikes for any tiling.  Reference: the
- * encoder treats a recording as ONE stream (snn_beamformer.py:330-338, spike_encoder.py:115-137); its live demo
- * (localization_demo_snn.py:125-193) restarts every 0.25 s frame instead.  t_base and every T_tile but the last are
- * multiples of 16; final_tile closes the clusters still open.  A stream whose candidate ring overflows (> 63 pending
- * candidates: out-of-band input) cannot be redone from its start here; micloc_stream_overflow returns how many were lost
- * (synchronises the stream) -- callers must treat a non-zero count as an error. */
-size_t micloc_lif_beamform_workspace_bytes(const micloc_plan *plan, int B, int T); /* ws of micloc_lif_beamform_f64 alone (bf_mat set) */
+/* ---- streaming: a recording delivered tile by tile, localised while it arrives ----------------------------------- */
+/* apply_to_signal (micloc/snn_beamformer.py:283-370) treats a recording as ONE stream; the reference's live loop restarts the chain
+ * on every 0.25 s frame instead (micloc/localization_demo_snn.py:125-193).  Here the recording is one stream that arrives in tiles:
+ *   - the band-pass / RZCC stage is a resumable machine: a tile of T_tile frames per call, the complete state of every stream (DF2T
+ *     registers, running sum, detector state, the candidate ring with its open clusters and selection cursors) kept in `enc_state`
+ *     (micloc_stream_state_bytes, 256-B aligned), so that the tiles together perform exactly the operations of one call on the whole
+ *     recording: the spikes are bit-identical for any tiling (spike_encoder.py:115-137); tile lengths are multiples of 16 except the
+ *     last, final_tile closes the clusters still open.  A stream whose candidate ring overflows (> 63 pending candidates: out-of-band
+ *     input) cannot be redone from its start; micloc_stream_overflow returns how many were lost (synchronises) -- a non-zero count
+ *     is an error;
+ *   - the spikes go into a sliding WINDOW of the int8 raster ([B][window_frames][2M] over the absolute frames [base, base +
+ *     window_frames), multiples of micloc_stream_chunk_frames), and after every tile the DEVICE decides which frames can no longer
+ *     receive a spike (the earliest position an open cluster or an incomplete candidate of any stream can still emit), runs LIF +
+ *     beamforming on the chunks that became final and adds their sums of y^2 to an accumulator in `loc_state` in the order of the
+ *     one-shot time reduction: power / argmax (may be NULL) are the running estimate over the frames beamformed so far and, after
+ *     the last tile, the one-shot result bit for bit;
+ *   - the CLOCK of the stream (frames pushed, base of the window) lives in the control words of `loc_state`, on the device: no call
+ *     takes an absolute time, every launch of a tile of n frames has the same arguments, so a tile is ONE capturable hipGraph.
+ * One tile of n frames =
+ *   micloc_stream_begin_tile        clock: t_end = t + n; the window slides forward by whole chunks when it must (through
+ *                                   scratch_window; a slide past rows the next chunk still needs is counted as a lag failure)
+ *   micloc_stht_f64                 on [history | tile] (the last L - 1 frames of the previous tile in front), by the caller
+ *   micloc_stream_wrap_rows_f64     np.roll's wrap-around rows of the in-phase channels while t < L/2 (wrap_tail [B][L/2][M] or NULL:
+ *                                   zeros -- a live source cannot know them; the tile's frame i sits at column first_col + i of
+ *                                   h [B][2M][Ts])
+ *   micloc_stream_encode_tile_f64   h = the tile's first column (row stride row_stride), spikes into the window
+ *   micloc_stream_localize_tile_f64 horizon, LIF + beamforming of the final chunks, accumulation; ends with the clock's tick
+ * micloc_stream_reset zero-fills the clock, both states and the window (once, before the first tile).  The last tile of a recording
+ * is issued with final_tile = 1 (both calls).  micloc_stream_localize_status: {chunks beamformed, frames beamformed, lag failures,
+ * open block fill}; synchronises the stream.  ws: micloc_stream_localize_workspace_bytes(B, window_frames). */
+size_t micloc_lif_beamform_workspace_bytes(const micloc_plan *plan, int B, int T); /* ws of micloc_lif_beamform_f64 / micloc_beamform_c128_f64 alone (bf_mat set) */
 size_t micloc_stream_state_bytes(const micloc_plan *plan, int B);
-int micloc_stream_encode_f64(const micloc_plan *plan, const double *h, int B, int T_tile, int row_stride, long long t_base,
-                             int first_tile, int final_tile, int8_t *spikes, int T_total, void *state, size_t state_bytes,
-                             void *stream);
-int micloc_stream_overflow(const void *state, int *count, void *stream);
-
-/* ---- streaming localisation: LIF + beamforming + power while the recording arrives ------------------------------------------
- * The reference's live loop produces a DoA per 0.25 s frame by restarting the chain on every frame
- * (micloc/localization_demo_snn.py:125-193); apply_to_signal (snn_beamformer.py:283-370) treats a recording as ONE stream.
- * These calls do the latter incrementally, in O(tile) memory and without host synchronisation: the encoder scatters its spikes
- * into a sliding WINDOW of the raster (int8 [B][window_frames][C] covering the absolute frames [window_base, window_base +
- * window_frames), both multiples of micloc_stream_chunk_frames); after every tile micloc_stream_localize_f64 decides ON THE
- * DEVICE which frames can no longer receive a spike (all clusters below them have closed), runs the LIF filter and the
- * beamformer on the chunks that became final, and adds their sum of y^2 to a persistent [B][G] accumulator in exactly the order
- * of the one-shot call's time reduction (blocks of 32 chunks, then the block sums) -- so that after the last tile power and
- * arg-max equal micloc_lif_beamform_f64 / micloc_snn_pipeline_f64 of the whole recording BIT FOR BIT, for any tiling.  `power`
- * [B][G] / `argmax` [B] (may be NULL) are the running values over the frames beamformed so far.
- *   micloc_stream_encode_window_f64   like micloc_stream_encode_f64, raster = the window (zeroed on the first tile)
- *   micloc_stream_window_shift        dst = the window moved forward to base_new (src != dst); the rows of the chunk in front
- *                                     of the first chunk not yet beamformed must stay inside (else a lag failure is counted)
- *   micloc_stream_localize_status     {chunks beamformed, frames beamformed, lag failures, open block fill}; synchronises
- * loc_state: micloc_stream_localize_state_bytes (256-B aligned), zeroed by the call with first_tile = 1. */
 size_t micloc_stream_localize_state_bytes(const micloc_plan *plan, int B);
-int micloc_stream_chunk_frames(const micloc_plan *plan);
 size_t micloc_stream_localize_workspace_bytes(const micloc_plan *plan, int B, int window_frames);
-int micloc_stream_encode_window_f64(const micloc_plan *plan, const double *h, int B, int T_tile, int row_stride, long long t_base,
-                                    int first_tile, int final_tile, int8_t *window, int window_frames, long long window_base,
-                                    void *state, size_t state_bytes, void *stream);
-int micloc_stream_localize_f64(const micloc_plan *plan, const void *enc_state, void *loc_state, size_t loc_state_bytes,
-                               const int8_t *window, int B, int window_frames, long long window_base, long long t_end,
-                               int first_tile, int final_tile, double *power, int32_t *argmax, void *ws, size_t ws_bytes,
-                               void *stream);
-int micloc_stream_window_shift(const micloc_plan *plan, void *loc_state, const int8_t *src, int8_t *dst, int B, int window_frames,
-                               long long base_old, long long base_new, void *stream);
+int micloc_stream_chunk_frames(const micloc_plan *plan);
+int micloc_stream_reset(const micloc_plan *plan, int B, void *enc_state, size_t enc_bytes, void *loc_state, size_t loc_bytes, int8_t *window,
+                        int window_frames, void *stream);
+int micloc_stream_begin_tile(const micloc_plan *plan, void *loc_state, int8_t *window, int8_t *scratch_window, int B, int n, int window_frames,
+                             void *stream);
+int micloc_stream_wrap_rows_f64(const micloc_plan *plan, const void *loc_state, double *h, int B, int Ts, int first_col, int n,
+                                const double *wrap_tail, void *stream);
+int micloc_stream_encode_tile_f64(const micloc_plan *plan, const double *h, int B, int T_tile, int row_stride, int final_tile, int8_t *window,
+                                  int window_frames, void *enc_state, size_t enc_bytes, const void *loc_state, void *stream);
+int micloc_stream_localize_tile_f64(const micloc_plan *plan, const void *enc_state, void *loc_state, size_t loc_bytes, const int8_t *window, int B,
+                                    int window_frames, int final_tile, double *power, int32_t *argmax, void *ws, size_t ws_bytes, void *stream);
+int micloc_stream_overflow(const void *state, int *count, void *stream);
 int micloc_stream_localize_status(const void *loc_state, int *status4, void *stream);
 
 /* ---- beamforming vectors from membrane covariances (design_from_template's decomposition step) ------ */

@@ -73,7 +73,6 @@ def test_round2_entry_points_validate_before_touching_the_device():
     assert lib.micloc_xylo_upload(65, one, 10, one, one, one, one, 1 << 20, None) == _lib.MICLOC_ERR_SHAPE
     assert lib.micloc_xylo_lif_resident_i16(one, 7, 1, 10, 28, 10, 0, 31, None, one, one, 1 << 20, None) == _lib.MICLOC_ERR_SHAPE  # Cin != 2 x ternary
     assert lib.micloc_stream_state_bytes(None, 4) == 0
-    assert lib.micloc_stream_encode_f64(None, one, 1, 16, 16, 0, 1, 0, one, 16, one, 1 << 20, None) == _lib.MICLOC_ERR_INVALID
     assert lib.micloc_stream_overflow(None, None, None) == _lib.MICLOC_ERR_INVALID
     assert lib.micloc_lif_beamform_workspace_bytes(None, 1, 10) == 0
 
@@ -106,9 +105,20 @@ def test_round3_entry_points_validate_before_touching_the_device():
     # streaming localisation
     assert lib.micloc_stream_localize_state_bytes(None, 4) == 0 and lib.micloc_stream_localize_workspace_bytes(None, 4, 512) == 0
     assert lib.micloc_stream_chunk_frames(None) == _lib.MICLOC_ERR_NOT_SET
-    assert lib.micloc_stream_encode_window_f64(None, one, 1, 16, 16, 0, 1, 0, one, 512, 0, one, 1 << 20, None) == _lib.MICLOC_ERR_INVALID
-    assert lib.micloc_stream_localize_f64(None, one, one, 1 << 20, one, 1, 512, 0, 16, 1, 0, None, None, one, 1 << 20, None) == _lib.MICLOC_ERR_INVALID
-    assert lib.micloc_stream_window_shift(None, one, one, vp(512), 1, 512, 0, 256, None) == _lib.MICLOC_ERR_INVALID
+    # the clocked tile calls (no absolute time by value)
+    assert lib.micloc_stream_reset(None, 1, one, 1 << 20, one, 1 << 20, one, 512, None) == _lib.MICLOC_ERR_INVALID
+    assert lib.micloc_stream_begin_tile(None, one, one, vp(512), 1, 16, 512, None) == _lib.MICLOC_ERR_INVALID
+    assert lib.micloc_stream_wrap_rows_f64(None, one, one, 1, 512, 480, 16, None, None) == _lib.MICLOC_ERR_INVALID
+    assert lib.micloc_stream_encode_tile_f64(None, one, 1, 16, 16, 0, one, 512, one, 1 << 20, one, None) == _lib.MICLOC_ERR_INVALID
+    assert lib.micloc_stream_localize_tile_f64(None, one, one, 1 << 20, one, 1, 512, 0, None, None, one, 1 << 20, None) == _lib.MICLOC_ERR_INVALID
+    # the sweep's Xylo call and the Demo's channel bookkeeping
+    assert lib.micloc_xylo_sweep_scratch_bytes(0) == 0 and lib.micloc_xylo_sweep_scratch_bytes(4) > 0
+    assert lib.micloc_xylo_lif_sweep_i16(None, 7, 1, 10, 14, 10, 31, one, one, 1 << 20, one, 1 << 20, 0, None) == _lib.MICLOC_ERR_INVALID
+    assert lib.micloc_xylo_lif_sweep_i16(one, 7, 1, 10, 28, 10, 31, one, one, 1 << 20, one, 1 << 20, 0, None) == _lib.MICLOC_ERR_SHAPE  # Cin != 2 x ternary
+    assert lib.micloc_xylo_lif_sweep_i16(one, 7, 1, 10, 14, 10, 31, one, one, 1 << 20, one, 1 << 20, 9, None) == _lib.MICLOC_ERR_INVALID  # workers per CU
+    assert lib.micloc_pack_events_u8(one, 1, 10, 14, 2, 2, 2, one, None) == _lib.MICLOC_ERR_INVALID  # band >= bands
+    assert lib.micloc_pack_events_u8(one, 1, 10, 14, 0, 1, 3, one, None) == _lib.MICLOC_ERR_INVALID  # unknown mode
+    assert lib.micloc_rate_from_counts_f64(None, 1, 10, 1, 100, 48000.0, one, None) == _lib.MICLOC_ERR_INVALID
     assert lib.micloc_stream_localize_status(None, None, None) == _lib.MICLOC_ERR_INVALID
 
 

@@ -1,4 +1,4 @@
-"""Streaming with exact state hand-off (streaming.StreamingLocalizer, micloc_stream_encode_f64): a recording pushed tile by
+"""Streaming with exact state hand-off (streaming.StreamingLocalizer, micloc_stream_encode_tile_f64 / micloc_stream_localize_tile_f64): a recording pushed tile by
 tile gives the spikes, power and arg-max of the one-shot call bit for bit, for any tiling -- including the reference's own
 golden trials and the speech-length trial."""
 import hashlib
@@ -216,3 +216,47 @@ def test_stream_other_kernel_families(num_mic, G):
         out = s.finish()
         np.testing.assert_array_equal(out["power"].cpu().numpy(), one["power"].cpu().numpy(), err_msg=f"tiles={tiles}")
         np.testing.assert_array_equal(out["argmax"].cpu().numpy(), one["argmax"].cpu().numpy())
+
+
+def test_stream_push_replay_is_one_graph_per_tile(cfg2):
+    """The live loop (micloc/localization_demo_snn.py:125-193: one 0.25 s frame after the other) as ONE hipGraph launch per tile: the
+    stream's clock lives on the device, so every launch of a tile of n frames has the same arguments.  push_replay captures the tile
+    on its second occurrence and replays it from then on -- running estimates equal to push()'s after every tile, the final result
+    equal to the one-shot call bit for bit, with the window sliding and np.roll's wrap-around rows inside the graph."""
+    import torch
+
+    from haghighatshoarmuir2024_amd.streaming import StreamingLocalizer
+
+    z = golden("trials_cfg2.npz")
+    rng = np.random.RandomState(9)
+    n, tiles = 2400, 11
+    T = tiles * n + 799
+    x = rng.randn(2, T, 7)
+    x[:, :4799, :] += z["sig_in"][:2]
+    bf = _beamformer()
+    W = cfg2["bf_mat"]
+    one = bf.localize_batch(W, x)
+    L2 = len(bf.kernel) // 2
+    kw = dict(wrap_tail=x[:, T - L2 :, :], max_tile=n, lag_frames=1024)
+    a = StreamingLocalizer(bf, W, 2, **kw)  # eager pushes
+    g = StreamingLocalizer(bf, W, 2, **kw)  # graph replays
+    xd = torch.from_numpy(x).cuda()
+    for k in range(tiles):
+        pa, aa = a.push(xd[:, k * n : (k + 1) * n, :])
+        pg, ag = g.push_replay(xd[:, k * n : (k + 1) * n, :])
+        assert torch.equal(pa, pg) and torch.equal(aa, ag), k
+        assert a.status() == g.status(), k
+    assert list(g._graphs) == [n] and g.base > 0  # one captured graph, and the window did slide inside it
+    a.push(xd[:, tiles * n :, :], final=True)
+    g.push(xd[:, tiles * n :, :], final=True)  # (the ragged last tile is an ordinary push)
+    oa, og = a.finish(), g.finish()
+    np.testing.assert_array_equal(og["power"].cpu().numpy(), one["power"].cpu().numpy())
+    np.testing.assert_array_equal(og["argmax"].cpu().numpy(), one["argmax"].cpu().numpy())
+    np.testing.assert_array_equal(oa["power"].cpu().numpy(), og["power"].cpu().numpy())
+    # known length: push_replay recognises the last tile by itself and issues it as a final push
+    h = StreamingLocalizer(bf, W, 2, total_frames=tiles * n, wrap_tail=x[:, tiles * n - L2 : tiles * n, :], max_tile=n, lag_frames=1024)
+    for k in range(tiles):
+        h.push_replay(xd[:, k * n : (k + 1) * n, :])
+    assert h.done and len(h._graphs) == 1
+    ref = bf.localize_batch(W, x[:, : tiles * n, :])
+    np.testing.assert_array_equal(h.finish()["power"].cpu().numpy(), ref["power"].cpu().numpy())
