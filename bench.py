@@ -815,6 +815,7 @@ def run_xylo(args, rank, local_rank, world):
               "xylo_lif_kernel": timed(lambda: net.run(raster, ternary=True, **lif_kw)),
               "xylo_lif_queue_alone": timed(lambda: net.run(raster, ternary=True, queued=True)),
               "peak_location_kernel": timed(lambda: runtime.peak_location(counts, G, win))}
+        queue_gave_up = net.queue_status()["gave_up"]  # (of the stand-alone queue launch just timed: must be 0)
         dom = max((k for k in st if k != "xylo_lif_queue_alone"), key=st.get)
         N = net.N
         nblocks = -(-N // 512)
@@ -854,7 +855,7 @@ def run_xylo(args, rank, local_rank, world):
                                    f"{B} trials/GPU/step, {G} hidden neurons = DoA grid, {4 * M} input channels, find_peak_location(win={win})",
                        "trials_per_gpu": B, "frames_per_trial": T, "num_mic": M, "num_doa": G, "mic_samples_per_s": value * M,
                        "parallelism": f"trial-sharded x{group_size}", "hip_streams": nstreams, "hip_graphs": True,
-                       "w_rec_quantised": int(net.w_rec)},
+                       "w_rec_quantised": int(net.w_rec), "lif_launch": args.xylo_lif, "lif_queue_workers_gave_up": int(queue_gave_up)},
             "mae_deg_per_snr": [float(v) for v in (mae * 180 / np.pi).cpu().numpy()],
             "roofline": roof,
         }

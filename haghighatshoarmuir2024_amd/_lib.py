@@ -101,6 +101,7 @@ SYMBOLS = {
     "micloc_xylo_upload": (c_int, [c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "micloc_xylo_lif_resident_i16": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "micloc_xylo_sweep_scratch_bytes": (c_size_t, [c_int]),
+    "micloc_xylo_sweep_status": (c_int, [c_void_p, ctypes.POINTER(c_int), c_void_p]),
     "micloc_pack_events_u8": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "micloc_rate_from_counts_f64": (c_int, [c_void_p, c_int, c_int, c_int, c_int, ctypes.c_double, c_void_p, c_void_p]),
     "micloc_xylo_lif_sweep_i16": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_int, c_void_p]),

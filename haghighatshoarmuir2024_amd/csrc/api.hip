@@ -966,6 +966,17 @@ int micloc_xylo_lif_sweep_i16(const int8_t *raster, int ternary_channels, int B,
     return MICLOC_OK;
 }
 
+int micloc_xylo_sweep_status(const void *scratch, int *status2, void *stream)
+{
+    if (!scratch || !status2) return MICLOC_ERR_INVALID;
+    int ctl[2];
+    HIP_TRY(hipMemcpyAsync(ctl, scratch, sizeof(ctl), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    status2[0] = ctl[0];
+    status2[1] = ctl[1];
+    return MICLOC_OK;
+}
+
 int micloc_design_vectors_f64(const double *cov, int n_doa, int C, int bipolar, double rel_prec, double *bf_mat, int G, int g0,
                               void *stream)
 {

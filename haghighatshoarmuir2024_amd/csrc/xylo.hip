@@ -180,7 +180,7 @@ __device__ __forceinline__ short2_t xp_decay(short2_t v, short2_t dash)
 // earlier to a workgroup that is RUNNING (tickets are only taken by resident workgroups), so the wait for it always ends; it is
 // bounded all the same (a worker that gives up sets the error word and the launch drains).
 constexpr int XQ_CTL = 64;         // control ints in front of the per-trial chunk counters: [0] ticket, [1] error
-constexpr int XQ_SPIN_MAX = 1 << 18;  // x (s_sleep 8 + one coherent load): a fraction of a second
+constexpr int XQ_SPIN_MAX = 1 << 24;  // x (s_sleep 8 + one coherent load, ~2 us): half a minute -- a predecessor on a crowded chip takes milliseconds
 
 template <int KQ, bool WANT_OUT, bool QUEUE = false>
 __global__ __launch_bounds__(XP_WAVES * 64) void xylo_lif_pk_kernel(const int8_t *__restrict__ raster, int tc, int T, int Cin,

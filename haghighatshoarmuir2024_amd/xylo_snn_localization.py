@@ -149,12 +149,19 @@ class XyloNetwork:
             _lib.check(self.lib.micloc_xylo_lif_sweep_i16(runtime._ptr(spikes), C, B, T, self.Cin, self.N, int(max_spikes), runtime._ptr(rate),
                                                           runtime._ptr(self.ws), self.nbytes, runtime._ptr(scratch), nb, int(workers_per_cu), runtime._stream(self.device)),
                        "xylo_lif_sweep")
-            self.last_scratch = scratch  # (tests read the queue's control words: int32[0] tickets handed out, [1] a worker gave up waiting)
+            self.last_scratch = scratch  # (queue_status reads its control words)
             return None, rate
         _lib.check(self.lib.micloc_xylo_lif_resident_i16(runtime._ptr(spikes), C if ternary else 0, B, T, self.Cin, self.N, self.w_rec, int(max_spikes),
                                                          runtime._ptr(out), runtime._ptr(rate), runtime._ptr(self.ws), self.nbytes,
                                                          runtime._stream(self.device)), "xylo_lif_resident")
         return out, rate
+
+
+    def queue_status(self):
+        """dict(tickets, gave_up) of the last ticket-queue launch (micloc_xylo_sweep_status; synchronises): gave_up must be 0."""
+        st = (ctypes.c_int * 2)()
+        _lib.check(self.lib.micloc_xylo_sweep_status(runtime._ptr(self.last_scratch), st, runtime._stream(self.device)), "xylo_sweep_status")
+        return dict(tickets=int(st[0]), gave_up=int(st[1]))
 
 
 class Demo:

@@ -357,6 +357,10 @@ int micloc_xylo_lif_resident_i16(const void *spikes_in, int ternary_channels, in
  * not serve (N > 512, Cin > 64, unaligned raster) take that call's kernels.  workers_per_cu: persistent workgroups per CU, 0 = 4 (three
  * waves each: three per SIMD); fewer leave room for the kernels of other streams.  No host access, no synchronisation (graph-capturable). */
 size_t micloc_xylo_sweep_scratch_bytes(int B);
+/* status2 = {tickets handed out (>= chunks x trials once the launch has drained), workers that gave up waiting for a predecessor
+ * (must be 0: the wait is bounded at ~half a minute only to keep a broken launch from hanging the device)} of the last
+ * micloc_xylo_lif_sweep_i16 call on `scratch`; synchronises the stream. */
+int micloc_xylo_sweep_status(const void *scratch, int *status2, void *stream);
 int micloc_xylo_lif_sweep_i16(const int8_t *raster, int ternary_channels, int B, int T, int Cin, int N, int max_spikes, int32_t *rate,
                               void *ws, size_t ws_bytes, void *scratch, size_t scratch_bytes, int workers_per_cu, void *stream);
 /* Demo.spike_encoding's channel bookkeeping (micloc/xylo_snn_localization.py:339-354: the per-band rasters side by side,

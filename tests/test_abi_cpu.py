@@ -116,6 +116,7 @@ def test_round3_entry_points_validate_before_touching_the_device():
     assert lib.micloc_xylo_lif_sweep_i16(None, 7, 1, 10, 14, 10, 31, one, one, 1 << 20, one, 1 << 20, 0, None) == _lib.MICLOC_ERR_INVALID
     assert lib.micloc_xylo_lif_sweep_i16(one, 7, 1, 10, 28, 10, 31, one, one, 1 << 20, one, 1 << 20, 0, None) == _lib.MICLOC_ERR_SHAPE  # Cin != 2 x ternary
     assert lib.micloc_xylo_lif_sweep_i16(one, 7, 1, 10, 14, 10, 31, one, one, 1 << 20, one, 1 << 20, 9, None) == _lib.MICLOC_ERR_INVALID  # workers per CU
+    assert lib.micloc_xylo_sweep_status(None, None, None) == _lib.MICLOC_ERR_INVALID
     assert lib.micloc_pack_events_u8(one, 1, 10, 14, 2, 2, 2, one, None) == _lib.MICLOC_ERR_INVALID  # band >= bands
     assert lib.micloc_pack_events_u8(one, 1, 10, 14, 0, 1, 3, one, None) == _lib.MICLOC_ERR_INVALID  # unknown mode
     assert lib.micloc_rate_from_counts_f64(None, 1, 10, 1, 100, 48000.0, one, None) == _lib.MICLOC_ERR_INVALID

@@ -242,8 +242,11 @@ def test_queued_sweep_equals_one_workgroup_per_trial(B, T, C, N):
     Bs = min(B, 64)
     _, rate_w = net.run(raster[:Bs].contiguous(), ternary=True, want_spikes=True)  # one workgroup per trial (also stores the raster)
     assert torch.equal(rate_q[:Bs], rate_w)
+    st = net.queue_status()
+    assert st["gave_up"] == 0 and st["tickets"] >= B * -(-T // 2048)
     for _ in range(2):  # the scratch of a call is reset by the call itself: again, same result
         assert torch.equal(net.run(raster, ternary=True, want_spikes=False)[1], rate_q)
+    assert net.queue_status()["gave_up"] == 0
     r = raster[:2].cpu().numpy()
     events = np.concatenate([r > 0, r < 0], axis=2).astype(np.uint8)
     for b in range(2):
