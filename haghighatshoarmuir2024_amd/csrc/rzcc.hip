@@ -981,6 +981,20 @@ __global__ __launch_bounds__(448, (WANT_PRE && WANT_SPIKES) ? 2 : 4) void bandpa
             // better one -- the later one on a tie -- is the spike; both positions are in registers, two LDS reads for the priorities
             const double v0 = *val_at(s) * sgn, v1 = *val_at(s + stride) * sgn;
             emit(v1 >= v0 ? lastpos : first);
+        } else if (e - s <= 3 * stride) {
+            // three candidates p0 < p1 < p2, consecutive gaps < w (the order-1 band-pass of the Xylo path produces them by the
+            // thousand): the greedy rule in closed form -- the best one (the later one on a tie) is a spike and removes its
+            // neighbours; if that was an end and the other end is >= w away, the other end is a spike too.  Three priorities and
+            // the middle position from LDS, no selection loop for the whole wave to sit through.
+            const double v0 = *val_at(s) * sgn, v1 = *val_at(s + stride) * sgn, v2 = *val_at(s + 2 * stride) * sgn;
+            const bool mid = v1 >= v0 && v2 < v1;  // arg-max with "later wins": 1 beats 0 on >=, 2 beats the best so far on >=
+            if (mid) {
+                emit(*word_at(s + stride) >> 1);
+            } else {
+                const bool last_best = v2 >= (v1 >= v0 ? v1 : v0);
+                emit(last_best ? lastpos : first);
+                if (lastpos - first >= w) emit(last_best ? first : lastpos);
+            }
         } else {
             // (collecting the clusters of three or more candidates in a per-lane queue and resolving them once per tile instead of
             // once per trip was measured and rejected: select waves 3300 -> 4200 cycles per tile on config 4)
