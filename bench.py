@@ -901,6 +901,16 @@ def run(args):
     # consecutive steps are independent batches: on every workload the serial scan / encoder of one step (few, long
     # latency-bound workgroups) overlaps the throughput-bound STHT and beamforming kernels of its neighbours
     nstreams = max(1, args.streams)
+    # every stream holds its own batch, end-to-end copy and workspace: fewer streams rather than an out-of-memory kill when a
+    # rank's share is large (--baseline-total on few GPUs)
+    per_stream = 2 * wl["x"].numel() * 8 + wl["plan"].lib.micloc_workspace_bytes(wl["plan"].handle, wl["x"].shape[0], wl["x"].shape[1])
+    free_bytes = torch.cuda.mem_get_info(device)[0]
+    while nstreams > 1 and (nstreams - 1) * per_stream > 0.6 * free_bytes:
+        nstreams -= 1
+    if nstreams == 1 and 1.2 * wl["x"].numel() * 8 > free_bytes:  # (the end-to-end variant keeps a second copy of the batch)
+        print(f"bench.py: {wl['x'].shape[0]} trials per rank need about {per_stream / 1e9:.0f} GB per stream, {free_bytes / 1e9:.0f} GB are free: "
+              "use --trials or more GPUs", file=sys.stderr)
+        return 2
     step, pipe = make_step(wl, nstreams, variants=True if noisy else None)
     B, T, M = wl["x"].shape
     G = wl["bf_mat"].shape[1]
