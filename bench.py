@@ -656,6 +656,44 @@ def beamformer_c128_block(wl, args):
     return res
 
 
+def streaming_live_block(wl):
+    """The reference's live loop (micloc/localization_demo_snn.py:125-193: a 0.25 s frame of 12 000 samples, the chain, a DoA) as a
+    stream: StreamingLocalizer on one recording, tiles of 12 000 frames, eager push() against push_replay() (ONE hipGraph launch per
+    tile: the stream's clock lives on the device).  Reports the wall time per tile with the device drained after every tile (what a
+    live consumer sees), and that both give the same running estimate."""
+    import torch
+
+    from haghighatshoarmuir2024_amd.streaming import StreamingLocalizer
+
+    beamf, bf_mat = wl["beamf"], wl["bf_mat"]
+    n, tiles = 12_000, 24
+    rng = np.random.RandomState(5)
+    x = torch.from_numpy(rng.randn(1, n * tiles, len(beamf.geometry))).to(wl["x"].device)
+    out = {}
+    ref = None
+    for mode in ("push", "push_replay"):
+        s = StreamingLocalizer(beamf, bf_mat, 1, max_tile=n, lag_frames=4096)
+        fn = getattr(s, mode)
+        ts = []
+        for k in range(tiles):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            p, a = fn(x[:, k * n : (k + 1) * n, :])
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        out[mode + "_ms_per_tile"] = float(np.median(ts[4:]) * 1e3)  # (the first tiles include the capture)
+        st = s.status()
+        if ref is None:
+            ref = (p.clone(), a.clone(), st)
+        else:
+            out["same_estimate"] = bool(torch.equal(ref[0], p) and torch.equal(ref[1], a) and ref[2] == st)
+    out["tile_frames"] = n
+    out["realtime_factor"] = 0.25 / (out["push_replay_ms_per_tile"] * 1e-3)
+    out["note"] = ("one recording, 0.25 s tiles (12 000 frames x 7 mics), wall time per tile incl. the H2D-free hand-over and a device "
+                   "synchronisation; push_replay = one captured hipGraph per tile (DESIGN.md 4.2)")
+    return out
+
+
 def other_configs_block(args):
     """The other BASELINE configs on the same box, a few steps each, as CHILD processes of this (GPU-initialised) process --
     started, never exec'ed; one at a time."""
@@ -1076,6 +1114,7 @@ def run(args):
         }
         if noisy and M * 2 <= 16:
             result["variants"]["beamformer_c128"] = beamformer_c128_block(wl, args)
+            result["variants"]["streaming_live"] = streaming_live_block(wl)
         if noisy and group_size == 1 and not args.no_other_configs:
             torch.cuda.synchronize()
             result["mae_ref"] = reference_mae_block(device)
