@@ -54,3 +54,24 @@ def test_child_failure_ends_the_job():
     r = _run("--gpus", "2", "--cpu-stub", "--steps", "-1")
     assert r.returncode != 0
     assert not any(l.lstrip().startswith("{") for l in r.stdout.splitlines())
+
+
+def test_cpu_core_pinning_and_baseline_total_flags():
+    """--cpu-cores pins a rank to its own slice of the allowed host cores before anything touches the GPU (8 ranks on a 16-core
+    cgroup get two each); --baseline-total parses for the speech / stress workloads.  Run in a child: the mask is per process."""
+    code = r"""
+import os, sys
+sys.path.insert(0, %r)
+import bench
+allowed = sorted(os.sched_getaffinity(0))
+n = bench.pin_cpu_cores(2, 1)
+now = sorted(os.sched_getaffinity(0))
+assert n == min(2, len(allowed)) and len(now) == n and set(now) <= set(allowed), (allowed, now)
+if len(allowed) >= 4:
+    assert now == allowed[2:4]
+a = bench.parse(["--config", "stress", "--baseline-total", "--gpus", "8", "--cpu-cores", "2", "--xylo-lif", "queue:3"])
+assert a.baseline_total and a.cpu_cores == 2 and a.gpus == 8 and a.xylo_lif == "queue:3"
+print("ok")
+""" % os.path.dirname(BENCH)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
