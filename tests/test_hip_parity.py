@@ -613,7 +613,10 @@ def test_stht_vector_form_still_exact():
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     variant = os.path.join(root, "tools", "_variants", "libmicloc_hip_stht_valu.so")
-    assert os.path.exists(variant), "tools/_variants/libmicloc_hip_stht_valu.so missing: run __graft_entry__.build() (tools/dev/make_variant.py stht_valu)"
+    # built by __graft_entry__.build(); (re)built here if it is missing or older than the objects it links (a no-op otherwise)
+    mk = subprocess.run([sys.executable, os.path.join(root, "tools", "dev", "make_variant.py"), "stht_valu"], stdout=subprocess.PIPE,
+                        stderr=subprocess.PIPE, timeout=900)
+    assert mk.returncode == 0 and os.path.exists(variant), mk.stderr.decode()[-2000:]
     code = r"""
 import numpy as np, sys
 sys.path.insert(0, %r); sys.path.insert(0, %r)
