@@ -1021,10 +1021,14 @@ __global__ __launch_bounds__(BF_THREADS, 4) void beamform_gen_kernel(const int8_
             }
             __syncthreads();  // every wave is done with the spike tile and the nir table: slab buffer 1 may overwrite them
         } else {
+            // planar source: channel c = 16 ct + 4 r + q of frame tb + lc -- one running pointer that steps 4 rows per load (32 loads
+            // with their own 64-bit addresses each were the 148-244 B of scratch this branch had at 128 channels)
 #pragma unroll
             for (int tt = 0; tt < NT; ++tt) {
                 const int tb = tb0 + 16 * tt;
                 const bool tvalid = (tb + lc) < T;
+                const double *pp = pre + ((size_t)b * C + q) * Ts + (tvalid ? tb + lc : 0);
+                const size_t step = (size_t)4 * Ts;
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) {
                     double4_t acc;
@@ -1032,8 +1036,9 @@ __global__ __launch_bounds__(BF_THREADS, 4) void beamform_gen_kernel(const int8_
                     for (int r = 0; r < 4; ++r) {
                         const int c = 16 * ct + 4 * r + q;
                         double v = 0.0;
-                        if (tvalid && c < C) v = pre[((size_t)b * C + c) * Ts + tb + lc];
+                        if (tvalid && c < C) v = *pp;
                         acc[r] = v;
+                        pp += step;
                     }
                     Vf[tt][ct] = acc;
                 }
@@ -1047,62 +1052,56 @@ __global__ __launch_bounds__(BF_THREADS, 4) void beamform_gen_kernel(const int8_
             const int buf = sl & 1;
             const double *sbuf = buf ? U : slab0;
             if (sl + 1 < NSL) stage_slab(sl + 1, buf ^ 1);  // in flight behind this slab's MFMAs (the other buffer was released by the last barrier)
-            double4_t acc[2][NT];
-#pragma unroll
-            for (int gl = 0; gl < 2; ++gl)
-#pragma unroll
-                for (int tt = 0; tt < NT; ++tt) acc[gl][tt] = double4_t{0.0, 0.0, 0.0, 0.0};
-            if (tb0 < T) {
-                // B fragments D k-steps ahead of their MFMAs, the order pinned: left alone the scheduler hoists as many of the
-                // 2 KS reads as the register budget holds -- and at 128 channels (64 VGPRs of membrane fragments) then spills
-                const double *w0 = sbuf + boff0, *w1 = sbuf + (boff0 ^ 16);
-                constexpr int D = 3;
-                double wk0[KS], wk1[KS];
-#pragma unroll
-                for (int k = 0; k < D && k < KS; ++k) {
-                    wk0[k] = w0[4 * k * GEN_COLS];
-                    wk1[k] = w1[4 * k * GEN_COLS];
-                }
-                __builtin_amdgcn_sched_group_barrier(0x100, 2 * (D < KS ? D : KS), 0);
-#pragma unroll
-                for (int k = 0; k < KS; ++k) {
-                    if (k + D < KS) {
-                        wk0[k + D] = w0[4 * (k + D) * GEN_COLS];
-                        wk1[k + D] = w1[4 * (k + D) * GEN_COLS];
-                        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                    }
-#pragma unroll
-                    for (int tt = 0; tt < NT; ++tt) {
-                        acc[0][tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(Vf[tt][k >> 2][k & 3], wk0[k], acc[0][tt], 0, 0, 0);
-                        acc[1][tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(Vf[tt][k >> 2][k & 3], wk1[k], acc[1][tt], 0, 0, 0);
-                    }
-                    __builtin_amdgcn_sched_group_barrier(0x008, 2 * NT, 0);
-                }
-            }
 #pragma unroll
             for (int gl = 0; gl < 2; ++gl) {
+                // one 16-column tile at a time: one accumulator set and one stream of B fragments (both tiles at once cost 16 more
+                // registers than the 128-channel instantiation has: scratch in the slab loop's prologue)
+                double4_t acc[NT];
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt) acc[tt] = double4_t{0.0, 0.0, 0.0, 0.0};
+                if (tb0 < T) {
+                    // B fragments D k-steps ahead of their MFMAs, the order pinned: left alone the scheduler hoists as many of the
+                    // KS reads as the register budget holds -- and at 128 channels (64 VGPRs of membrane fragments) then spills
+                    const double *w0 = sbuf + (gl ? (boff0 ^ 16) : boff0);
+                    constexpr int D = WANT_Y ? 1 : 3;  // (with y stored the launch is HBM-write bound and short of registers: one read ahead)
+                    double wk[KS];
+#pragma unroll
+                    for (int k = 0; k < D && k < KS; ++k) wk[k] = w0[4 * k * GEN_COLS];
+                    __builtin_amdgcn_sched_group_barrier(0x100, D < KS ? D : KS, 0);
+#pragma unroll
+                    for (int k = 0; k < KS; ++k) {
+                        if (k + D < KS) {
+                            wk[k + D] = w0[4 * (k + D) * GEN_COLS];
+                            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        }
+#pragma unroll
+                        for (int tt = 0; tt < NT; ++tt)
+                            acc[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(Vf[tt][k >> 2][k & 3], wk[k], acc[tt], 0, 0, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);
+                    }
+                }
                 double sq = 0.0;
 #pragma unroll
                 for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) sq = __builtin_fma(acc[gl][tt][r], acc[gl][tt][r], sq);
+                    for (int r = 0; r < 4; ++r) sq = __builtin_fma(acc[tt][r], acc[tt][r], sq);
                 if (WANT_Y) {
+                    // (the planar source is the complex Beamformer's: y interleaved (re, im), columns [0, Ghp) real, [Ghp, Gp) imaginary;
+                    //  the spike source is the SNN beamformer's real y) -- one row pointer per time tile, stepping four rows per store
                     const int gcol = 16 * (2 * sl + gl) + lc;
+                    const int part = gcol >= Ghp;
+                    const int gc = gcol - (part ? Ghp : 0);
+                    const bool colok = SRC_SPIKES ? gcol < G : (gcol < Gp && gc < (G >> 1));
+                    const size_t rowlen = SRC_SPIKES ? (size_t)G : (size_t)G;  // doubles per row of y (complex: 2 x G / 2)
+                    const size_t coloff = SRC_SPIKES ? (size_t)gcol : (size_t)2 * gc + part;
 #pragma unroll
                     for (int tt = 0; tt < NT; ++tt) {
-                        const int tb = tb0 + 16 * tt;
+                        const int t0r = tb0 + 16 * tt + q;
+                        double *yp = y + ((size_t)b * T + t0r) * rowlen + coloff;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const int t = tb + q + 4 * r;
-                            if (t < T) {
-                                if (!y_complex) {
-                                    if (gcol < G) y[((size_t)b * T + t) * G + gcol] = acc[gl][tt][r];
-                                } else {
-                                    const int part = gcol >= Ghp;
-                                    const int g = gcol - (part ? Ghp : 0);
-                                    if (gcol < Gp && g < (G >> 1)) y[(((size_t)b * T + t) * (G >> 1) + g) * 2 + part] = acc[gl][tt][r];
-                                }
-                            }
+                            if (colok && t0r + 4 * r < T) *yp = acc[tt][r];
+                            yp += 4 * rowlen;
                         }
                     }
                 }
