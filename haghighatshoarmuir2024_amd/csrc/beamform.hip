@@ -502,8 +502,8 @@ __global__ __launch_bounds__(BF_THREADS, WANT_Y ? 2 : (KV ? WS_KV_WAVES : (NT ==
         return;
     }
     // NGW = ceil(GT / 8): every wave owns NGW or NGW - 1 DoA tiles (wave-uniform choice of the instantiation)
-    if constexpr (KM < 4) {
-        constexpr bool LEAN = KV > 0 && WS_KV_WAVES >= 6;
+    if constexpr (KM < 4 || NGW == 4) {  // (16 channels with four DoA tiles per wave: the two-pass form as well -- 8 B of scratch otherwise)
+        constexpr bool LEAN = (KV > 0 || NGW == 4) && WS_KV_WAVES >= 6;
         if constexpr (LEAN && NGW == 4) {
             // four DoA tiles per wave do not fit 80 registers: two passes of two over the parked fragments (the LDS reads
             // double, the MFMAs do not) keep three workgroups per CU

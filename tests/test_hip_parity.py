@@ -379,6 +379,36 @@ def test_complex_beamformer_bf_stationary_shapes(torch, M, G, T):
         assert int(out["argmax"][i]) == ref["argmax"]
 
 
+@pytest.mark.parametrize("M,G", [(8, 449), (8, 512), (6, 400), (8, 513)])
+def test_eight_mics_many_doas_vs_oracle(torch, M, G):
+    """16 (and 12) channels with four DoA tiles per wave (385-512 DoAs: beamform_ws_kernel's two-pass form without a vector tail), and
+    one DoA more than the bf_mat-stationary kernel serves (513: the general kernel with one channel tile) -- vs the oracle."""
+    from haghighatshoarmuir2024_amd.runtime import Plan
+
+    fs, T = 48_000, 700
+    rng = np.random.RandomState(M * 1000 + G)
+    ker = O.stht_kernel(fs, 10e-3)
+    b, a = O.bandpass(fs, [1000.0, 2000.0])
+    w = O.robust_width(fs, 2000.0)
+    tau = 1 / (2 * np.pi * 2000.0)
+    nir = O.neuron_kernel(np.arange(T) / fs, [tau, tau])
+    W = rng.randn(2 * M, G)
+    x = rng.randn(2, T, M)
+    p = Plan(M, ker, b, a, w, True)
+    p.set_neuron_kernel(nir)
+    p.set_bf_mat(W)
+    xd = p.to_device(x)
+    out = p.snn_pipeline(xd, want_spikes=True, want_y=True, want_power=True)
+    only = p.snn_pipeline(xd, want_power=True)
+    for i in range(2):
+        ref = O.snn_chain(x[i], ker, b, a, w, True, nir, W)
+        np.testing.assert_array_equal(out["spikes"][i].cpu().numpy(), ref["spikes"])
+        np.testing.assert_array_equal(out["y"][i].cpu().numpy(), ref["y"])
+        np.testing.assert_allclose(out["power"][i].cpu().numpy(), ref["power"], rtol=1e-12)
+        np.testing.assert_allclose(only["power"][i].cpu().numpy(), ref["power"], rtol=1e-12)
+        assert int(out["argmax"][i]) == ref["argmax"] == int(only["argmax"][i])
+
+
 @pytest.mark.parametrize("T", [2, 3, 16, 17, 31, 100, 511, 512, 513, 1025])
 def test_pipeline_short_and_boundary_lengths(plan2, cfg2, T):
     """Ragged lengths around every tile size in the kernels (16-step RZCC tiles, 512-frame beamforming chunks)."""
