@@ -925,9 +925,7 @@ __global__ __launch_bounds__(BF_THREADS, 4) void beamform_gen_kernel(const int8_
     };
     auto slabs_landed = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
 
-    const double *pout_chunk = nullptr;
     double *pout = partial ? partial + ((size_t)b * nchunks + chunk) * Gp : nullptr;
-    (void)pout_chunk;
     const int Ghp = Gp >> 1;
 
     for (int s = 0; s < NSUB; ++s) {
@@ -1092,7 +1090,7 @@ __global__ __launch_bounds__(BF_THREADS, 4) void beamform_gen_kernel(const int8_
                     const int part = gcol >= Ghp;
                     const int gc = gcol - (part ? Ghp : 0);
                     const bool colok = SRC_SPIKES ? gcol < G : (gcol < Gp && gc < (G >> 1));
-                    const size_t rowlen = SRC_SPIKES ? (size_t)G : (size_t)G;  // doubles per row of y (complex: 2 x G / 2)
+                    const size_t rowlen = (size_t)G;  // doubles per row of y (complex: G counts real columns = 2 x the DoA count)
                     const size_t coloff = SRC_SPIKES ? (size_t)gcol : (size_t)2 * gc + part;
 #pragma unroll
                     for (int tt = 0; tt < NT; ++tt) {
