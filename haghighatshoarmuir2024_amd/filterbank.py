@@ -15,8 +15,13 @@ class Filterbank:
         """[T, M] -> device tensor [F, T, M]."""
         import torch
 
-        outs = [runtime.lfilter(b, a, sig_in, device=self.device) for b, a in self.ba_list]
-        return torch.stack(outs, dim=0)
+        dev = runtime.require_gpu(self.device)
+        x = sig_in if isinstance(sig_in, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(sig_in, dtype=np.float64))
+        x = x.to(device=dev, dtype=torch.float64).contiguous()  # uploaded once, every band's kernel writes its own slice of the result
+        out = torch.empty((len(self.ba_list),) + tuple(x.shape), dtype=torch.float64, device=dev)
+        for f, (b, a) in enumerate(self.ba_list):
+            runtime.lfilter(b, a, x, device=dev, out=out[f])
+        return out
 
     def evolve(self, sig_in):
         sig_in = np.asarray(sig_in, dtype=np.float64)

@@ -347,8 +347,9 @@ def rzcc_encode(sig, robust_width, bipolar, device=None, chunk_frames=0):
     return spikes[0] if squeeze else spikes
 
 
-def lfilter(b, a, x, device=None):
-    """scipy.signal.lfilter(b, a, x, axis=0) for real x [T, C] or [B, T, C] on the device."""
+def lfilter(b, a, x, device=None, out=None):
+    """scipy.signal.lfilter(b, a, x, axis=0) for real x [T, C] or [B, T, C] on the device (`out`: a contiguous float64 device tensor of
+    x's shape to write into -- e.g. one band's slice of a filterbank's [F, T, M] result)."""
     torch = _torch()
     lib = _lib.load()
     device = require_gpu(device)
@@ -360,7 +361,12 @@ def lfilter(b, a, x, device=None):
     if squeeze:
         x = x.unsqueeze(0)
     B, T, C = x.shape
-    y = torch.empty_like(x)
+    if out is None:
+        y = torch.empty_like(x)
+    else:
+        y = out.unsqueeze(0) if squeeze else out
+        if tuple(y.shape) != (B, T, C) or y.dtype != torch.float64 or not y.is_contiguous() or y.device != x.device:
+            raise ValueError("out must be a contiguous float64 device tensor of the input's shape")
     if B * T * C > 0:
         nbytes = lib.micloc_lfilter_workspace_bytes(B, T, C)
         ws = _op_workspace(device, nbytes)
