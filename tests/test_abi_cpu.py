@@ -150,3 +150,35 @@ def test_product_does_not_import_the_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 for needle in ("import oracle", "from oracle", "libmicloc_oracle", '#include "micloc_oracle', "oracle/_build"):
                     assert needle not in text, (f, needle)
+
+
+def test_header_is_plain_c_and_links_from_c(tmp_path):
+    """include/micloc_hip.h is the drop-in boundary: it must be usable from plain C (C99, -pedantic), and a C program must be able to
+    link against libmicloc_hip.so and call the entry points that need no GPU."""
+    import shutil
+    import subprocess
+
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc on this host")
+    src = tmp_path / "abi_c.c"
+    src.write_text(
+        '#include "micloc_hip.h"\n#include <stdio.h>\n'
+        "int main(void) {\n"
+        '    printf("%d %s %d %zu\\n", micloc_abi_version(), micloc_status_string(MICLOC_ERR_SHAPE), micloc_padded_T(4799),\n'
+        "           micloc_rzcc_workspace_bytes(2, 100, 14));\n"
+        "    return micloc_abi_version() == MICLOC_ABI_VERSION ? 0 : 1;\n}\n")
+    inc = os.path.join(ROOT, "include")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", inc, "-fsyntax-only", str(src)])
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    exe = tmp_path / "abi_c"
+    # (the HIP runtime the library needs is the one PyTorch-ROCm ships or /opt/rocm's: let the dynamic loader find either)
+    import torch
+
+    rpaths = [libdir, os.path.join(os.path.dirname(torch.__file__), "lib"), "/opt/rocm/lib"]
+    r = subprocess.run(["gcc", "-std=c99", "-I", inc, str(src), "-o", str(exe), "-L", libdir, "-lmicloc_hip", "-Wl,--allow-shlib-undefined"]
+                       + [f"-Wl,-rpath,{p}" for p in rpaths], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    out = subprocess.run([str(exe)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    fields = out.stdout.decode().split()
+    assert fields[0] == "1" and fields[-2] == "4800" and int(fields[-1]) > 0
