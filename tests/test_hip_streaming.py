@@ -260,3 +260,39 @@ def test_stream_push_replay_is_one_graph_per_tile(cfg2):
     assert h.done and len(h._graphs) == 1
     ref = bf.localize_batch(W, x[:, : tiles * n, :])
     np.testing.assert_array_equal(h.finish()["power"].cpu().numpy(), ref["power"].cpu().numpy())
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_stream_random_tilings_eager_and_replayed(cfg2, seed):
+    """Random tile sequences (lengths from a small set, so that several lengths get their own captured graph), every tile randomly
+    pushed eagerly or replayed, a window small enough to slide many times: the device clock, the in-graph slide and the wrap-around
+    rows must give the one-shot result bit for bit whatever the mix."""
+    import torch
+
+    from haghighatshoarmuir2024_amd.streaming import StreamingLocalizer
+
+    rng = np.random.RandomState(100 + seed)
+    sizes = [int(v) for v in rng.choice([64, 160, 256, 400, 1024, 1600], size=3, replace=False)]
+    T = int(rng.randint(9000, 16000))
+    x = rng.randn(2, T, 7)
+    x[:, : min(T, 4799), :] += golden("trials_cfg2.npz")["sig_in"][:2][:, : min(T, 4799), :]
+    bf = _beamformer()
+    W = cfg2["bf_mat"]
+    one = bf.localize_batch(W, x)
+    L2 = len(bf.kernel) // 2
+    s = StreamingLocalizer(bf, W, 2, wrap_tail=x[:, T - L2 :, :], max_tile=max(sizes), lag_frames=1536, keep_raster=True, total_frames=T)
+    xd = torch.from_numpy(x).cuda()
+    t = 0
+    while t < T:
+        n = int(rng.choice(sizes))
+        if t + n >= T:
+            s.push(xd[:, t:, :], final=True)  # the ragged rest
+            break
+        (s.push_replay if rng.rand() < 0.6 else s.push)(xd[:, t : t + n, :])
+        t += n
+    out = s.finish(want_spikes=True)
+    assert s.base > 0 and len(s._graphs) >= 1
+    np.testing.assert_array_equal(out["power"].cpu().numpy(), one["power"].cpu().numpy())
+    np.testing.assert_array_equal(out["argmax"].cpu().numpy(), one["argmax"].cpu().numpy())
+    ref = bf.localize_batch(W, x, return_spikes=True)
+    assert torch.equal(out["spikes"], ref["spikes"])
