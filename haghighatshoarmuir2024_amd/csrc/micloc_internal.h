@@ -15,6 +15,17 @@ namespace micloc {
 constexpr bool VARIANT_WS_FOUR_KSTEPS = false;    // ws_k4: beamform_ws_kernel multiplies four k-steps whatever the channel count
 constexpr bool VARIANT_STHT_VECTOR_FORM = false;  // stht_valu: stride-2 STHT kernels on the vector ALU instead of the matrix cores
 
+// ---- XCD-aware workgroup order (speed only, never correctness) -------------------------------------------------------
+// Workgroup L of a launch runs on XCD L % 8, and every XCD has its own L2.  Kernels whose NEIGHBOURING work items read the same
+// cache lines (stream groups that end in the middle of a trial: a frame row [t][0..M) is shorter than a line; time tiles that
+// share a halo) walk the items so that XCD x gets the contiguous range [x n/8, (x + 1) n/8) in ascending order; the n % 8
+// items at the end keep their place.  A bijection of [0, n).
+__device__ __forceinline__ int xcd_walk(int L, int n)
+{
+    const int per = n >> 3;
+    return L < 8 * per ? (L & 7) * per + (L >> 3) : L;
+}
+
 // ---- STHT ---------------------------------------------------------------------------------------
 constexpr int STHT_R = 8;                // consecutive output samples per lane (register window; groups of STHT_R delays)
 constexpr int STHT_TILE = 64 * STHT_R;   // outputs per wave-task

@@ -434,7 +434,7 @@ __global__ __launch_bounds__(192) void rzcc_scan_kernel(const double *__restrict
     __shared__ __attribute__((aligned(16))) double X[3][RZ_MT][RZ_ROW];
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
-    const int base = blockIdx.x * 64;
+    const int base = xcd_walk(blockIdx.x, gridDim.x) * 64;
     const int m_end = (g.P - 1) * g.Lt - g.Vt;  // tile of the last checkpoint: nothing to do beyond it
     const int nstep = m_end + 2;                // the filter wave runs one tile behind the LDS ring
     if (wave == 0) {
@@ -640,8 +640,9 @@ __global__ __launch_bounds__(448, (WANT_PRE && WANT_SPIKES) ? 2 : 4) void bandpa
     const int wave_hw = threadIdx.x >> 6;
     const int wave = LD2 ? (wave_hw == 0 ? 0 : wave_hw - 1) : wave_hw;
     const int lane = threadIdx.x & 63;
-    const int blk = blockIdx.x % nblk;
-    const int p = blockIdx.x / nblk;
+    const int vid = xcd_walk(blockIdx.x, gridDim.x);
+    const int blk = vid % nblk;
+    const int p = vid / nblk;
     const int base = blk * SW;
     const RzSpan sp_ = rz_span(g, p, (T + RZ_MT - 1) / RZ_MT);
     const int m_lo = sp_.m_lo;

@@ -237,19 +237,14 @@ __global__ __launch_bounds__(SM_THREADS, 2) void stht_mfma_kernel(const double *
     // two workgroups per CU (one multiplies while the other waits for its loads).
     double *XS = Xs, *G = Xs + (size_t)R * 16;
     const int tid = threadIdx.x;
-    // consecutive time tiles of a stream group share most of their input: keep them on one XCD (one L2) -- see above
-    int tile = blockIdx.x, grp = blockIdx.y;
-    {
-        const int ntile = gridDim.x, ngrp = gridDim.y;
-        const int L = tile + ntile * grp;
-        const int full = (ngrp >> 3) << 3;
-        if (L < full * ntile) {
-            const int j = L >> 3;
-            const int rq = j / ntile;
-            tile = j - rq * ntile;
-            grp = 8 * rq + (L & 7);
-        }
-    }
+    // XCD-aware order (xcd_walk, micloc_internal.h).  Two kinds of workgroups read the same input lines: consecutive time tiles of
+    // a stream group (the halo, half of what a tile reads) and NEIGHBOURING stream groups (16 streams end in the middle of a trial
+    // whenever 16 % M != 0).  An XCD walks a contiguous range of groups, tile by tile: both kinds of sharing meet in one L2.
+    // Dealing the groups round-robin (neighbours on different XCDs; until round 4) fetched 451 MB per launch on the sweep shape
+    // for 296 MB of input, this walk 308 MB (FETCH_SIZE, tools/dev/stht_fetch_ab.sh).
+    const int ntile = gridDim.x;
+    const int vid = xcd_walk(blockIdx.x + ntile * blockIdx.y, ntile * gridDim.y);
+    const int grp = vid / ntile, tile = vid - grp * ntile;
     const int I0 = tile * TI;
     // input parity and offset of the two output parities
     const int e0 = -klo, e1 = 1 - klo;
