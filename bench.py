@@ -55,7 +55,13 @@ def parse(argv=None):
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of each cpu_baseline leg")
     ap.add_argument("--repeats", type=int, default=5, help="the K-step timed region is run this many times; ms_per_step / value are the median")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the speech / xylo / stress child runs and the reference-MAE / per-call blocks")
-    ap.add_argument("--streams", type=int, default=3, help="HIP streams consecutive steps are pipelined over (1 = serial)")
+    ap.add_argument("--streams", type=int, default=None, help="HIP streams consecutive steps are pipelined over (1 = serial; default 3, "
+                    "4 with the scan-lane schedule)")
+    ap.add_argument("--schedule", choices=["auto", "graphs", "scan-lane"], default="auto", help="graphs: one captured hipGraph per stream, replayed "
+                    "round-robin.  scan-lane: eager launches, the serial checkpoint scans of all batches on one stream that owns --scan-lane-cus "
+                    "compute units of every XCD, everything else on streams restricted to the other units (runtime.StreamPipeline).  auto: scan-lane "
+                    "for the speech workload (long recordings: the scan is a 10 ms latency chain on 28 workgroups), graphs otherwise")
+    ap.add_argument("--scan-lane-cus", type=int, default=4, help="compute units per XCD of the scan lane")
     ap.add_argument("--xylo-lif", default="static", help="xylo: 'static' (one workgroup per trial: what the three-stream step runs best with) or "
                     "'queue' / 'queue:<workgroups per CU>' (persistent workgroups on the ticket queue: the faster launch when it runs alone)")
     ap.add_argument("--cpu-cores", type=int, default=None, help="pin every rank to this many host cores (its own slice of the allowed set) before "
@@ -70,6 +76,11 @@ def parse(argv=None):
     args = ap.parse_args(argv)
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")
+    if args.schedule == "auto":
+        args.schedule = "scan-lane" if args.config == "speech" else "graphs"
+    args.streams_given = args.streams is not None
+    if args.streams is None:
+        args.streams = 4 if args.schedule == "scan-lane" else 3
     return args
 
 
@@ -215,7 +226,7 @@ def build_workload(args, rank, device):
                 make_batch=make_batch)
 
 
-def make_step(wl, nstreams, variants=True):
+def make_step(wl, nstreams, variants=True, scan_lane=0):
     # variants: True = covariance + fp32 tails (noisy workload), None = covariance only, False = none (debugging)
     """One step = one pass of the hot path over the batch.  Consecutive steps are independent batches, so they are
     dispatched round-robin over `nstreams` HIP streams (one plan/workspace each): the latency-bound RZCC kernel of
@@ -239,7 +250,7 @@ def make_step(wl, nstreams, variants=True):
         plans.append(p)
         _, x_i, doa_i = wl["make_batch"](i)
         inputs[id(p)] = (x_i, _torch.from_numpy(doa_i).to(x.device))
-    pipe = StreamPipeline(plans)
+    pipe = StreamPipeline(plans, scan_lane=scan_lane)
 
     def body(plan, cov=False):
         xs, doas = inputs[id(plan)]
@@ -252,7 +263,7 @@ def make_step(wl, nstreams, variants=True):
         return out, mae
 
     # one HIP graph per stream (pipeline kernels + the DoA-error / MAE kernel), replayed round-robin
-    replay_direct = pipe.capture(lambda plan: body(plan, False))
+    replay_direct = pipe.capture(lambda plan: body(plan, False)) if not scan_lane else None
     small = variants and x.shape[2] * 2 <= 64
     replay_cov = pipe.capture(lambda plan: body(plan, True)) if (variants is not False and x.shape[2] * 2 <= 128) else None
     replay_f32 = pipe.capture(lambda plan: body(plan, "f32")) if small else None
@@ -290,10 +301,33 @@ def make_step(wl, nstreams, variants=True):
         _, mae = runtime.doa_error(out["argmax"], doa_list, st["doa"], groups=S, want_err=False)
         return out, mae
 
-    replay_e2e = pipe.capture(body_e2e)
+    replay_e2e = pipe.capture(body_e2e) if not scan_lane else None
+
+    # scan-lane schedule (long recordings): the same calls launched eagerly, the serial scan of every batch on the pipeline's lane
+    # (runtime.StreamPipeline.snn_pipeline); a step is a handful of millisecond-scale launches, a graph saves nothing here
+    lane_out, lane_out_e2e = [None] * len(plans), [None] * len(plans)
+
+    def e2e_before(i):
+        st = e2e_state[id(plans[i])]
+        runtime.counter_add_(st["epoch"], 1)
+        runtime.uniform(B, 77, substream=0, lo=0.0, hi=2 * np.pi, out=st["doa"], epoch=st["epoch"])
+        runtime.delay_min(st["doa"].view(B, 1), geo, out=st["shift"])
+        runtime.synth_awgn(tpl, "apply_to_template", snr_dev, seed=77, substream=0, epoch=st["epoch"], ws=st["ws"], doa=st["doa"].view(B, 1),
+                           geometry=geo, shift=st["shift"], out=st["x"])
+
+    def step_lane(cov=False, index=None):
+        if cov == "e2e":
+            return pipe.snn_pipeline(lambda i: e2e_state[id(plans[i])]["x"], before=e2e_before, index=index, out=lane_out_e2e, want_power=True,
+                                     after=lambda i, o: runtime.doa_error(o["argmax"], doa_list, e2e_state[id(plans[i])]["doa"], groups=S, want_err=False)[1])
+        if cov:
+            return replay_cov(index)
+        return pipe.snn_pipeline(lambda i: inputs[id(plans[i])][0], index=index, out=lane_out, want_power=True,
+                                 after=lambda i, o: runtime.doa_error(o["argmax"], doa_list, inputs[id(plans[i])][1], groups=S, want_err=False)[1])
 
     def step(cov=False, index=None):
         # index: replay a given stream's graph (the comparisons between variants read stream 0's batch, wl["x"])
+        if scan_lane:
+            return step_lane(cov, index)
         if cov == "e2e":
             return replay_e2e(index)
         if cov == "f32":
@@ -711,9 +745,9 @@ def other_configs_block(args):
         out["noisy_on_2_host_cores"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     # (enough steps per timed region for the three streams to drift out of step: with one step per stream they start together and
     #  finish together, which is not the steady state -- xylo 18.0 ms/step at 3 steps, 17.0 at 12)
-    for cfg, steps in (("speech", 9), ("xylo", 12), ("stress", 9)):
-        cmd = [sys.executable, os.path.abspath(__file__), "--config", cfg, "--steps", str(steps), "--warmup", "3", "--repeats", "3",
-               "--no-cpu-baseline", "--no-other-configs", "--streams", str(args.streams)]
+    for cfg, steps in (("speech", 16), ("xylo", 12), ("stress", 9)):
+        cmd = [sys.executable, os.path.abspath(__file__), "--config", cfg, "--steps", str(steps), "--warmup", "4" if cfg == "speech" else "3", "--repeats", "3",
+               "--no-cpu-baseline", "--no-other-configs"] + (["--streams", str(args.streams)] if args.streams_given else [])
         t0 = time.perf_counter()
         try:
             p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
@@ -721,6 +755,7 @@ def other_configs_block(args):
             d = json.loads(lines[-1])
             r = d["roofline"]
             out[cfg] = {"ms_per_step": d["ms_per_step"], "value": d["value"], "unit": "frames/s", "workload": d["config"]["workload"],
+                        "schedule": d["config"].get("schedule"),
                         "roofline": {k: r.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_ms")},
                         "stages_ms": r.get("stages_ms"), "steps": d["steps"], "wall_s": time.perf_counter() - t0}
             if "parity" in d:
@@ -950,7 +985,10 @@ def run(args):
         print(f"bench.py: {wl['x'].shape[0]} trials per rank need about {per_stream / 1e9:.0f} GB per stream, {free_bytes / 1e9:.0f} GB are free: "
               "use --trials or more GPUs", file=sys.stderr)
         return 2
-    step, pipe = make_step(wl, nstreams, variants=True if noisy else None)
+    # long recordings: the encoder's serial scan on a stream with compute units of its own (when the encoder is time-chunked at all)
+    scan_lane = args.scan_lane_cus if (args.schedule == "scan-lane" and nstreams > 1 and
+                                       wl["plan"].encoder_chunks(wl["x"].shape[0], wl["x"].shape[1]) > 1) else 0
+    step, pipe = make_step(wl, nstreams, variants=True if noisy else None, scan_lane=scan_lane)
     B, T, M = wl["x"].shape
     G = wl["bf_mat"].shape[1]
 
@@ -1098,7 +1136,10 @@ def run(args):
             "config": {"workload": f"{names[args.config]}: {M}-mic, {wl['fs'] // 1000} kHz, T={T}, {B} trials/GPU/step, "
                                    f"{G}-DoA grid, bipolar RZCC, bf_mat designed on device from the 1 s chirp",
                        "trials_per_gpu": B, "frames_per_trial": T, "num_mic": M, "num_doa": G, "mic_samples_per_s": value * M,
-                       "parallelism": f"trial-sharded x{group_size}", "hip_streams": nstreams, "hip_graphs": True,
+                       "parallelism": f"trial-sharded x{group_size}", "hip_streams": nstreams, "hip_graphs": not scan_lane,
+                       "schedule": (f"scan-lane: eager launches on {nstreams} streams restricted to {32 - scan_lane} compute units per XCD, the "
+                                    f"serial checkpoint scans of all batches on one stream that owns the other {scan_lane}") if scan_lane
+                                   else "one captured hipGraph per stream, replayed round-robin",
                        "design_from_template_seconds": wl["design_seconds"],
                        "design_note": "bf_mat from the 1 s chirp for all G DoAs, entirely on the device (reference: 24.8 s for 449 DoAs on 8 vCPUs, SURVEY 6)"},
             "mae_deg_per_snr": [float(v) for v in (mae * 180 / np.pi).cpu().numpy()],

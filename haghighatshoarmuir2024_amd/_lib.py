@@ -64,6 +64,8 @@ SYMBOLS = {
     "micloc_plan_generation": (c_int, [c_void_p]),
     "micloc_plan_set_encoder_chunk": (c_int, [c_void_p, c_int]),
     "micloc_plan_encoder_chunks": (c_int, [c_void_p, c_int, c_int]),
+    "micloc_stream_create_cu_range": (c_int, [c_int, c_int, c_int, ctypes.POINTER(c_void_p)]),
+    "micloc_stream_destroy": (c_int, [c_void_p]),
     "micloc_padded_T": (c_int, [c_int]),
     "micloc_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),
     "micloc_stht_f64": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),

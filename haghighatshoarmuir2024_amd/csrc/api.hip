@@ -337,6 +337,41 @@ int micloc_plan_set_bf_mat_c128(micloc_plan *p, const double *Wre, const double 
 
 int micloc_plan_generation(const micloc_plan *p) { return p ? p->generation : -1; }
 
+// ---- streams restricted to a part of every XCD ------------------------------------------------------------------------
+int micloc_stream_create_cu_range(int device, int cu_lo, int cu_hi, void **stream)
+{
+    if (!stream || device < 0) return MICLOC_ERR_INVALID;
+    *stream = nullptr;
+    DeviceGuard guard(device);
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return MICLOC_ERR_INVALID;
+    // gfx950: 8 XCDs; bit i of the mask is compute unit i / 8 of XCD i % 8 (measured: tools/dev/cu_mask_probe.hip), and an XCD
+    // whose bits are all clear is NOT excluded -- it runs the stream on all of its compute units -- so a range is given per XCD
+    constexpr int NXCD = 8;
+    const int ncu = prop.multiProcessorCount;
+    if (ncu <= 0 || ncu % NXCD) return MICLOC_ERR_INVALID;
+    const int per = ncu / NXCD;
+    if (cu_lo < 0 || cu_hi > per || cu_lo >= cu_hi) return MICLOC_ERR_INVALID;
+    std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
+    for (int c = cu_lo; c < cu_hi; ++c)
+        for (int x = 0; x < NXCD; ++x) {
+            const int bit = c * NXCD + x;
+            mask[bit / 32] |= 1u << (bit % 32);
+        }
+    hipStream_t st = nullptr;
+    HIP_TRY(hipExtStreamCreateWithCUMask(&st, (uint32_t)mask.size(), mask.data()));
+    *stream = st;
+    return MICLOC_OK;
+}
+
+int micloc_stream_destroy(void *stream)
+{
+    if (!stream) return MICLOC_ERR_INVALID;
+    HIP_TRY(hipStreamDestroy((hipStream_t)stream));
+    return MICLOC_OK;
+}
+
 int micloc_plan_set_encoder_chunk(micloc_plan *p, int chunk_frames)
 {
     if (!p) return MICLOC_ERR_INVALID;
@@ -434,10 +469,13 @@ int micloc_snn_pipeline_stages_f64(const micloc_plan *p, const double *x, int B,
 {
     if (!p || !x || bad_batch(B) || T < 1 || (!spikes && !y && !power && !argmax)) return MICLOC_ERR_INVALID;
     DeviceGuard guard(p->device);  // launches and stream belong to the plan's device, whatever the caller's current one
-    if (stages <= 0 || (stages & ~MICLOC_STAGE_ALL)) return MICLOC_ERR_INVALID;
+    if (stages <= 0 || (stages & ~(MICLOC_STAGE_ALL | MICLOC_STAGE_ENCODE_SCAN | MICLOC_STAGE_ENCODE_REST))) return MICLOC_ERR_INVALID;
     const bool want_bf = y || power || argmax;
     if (want_bf && (!p->d_ntab || !p->d_W)) return MICLOC_ERR_NOT_SET;
     if (want_bf && p->W_is_complex) return MICLOC_ERR_SHAPE;
+    const int phases = (stages & MICLOC_STAGE_ENCODE) ? RZ_PHASE_ALL
+                                                      : ((stages & MICLOC_STAGE_ENCODE_SCAN) ? RZ_PHASE_SCAN : 0) |
+                                                            ((stages & MICLOC_STAGE_ENCODE_REST) ? RZ_PHASE_ENCODE : 0);
     const WsLayout w = ws_layout(p, B, T);
     if (bad_ws(ws, ws_bytes, w.total)) return MICLOC_ERR_WORKSPACE;
     unsigned char *base = reinterpret_cast<unsigned char *>(ws);
@@ -447,9 +485,9 @@ int micloc_snn_pipeline_stages_f64(const micloc_plan *p, const double *x, int B,
     hipStream_t st = (hipStream_t)stream;
     // the in-phase channels are the rolled input frames: the band-pass kernel reads them from x directly
     if (stages & MICLOC_STAGE_STHT) HIP_TRY(launch_stht(p->taps, x, h, B, T, p->M, Ts, st, false));
-    if (stages & MICLOC_STAGE_ENCODE)
+    if (phases)
         HIP_TRY(launch_bandpass_rzcc(p->iir, h, B * p->C, p->C, T, Ts, p->robust_width, p->bipolar, nullptr, spk,
-                                     base + w.scratch, st, x, p->M, p->taps.shift, p->chunk_frames));
+                                     base + w.scratch, st, x, p->M, p->taps.shift, p->chunk_frames, phases));
     if (want_bf && (stages & MICLOC_STAGE_BEAMFORM)) {
         const int Gp = 16 * p->W.GT;
         const bool want_power = power || argmax;

@@ -56,10 +56,13 @@ struct IirCoef {
 // chunk_frames: 0 = automatic, < 0 = never chunk, > 0 = owned frames per chunk.
 size_t rzcc_scratch_bytes(int nlanes, int T, int robust_width, int chunk_frames);
 int rzcc_chunks(int nlanes, int T, int robust_width, int chunk_frames);  // chunks per stream the launcher will use
+// phases: the serial scan of a chunked launch (RZ_PHASE_SCAN: checkpoints into the scratch; nothing when the launch is not chunked)
+// and everything else (RZ_PHASE_ENCODE) may be enqueued by separate calls, scan first, with the same arguments
+constexpr int RZ_PHASE_SCAN = 1, RZ_PHASE_ENCODE = 2, RZ_PHASE_ALL = 3;
 hipError_t launch_bandpass_rzcc(const IirCoef &coef, const double *h, int nlanes, int C, int T, int Ts,
                                 int robust_width, int bipolar, double *pre, int8_t *spikes, void *scratch,
                                 hipStream_t stream, const double *xin = nullptr, int M = 0, int shift = 0,
-                                int chunk_frames = 0);
+                                int chunk_frames = 0, int phases = RZ_PHASE_ALL);
 // streaming: one tile per launch, exact state hand-off (rzcc.hip "streaming")
 size_t rzcc_stream_state_bytes(int nlanes);
 hipError_t launch_stream_encode(const IirCoef &coef, const double *h, int nlanes, int C, int T, int Ts, int robust_width,

@@ -1397,16 +1397,17 @@ static void launch_rz_spikes(const IirCoef &coef, const double *h, int nlanes, i
 template <int N>
 static void launch_rz(const IirCoef &coef, const double *h, int nlanes, int C, int T, int Ts, int w, int bipolar,
                       double *pre, int8_t *spikes, unsigned char *scratch, const RzGeom &g, const RzScratch &sc,
-                      const double *xin, int M, int shift, hipStream_t stream)
+                      const double *xin, int M, int shift, hipStream_t stream, int phases)
 {
     const int nblk = (nlanes + 63) / 64;
     int *flag_count = scratch ? reinterpret_cast<int *>(scratch + sc.count) : nullptr;
     int *flag_list = scratch ? reinterpret_cast<int *>(scratch + sc.list) : nullptr;
     double *ckd = scratch ? reinterpret_cast<double *>(scratch + sc.ckd) : nullptr;
     int *cki = scratch ? reinterpret_cast<int *>(scratch + sc.cki) : nullptr;
-    if (g.P > 1)
+    if (g.P > 1 && (phases & RZ_PHASE_SCAN))
         hipLaunchKernelGGL((rzcc_scan_kernel<N>), dim3(nblk), dim3(192), 0, stream, h, coef, nlanes, C, T, Ts, xin, M, shift,
                            g, ckd, cki);
+    if (!(phases & RZ_PHASE_ENCODE)) return;
     dim3 grid(nblk * g.P), block(spikes ? 320 : 128);
     if (pre && spikes)
         hipLaunchKernelGGL((bandpass_rzcc_fast_kernel<N, true, true>), grid, block, 0, stream, h, pre, spikes,
@@ -1425,22 +1426,23 @@ static void launch_rz(const IirCoef &coef, const double *h, int nlanes, int C, i
 
 hipError_t launch_bandpass_rzcc(const IirCoef &coef, const double *h, int nlanes, int C, int T, int Ts,
                                 int robust_width, int bipolar, double *pre, int8_t *spikes, void *scratch,
-                                hipStream_t stream, const double *xin, int M, int shift, int chunk_frames)
+                                hipStream_t stream, const double *xin, int M, int shift, int chunk_frames, int phases)
 {
     if (!pre && !spikes) return hipErrorInvalidValue;
+    if (!(phases & (RZ_PHASE_SCAN | RZ_PHASE_ENCODE))) return hipErrorInvalidValue;
     if ((unsigned long long)T * (unsigned long long)(M > 0 ? M : 1) > 0xffffffffull) return hipErrorInvalidValue;  // (the loaders index a trial with 32 bits)
     // launches that also store the filtered signal walk each stream once (the loader stores tile by tile)
     const RzGeom g = rz_geom(nlanes, T, robust_width, (pre || !spikes) ? -1 : chunk_frames);
     const RzScratch sc = rz_scratch(nlanes, T, g.P);
     unsigned char *base = reinterpret_cast<unsigned char *>(scratch);
-    if (spikes) {
+    if (spikes && (phases & RZ_PHASE_ENCODE)) {
         hipError_t e = zero_fill(spikes, (size_t)nlanes * T, stream, base + sc.count);  // (+ the 256-byte counter block: one launch)
         if (e != hipSuccess) return e;
     }
 #define RZ_CASE(NN)                                                                                                 \
     case NN:                                                                                                        \
         launch_rz<NN>(coef, h, nlanes, C, T, Ts, robust_width, bipolar, pre, spikes, spikes ? base : nullptr, g, sc, \
-                      xin, M, shift, stream);                                                                       \
+                      xin, M, shift, stream, phases);                                                               \
         break;
     switch (coef.n) {
         RZ_CASE(1)

@@ -184,8 +184,9 @@ class Plan:
     # ---- pipelines -----------------------------------------------------------------------------------
     def snn_pipeline(self, x, want_spikes=False, want_y=False, want_power=True, stages=7, out=None):
         """x: device tensor [B, T, M]. Returns dict of device tensors (spikes int8, y, power, argmax).
-        `stages` (MICLOC_STAGE_* bits: 1 STHT, 2 band-pass + RZCC, 4 LIF + beamforming + power) launches a part of the
-        pipeline; the parts of one batch share this plan's workspace and, via `out`, the output tensors."""
+        `stages` (MICLOC_STAGE_* bits: 1 STHT, 2 band-pass + RZCC, 4 LIF + beamforming + power; 8 / 16: only the serial scan of a
+        chunked band-pass + RZCC stage / the stage without it) launches a part of the pipeline; the parts of one batch share this
+        plan's workspace and, via `out`, the output tensors."""
         torch = _torch()
         B, T, M = x.shape
         if M != self.num_mic:
@@ -629,6 +630,35 @@ def doa_error(argmax, doa_list, doa_true, groups=1, want_err=True):
     return err, mae
 
 
+STAGE_STHT, STAGE_ENCODE, STAGE_BEAMFORM, STAGE_ENCODE_SCAN, STAGE_ENCODE_REST = 1, 2, 4, 8, 16  # include/micloc_hip.h MICLOC_STAGE_*
+
+
+class CuRangeStream:
+    """A HIP stream restricted to compute units [cu_lo, cu_hi) of every XCD (micloc_stream_create_cu_range), as a torch stream
+    (`.stream`); destroyed with the object."""
+
+    def __init__(self, device, cu_lo, cu_hi):
+        torch = _torch()
+        import ctypes
+
+        self.lib = _lib.load()
+        dev = require_gpu(device)
+        h = ctypes.c_void_p()
+        _lib.check(self.lib.micloc_stream_create_cu_range(dev.index, int(cu_lo), int(cu_hi), ctypes.byref(h)), "stream_create_cu_range")
+        self.handle = h
+        self.stream = torch.cuda.ExternalStream(h.value, device=dev)
+
+    def __del__(self):
+        h = getattr(self, "handle", None)
+        if h is not None and h.value:
+            try:
+                self.stream.synchronize()
+                self.lib.micloc_stream_destroy(h)
+            except Exception:
+                pass
+            self.handle = None
+
+
 class StreamPipeline:
     """Round-robin dispatch of consecutive batches over several HIP streams, one Plan (= workspace) per stream.
 
@@ -636,14 +666,75 @@ class StreamPipeline:
     most of the chip idle; running batch i+1's STHT / batch i-1's beamformer next to it on other streams fills
     the machine.  Results are device tensors owned by the stream that produced them: call synchronize() (or make
     the consumer stream wait) before reading them elsewhere.
+
+    scan_lane = k > 0 (long recordings, whose encoder is time-chunked: Plan.encoder_chunks(B, T) > 1): the serial checkpoint scans
+    of ALL plans go through one extra stream that owns compute units [0, k) of every XCD, the plans' own streams get the other
+    32 - k (micloc_stream_create_cu_range).  A scan is a chain of dependent fp64 operations on few workgroups (speech sweep: 28): on
+    a SIMD that also issues another kernel's matrix instructions it runs at half its pace or less, and streams left to themselves
+    fall into step -- all scans together, the chip idle beside them.  With the lane the scans of consecutive batches run back to
+    back at full pace and the throughput stages of the other batches fill the rest of the chip (snn_pipeline below; eager launches
+    with event dependencies -- a captured graph has no streams).  Speech sweep, 125 trials x 332 157 frames per step: 15.6 -> 14.1
+    ms per step with four plans (tools/dev/speech_lane.py).
     """
 
-    def __init__(self, plans):
+    def __init__(self, plans, scan_lane=0):
         torch = _torch()
         self.plans = list(plans)
         self.device = self.plans[0].device
-        self.streams = [torch.cuda.Stream(device=self.device) for _ in self.plans]
+        self.scan_lane = int(scan_lane)
+        if self.scan_lane > 0:
+            cus = torch.cuda.get_device_properties(self.device).multi_processor_count // 8
+            if not 0 < self.scan_lane < cus:
+                raise ValueError(f"scan_lane must leave compute units to both sides: 1 .. {cus - 1} per XCD")
+            self._masked = [CuRangeStream(self.device, 0, self.scan_lane)] + [CuRangeStream(self.device, self.scan_lane, cus) for _ in self.plans]
+            self.lane = self._masked[0].stream
+            self.streams = [m.stream for m in self._masked[1:]]
+            self._ev = [(torch.cuda.Event(), torch.cuda.Event()) for _ in self.plans]
+        else:
+            self.lane = None
+            self.streams = [torch.cuda.Stream(device=self.device) for _ in self.plans]
         self._next = 0
+
+    def snn_pipeline(self, x_of, before=None, after=None, index=None, **kw):
+        """One batch through plan i's snn_pipeline on stream i (round-robin, or `index`), launched eagerly: x_of(i) is the input
+        tensor, before(i) / after(i, out) run on the same stream in front of / behind it (synthesis; DoA error).  With a scan lane the
+        encoder's serial scan is enqueued on the lane between two events; without one this is submit().  Returns (out, after's
+        result); keyword arguments go to Plan.snn_pipeline (`out` may be a list with one entry per plan)."""
+        torch = _torch()
+        if index is None:
+            i = self._next % len(self.plans)
+            self._next += 1
+        else:
+            i = int(index) % len(self.plans)
+        plan, s = self.plans[i], self.streams[i]
+        outs = kw.pop("out", None)
+        out = outs[i] if isinstance(outs, list) else outs
+        cur = torch.cuda.current_stream(self.device)
+        # hipExtStreamCreateWithCUMask makes BLOCKING streams: the legacy default stream already orders them behind its earlier work,
+        # and an event recorded on it would in turn wait for every one of them -- the batches in flight would run one after the other
+        if self.lane is None or cur != torch.cuda.default_stream(self.device):
+            s.wait_stream(cur)
+        with torch.cuda.stream(s):
+            if before is not None:
+                before(i)
+            x = x_of(i)
+            B, T, _ = x.shape
+            if self.lane is None or plan.encoder_chunks(B, T) <= 1:
+                out = plan.snn_pipeline(x, out=out, **kw)
+            else:
+                ev_a, ev_b = self._ev[i]
+                out = plan.snn_pipeline(x, out=out, stages=STAGE_STHT, **kw)
+                ev_a.record(s)
+                self.lane.wait_event(ev_a)
+                with torch.cuda.stream(self.lane):
+                    plan.snn_pipeline(x, out=out, stages=STAGE_ENCODE_SCAN, **kw)
+                    ev_b.record(self.lane)
+                s.wait_event(ev_b)
+                plan.snn_pipeline(x, out=out, stages=STAGE_ENCODE_REST | STAGE_BEAMFORM, **kw)
+            if isinstance(outs, list):
+                outs[i] = out
+            res = after(i, out) if after is not None else None
+        return out, res
 
     def submit(self, fn):
         """Run fn(plan) on the next stream; returns fn's result."""

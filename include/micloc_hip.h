@@ -98,6 +98,16 @@ int micloc_plan_generation(const micloc_plan *plan);
 int micloc_plan_set_encoder_chunk(micloc_plan *plan, int chunk_frames);
 int micloc_plan_encoder_chunks(const micloc_plan *plan, int B, int T);
 
+/* A HIP stream whose kernels run only on compute units [cu_lo, cu_hi) of EVERY XCD of `device` (MI355X: 8 XCDs of 32 compute
+ * units; hipExtStreamCreateWithCUMask with the mask layout of gfx950).  For callers that keep several batches in flight: the serial
+ * scan of a chunked encoder (MICLOC_STAGE_ENCODE_SCAN below) is a latency chain of few workgroups that runs at a fraction of its
+ * pace when its SIMD also issues another kernel's matrix instructions; on a stream of its own with e.g. [0, 4), beside work streams
+ * restricted to [4, 32), consecutive batches' scans run one after the other at full pace while the other stages overlap them
+ * (runtime.StreamPipeline(scan_lane=...)).  Scheduling only: results never depend on where a kernel runs.  The reference has no
+ * counterpart (one NumPy process per trial, target_snn_localization.py:447-467). */
+int micloc_stream_create_cu_range(int device, int cu_lo, int cu_hi, void **stream);
+int micloc_stream_destroy(void *stream);
+
 /* padded time stride of planar buffers (multiple of 8 samples) */
 int micloc_padded_T(int T);
 /* bytes of scratch needed by any stage / pipeline call with this (B, T) */
@@ -140,6 +150,13 @@ int micloc_snn_pipeline_f64(const micloc_plan *plan, const double *x, int B, int
 #define MICLOC_STAGE_ENCODE 2   /* snn_beamformer.py:330-338 (band-pass, re/im stack, RZCC)      */
 #define MICLOC_STAGE_BEAMFORM 4 /* snn_beamformer.py:342-368 (LIF, beamforming) + power/arg-max  */
 #define MICLOC_STAGE_ALL 7
+/* MICLOC_STAGE_ENCODE in two parts.  Long recordings are encoded in time chunks that restart from checkpoints a serial scan of
+ * every stream stores first (micloc_plan_set_encoder_chunk): few workgroups, one dependent chain each -- latency, not throughput,
+ * and a chain that shares its SIMD with another kernel's waves runs at a fraction of its pace.  A caller with several batches in
+ * flight can give the scans a stream (and compute units) of their own: _SCAN enqueues only the scan (nothing when the launch is not
+ * chunked), _REST everything else of the stage; same workspace, scan first.  MICLOC_STAGE_ENCODE == both. */
+#define MICLOC_STAGE_ENCODE_SCAN 8
+#define MICLOC_STAGE_ENCODE_REST 16
 int micloc_snn_pipeline_stages_f64(const micloc_plan *plan, const double *x, int B, int T, int8_t *spikes, double *y,
                                    double *power, int32_t *argmax, void *ws, size_t ws_bytes, void *stream, int stages);
 /* Beamformer.apply_to_signal (beamformer.py:260-292) + power/argmax for B trials. */

@@ -139,3 +139,73 @@ def test_automatic_choice(cfg2, torch):
     assert p.encoder_chunks(1100, 4799) == 1
     assert p.encoder_chunks(125, 332157) > 32
     assert p.encoder_chunks(2, 100) == 1
+
+
+def test_scan_and_rest_in_two_calls(cfg2, torch):
+    """MICLOC_STAGE_ENCODE_SCAN + MICLOC_STAGE_ENCODE_REST (two calls, scan first) == MICLOC_STAGE_ENCODE; the scan part of an
+    un-chunked launch enqueues nothing."""
+    from haghighatshoarmuir2024_amd import runtime
+
+    rng = np.random.RandomState(21)
+    x = rng.randn(6, 4799, 7)
+    p = _plan(cfg2)
+    xd = p.to_device(x)
+    for chunk in (-1, 256, 1000):
+        p.set_encoder_chunk(chunk)
+        ref = p.snn_pipeline(xd, want_spikes=True, want_power=True)
+        out = p.snn_pipeline(xd, want_spikes=True, want_power=True, stages=runtime.STAGE_STHT)
+        out["spikes"].fill_(7)
+        p.snn_pipeline(xd, stages=runtime.STAGE_ENCODE_SCAN, out=out)
+        assert bool((out["spikes"] == 7).all())  # the scan writes checkpoints into the workspace, nothing else
+        p.snn_pipeline(xd, stages=runtime.STAGE_ENCODE_REST | runtime.STAGE_BEAMFORM, out=out)
+        np.testing.assert_array_equal(out["spikes"].cpu().numpy(), ref["spikes"].cpu().numpy(), err_msg=f"chunk={chunk}")
+        np.testing.assert_array_equal(out["power"].cpu().numpy(), ref["power"].cpu().numpy())
+        np.testing.assert_array_equal(out["argmax"].cpu().numpy(), ref["argmax"].cpu().numpy())
+    with pytest.raises(Exception):
+        p.snn_pipeline(xd, stages=32)
+
+
+def test_stream_pipeline_scan_lane(cfg2, torch):
+    """StreamPipeline(scan_lane=4): consecutive batches on streams restricted to compute units [4, 32) of every XCD, their serial scans
+    on one stream that owns [0, 4) -- scheduling only: spikes, power and arg-max equal the plain call, batch by batch, also when the
+    encoder is not chunked (the lane is then not used) and with before / after hooks."""
+    from haghighatshoarmuir2024_amd import runtime
+
+    rng = np.random.RandomState(22)
+    xs = [rng.randn(5, 4799, 7) for _ in range(3)]
+    plans = [_plan(cfg2) for _ in range(3)]
+    xd = [p.to_device(x) for p, x in zip(plans, xs)]
+    for chunk in (400, -1):
+        for p in plans:
+            p.set_encoder_chunk(chunk)
+        refs = [p.snn_pipeline(x, want_spikes=True, want_power=True) for p, x in zip(plans, xd)]
+        ref_np = [{k: r[k].cpu().numpy() for k in ("spikes", "power", "argmax")} for r in refs]
+        pipe = runtime.StreamPipeline(plans, scan_lane=4)
+        assert pipe.lane is not None and len(pipe.streams) == 3
+        outs = [None] * 3
+        seen = []
+        for k in range(7):  # several rounds over the three plans: events and output tensors are reused
+            out, res = pipe.snn_pipeline(lambda i: xd[i], before=lambda i: seen.append(i), after=lambda i, o: o["argmax"].clone(), out=outs,
+                                         want_spikes=True, want_power=True)
+            assert out is outs[k % 3]
+        pipe.synchronize()
+        assert seen == [0, 1, 2, 0, 1, 2, 0]
+        for i in range(3):
+            for key in ("spikes", "power", "argmax"):
+                np.testing.assert_array_equal(outs[i][key].cpu().numpy(), ref_np[i][key], err_msg=f"chunk={chunk} plan={i} {key}")
+        del pipe
+    with pytest.raises(ValueError):
+        runtime.StreamPipeline(plans, scan_lane=32)
+
+
+def test_cu_range_stream_arguments(torch):
+    from haghighatshoarmuir2024_amd import _lib, runtime
+
+    s = runtime.CuRangeStream(None, 0, 4)
+    with torch.cuda.stream(s.stream):
+        y = torch.arange(1000, device="cuda").sum()
+    s.stream.synchronize()
+    assert int(y.item()) == 499500
+    for lo, hi in ((4, 4), (-1, 3), (0, 33), (5, 2)):
+        with pytest.raises(_lib.MiclocError):
+            runtime.CuRangeStream(None, lo, hi)

@@ -71,9 +71,10 @@ def run(front, back, nplans, label):
 plain = [torch.cuda.Stream(device=dev) for _ in range(2)]
 run(plain[0], plain[1], 2, "two unmasked streams (front end | LIF), 2 plans")
 run(plain[0], plain[1], 3, "two unmasked streams (front end | LIF), 3 plans")
-for lif_cus in (96, 128, 144, 160, 176, 192):
-    order = list(range(NCU))
-    # interleaved choice: every (NCU / lif_cus)-th bit, so that both partitions span the mask's whole bit range (all shader engines / XCDs)
-    sel = set(int(round(j * NCU / lif_cus)) for j in range(lif_cus))
-    rest = [c for c in order if c not in sel]
-    run(masked_stream(rest), masked_stream(sorted(sel)), 2, f"masked: LIF on {len(sel)} CUs, front end on {len(rest)}")
+# compute units [0, k) of every XCD for the LIF, [k, 32) for the front end (mask layout of gfx950: micloc_stream_create_cu_range)
+keep = []
+for k in (int(a) for a in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["20"])):
+    back, front = runtime.CuRangeStream(dev, 0, k), runtime.CuRangeStream(dev, k, 32)
+    keep += [back, front]
+    run(front.stream, back.stream, 2, f"masked: LIF on {k} CUs per XCD, front end on {32 - k}, 2 plans")
+    run(front.stream, back.stream, 3, f"masked: LIF on {k} CUs per XCD, front end on {32 - k}, 3 plans")

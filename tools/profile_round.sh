@@ -12,7 +12,8 @@ if [ $PART != pmc ]; then
 python3 bench.py --steps 20 --warmup 5 > $OUT/bench_n1.json 2> $OUT/bench_n1.err   # the driver's command: all blocks (other configs as child runs)
 python3 bench.py --steps 40 --warmup 4 --streams 1 --no-cpu-baseline --no-other-configs > $OUT/bench_n1_streams1.json 2> $OUT/bench_n1_streams1.err
 python3 bench.py --steps 40 --warmup 4 --grid 449 --no-cpu-baseline --no-other-configs > $OUT/bench_n1_grid449.json 2> $OUT/bench_n1_grid449.err
-python3 bench.py --config speech --steps 9 --warmup 3 > $OUT/bench_n1_speech.json 2> $OUT/bench_n1_speech.err
+python3 bench.py --config speech --steps 16 --warmup 4 > $OUT/bench_n1_speech.json 2> $OUT/bench_n1_speech.err   # (scan-lane schedule, four batches in flight)
+python3 bench.py --config speech --steps 16 --warmup 4 --schedule graphs --no-cpu-baseline > $OUT/bench_n1_speech_graphs.json 2> $OUT/bench_n1_speech_graphs.err
 python3 bench.py --config stress --steps 9 --warmup 3 > $OUT/bench_n1_stress.json 2> $OUT/bench_n1_stress.err
 python3 bench.py --config xylo --steps 12 --warmup 3 > $OUT/bench_n1_xylo.json 2> $OUT/bench_n1_xylo.err
 # per-kernel times: serial steps so that every launch is timed alone
