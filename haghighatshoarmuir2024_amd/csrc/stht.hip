@@ -218,6 +218,7 @@ static int stht_rowstride(const SthtTaps &tp)
 // (stream, i) sit in the same lane: y[2i], y[2i + 1] leave as one 16-byte store, 256 contiguous bytes per stream row.
 constexpr int SM_WAVES = 8;
 constexpr int SM_THREADS = 64 * SM_WAVES;
+constexpr int SM_BAND = 8;  // neighbouring stream groups an XCD walks together when the recording is long (see the kernel)
 
 // NKT: the number of k-steps when it is known at compile time (the 480-tap kernel of the paper: 64), else 0.  With a constant
 // trip count the multiply loop unrolls completely and every s_waitcnt counts exactly the reads it needs; inside a loop the
@@ -242,9 +243,17 @@ __global__ __launch_bounds__(SM_THREADS, 2) void stht_mfma_kernel(const double *
     // whenever 16 % M != 0).  An XCD walks a contiguous range of groups, tile by tile: both kinds of sharing meet in one L2.
     // Dealing the groups round-robin (neighbours on different XCDs; until round 4) fetched 451 MB per launch on the sweep shape
     // for 296 MB of input, this walk 308 MB (FETCH_SIZE, tools/dev/stht_fetch_ab.sh).
-    const int ntile = gridDim.x;
-    const int vid = xcd_walk(blockIdx.x + ntile * blockIdx.y, ntile * gridDim.y);
-    const int grp = vid / ntile, tile = vid - grp * ntile;
+    // Inside its range an XCD holds 64 workgroups at a time.  Group by group that is 64 / ntile neighbouring groups: fine for short
+    // recordings (T = 4799: ten tiles, six groups), but a 94-tile recording has ONE group resident and its neighbours' shared lines are
+    // long gone when they come (T = 48 000: 5.1 GB fetched for 3.0 GB of input).  Long recordings are therefore walked in bands of
+    // SM_BAND groups, tile by tile across the band -- ~8 consecutive tiles of 8 neighbouring groups resident: 3.4 GB.  (Measured band
+    // widths 1 / 2 / 4 / 8 / 16: 5.1 / 4.0 / 3.6 / 3.4 / 3.9 GB at T = 48 000, 315 / 319 / 330 / 336 / 377 MB at T = 4799.)
+    const int ntile = gridDim.x, ngrp = gridDim.y;
+    const int vid = xcd_walk(blockIdx.x + ntile * blockIdx.y, ntile * ngrp);
+    const int bw = ntile <= 16 ? 1 : SM_BAND;
+    const int band = vid / (bw * ntile), rem = vid - band * (bw * ntile);
+    const int inband = ngrp - band * bw < bw ? ngrp - band * bw : bw;  // (the last band may be narrower)
+    const int tile = rem / inband, grp = band * bw + (rem - tile * inband);
     const int I0 = tile * TI;
     // input parity and offset of the two output parities
     const int e0 = -klo, e1 = 1 - klo;

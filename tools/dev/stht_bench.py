@@ -1,4 +1,5 @@
-"""Time the STHT stage alone (fused-pipeline form: quadrature rows only) on the sweep's batch; MICLOC_DEV_LIB selects a variant build."""
+"""Time the STHT stage alone (fused-pipeline form: quadrature rows only) on the sweep's batch (STHT_T: another recording length);
+MICLOC_DEV_LIB selects a variant build."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -9,7 +10,7 @@ if os.environ.get("MICLOC_DEV_LIB"):
 from haghighatshoarmuir2024_amd import runtime
 from oracle import oracle as O
 
-fs, M, B, T = 48000, 7, 1100, 4799
+fs, M, B, T = 48000, 7, 1100, int(os.environ.get("STHT_T", 4799))
 ker = O.stht_kernel(fs, 10e-3)
 b, a = O.bandpass(fs, [1000.0, 2000.0])
 p = runtime.Plan(M, ker, b, a, O.robust_width(fs, 2000.0), True)
@@ -19,7 +20,7 @@ def run():
 for _ in range(3): run()
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-N = 50
+N = 50 if T < 10000 else 10
 e0.record()
 for _ in range(N): run()
 e1.record(); torch.cuda.synchronize()
