@@ -75,3 +75,19 @@ print("ok")
 """ % os.path.dirname(BENCH)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+
+def test_schedule_defaults():
+    """--schedule auto: the scan-lane schedule (four batches in flight) for the speech workload only; an explicit --streams is kept and
+    handed to the child runs, a defaulted one is not."""
+    sys.path.insert(0, os.path.dirname(BENCH))
+    import bench
+
+    a = bench.parse([])
+    assert (a.schedule, a.streams, a.streams_given) == ("graphs", 3, False)
+    a = bench.parse(["--config", "speech"])
+    assert (a.schedule, a.streams, a.scan_lane_cus) == ("scan-lane", 4, 4)
+    a = bench.parse(["--config", "speech", "--schedule", "graphs"])
+    assert (a.schedule, a.streams) == ("graphs", 3)
+    a = bench.parse(["--config", "stress", "--schedule", "scan-lane", "--streams", "5", "--scan-lane-cus", "6"])
+    assert (a.schedule, a.streams, a.streams_given, a.scan_lane_cus) == ("scan-lane", 5, True, 6)
