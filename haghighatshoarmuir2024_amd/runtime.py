@@ -635,11 +635,13 @@ STAGE_STHT, STAGE_ENCODE, STAGE_BEAMFORM, STAGE_ENCODE_SCAN, STAGE_ENCODE_REST =
 
 class CuRangeStream:
     """A HIP stream restricted to compute units [cu_lo, cu_hi) of every XCD (micloc_stream_create_cu_range), as a torch stream
-    (`.stream`); destroyed with the object."""
+    (`.stream`).  Take them from cu_range_streams(): a masked stream holds a hardware queue for as long as it exists (a process that
+    keeps creating them slows down launch by launch), and torch's caching allocator remembers the stream of every block allocated
+    under it -- destroying one while such a block is alive ends in a crash at the block's release.  Streams of the pool therefore
+    live as long as the process; close() is for a caller that owns everything allocated under the stream."""
 
     def __init__(self, device, cu_lo, cu_hi):
         torch = _torch()
-        import ctypes
 
         self.lib = _lib.load()
         dev = require_gpu(device)
@@ -648,15 +650,25 @@ class CuRangeStream:
         self.handle = h
         self.stream = torch.cuda.ExternalStream(h.value, device=dev)
 
-    def __del__(self):
+    def close(self):
         h = getattr(self, "handle", None)
         if h is not None and h.value:
-            try:
-                self.stream.synchronize()
-                self.lib.micloc_stream_destroy(h)
-            except Exception:
-                pass
-            self.handle = None
+            self.stream.synchronize()
+            _lib.check(self.lib.micloc_stream_destroy(h), "stream_destroy")
+        self.handle = None
+
+
+_cu_range_pool = {}
+
+
+def cu_range_streams(device, cu_lo, cu_hi, n=1):
+    """The first n streams of the process-wide pool of streams restricted to compute units [cu_lo, cu_hi) of every XCD of `device`
+    (created on demand, never destroyed: see CuRangeStream).  Pipelines that are alive at the same time share them."""
+    dev = require_gpu(device)
+    pool = _cu_range_pool.setdefault((dev.index, int(cu_lo), int(cu_hi)), [])
+    while len(pool) < n:
+        pool.append(CuRangeStream(dev, cu_lo, cu_hi))
+    return [m.stream for m in pool[:n]]
 
 
 class StreamPipeline:
@@ -669,7 +681,7 @@ class StreamPipeline:
 
     scan_lane = k > 0 (long recordings, whose encoder is time-chunked: Plan.encoder_chunks(B, T) > 1): the serial checkpoint scans
     of ALL plans go through one extra stream that owns compute units [0, k) of every XCD, the plans' own streams get the other
-    32 - k (micloc_stream_create_cu_range).  A scan is a chain of dependent fp64 operations on few workgroups (speech sweep: 28): on
+    32 - k (cu_range_streams: a process-wide pool).  A scan is a chain of dependent fp64 operations on few workgroups (speech sweep: 28): on
     a SIMD that also issues another kernel's matrix instructions it runs at half its pace or less, and streams left to themselves
     fall into step -- all scans together, the chip idle beside them.  With the lane the scans of consecutive batches run back to
     back at full pace and the throughput stages of the other batches fill the rest of the chip (snn_pipeline below; eager launches
@@ -686,9 +698,8 @@ class StreamPipeline:
             cus = torch.cuda.get_device_properties(self.device).multi_processor_count // 8
             if not 0 < self.scan_lane < cus:
                 raise ValueError(f"scan_lane must leave compute units to both sides: 1 .. {cus - 1} per XCD")
-            self._masked = [CuRangeStream(self.device, 0, self.scan_lane)] + [CuRangeStream(self.device, self.scan_lane, cus) for _ in self.plans]
-            self.lane = self._masked[0].stream
-            self.streams = [m.stream for m in self._masked[1:]]
+            self.lane = cu_range_streams(self.device, 0, self.scan_lane)[0]
+            self.streams = cu_range_streams(self.device, self.scan_lane, cus, len(self.plans))
             self._ev = [(torch.cuda.Event(), torch.cuda.Event()) for _ in self.plans]
         else:
             self.lane = None

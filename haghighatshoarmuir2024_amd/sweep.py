@@ -95,13 +95,77 @@ def device_localizer(beamf, bf_mat, max_batch=1100):
     return run
 
 
+def _throughput_pipelined(beamf, bf_mat, time_test, sig_test, doa_all, snr_db_trial, lo, hi, batch_trials, seed, streams, scan_lane_cus):
+    """Trials [lo, hi) of a throughput-mode sweep with several batches in flight (runtime.StreamPipeline): batch k is synthesised
+    (micloc_synth_awgn_f64: delayed template + Philox noise numbered by global trial) and localised on stream k % streams, its
+    arg-max / power rows return through page-locked memory, nothing on the host waits before the end.  Long recordings (the encoder
+    is time-chunked) run their serial checkpoint scans on the pipeline's scan lane.  The same bits as one batch at a time.
+    Returns (argmax [hi - lo] int64, pmax [hi - lo])."""
+    import torch
+
+    from . import runtime, synthesis
+    from .snn_beamformer import neuron_impulse_response
+
+    fs = beamf.fs
+    geometry = beamf.geometry
+    M = len(geometry)
+    time_in, sig_in = synthesis._resample(time_test, sig_test, fs)
+    tpl = runtime.Template(time_in, sig_in, fs, device=beamf.device)
+    dev, T = tpl.device, tpl.T
+    starts = list(range(lo, hi, batch_trials))
+    nplans = max(1, min(int(streams), len(starts)))
+    nir = neuron_impulse_response(time_in, beamf.tau_vec)
+    plans = [beamf.plan()] + [beamf.new_plan() for _ in range(nplans - 1)]
+    for pl in plans:
+        pl.set_neuron_kernel(nir)
+        pl.set_bf_mat(np.asarray(bf_mat, dtype=np.float64))
+    G = plans[0].G
+    Bmax = min(batch_trials, hi - lo)
+    chunked = plans[0].encoder_chunks(Bmax, T) > 1
+    pipe = runtime.StreamPipeline(plans, scan_lane=scan_lane_cus if (chunked and nplans > 1) else 0)
+    # per plan: input batch and noise workspace (a batch in flight owns them until its stream has moved on); per batch: result rows
+    xs = [torch.empty((Bmax, T, M), dtype=torch.float64, device=dev) for _ in plans]
+    wss = [runtime.awgn_workspace(Bmax, T, M, dev) for _ in plans]
+    outs = [None] * nplans
+    snr_dev = torch.from_numpy(np.ascontiguousarray(snr_db_trial[lo:hi], dtype=np.float64)).to(dev)
+    am_host = torch.empty((hi - lo,), dtype=torch.int32).pin_memory()
+    pw_host = torch.empty((hi - lo, G), dtype=torch.float64).pin_memory()
+    cur = {}
+
+    def before(i):
+        s0, s1 = cur["range"]
+        # delays from NumPy's cos like the host path (bit-exact with np.interp on them), one global minimum per trial (:257)
+        delays = geometry.delays(doa_all[s0:s1], normalized=False)
+        delays = delays - delays.min(axis=1, keepdims=True)
+        d_delays = torch.from_numpy(np.ascontiguousarray(delays[:, None, :])).pin_memory().to(dev, non_blocking=True)
+        runtime.synth_awgn(tpl, "apply_to_template", snr_dev[s0 - lo : s1 - lo], seed=seed, first_trial=s0, ws=wss[i], delays=d_delays,
+                           out=xs[i][: s1 - s0])
+
+    def after(i, out):
+        s0, s1 = cur["range"]
+        am_host[s0 - lo : s1 - lo].copy_(out["argmax"], non_blocking=True)
+        pw_host[s0 - lo : s1 - lo].copy_(out["power"], non_blocking=True)
+
+    for k, s0 in enumerate(starts):
+        s1 = min(hi, s0 + batch_trials)
+        cur["range"] = (s0, s1)
+        i = k % nplans
+        if outs[i] is not None and outs[i]["argmax"].shape[0] != s1 - s0:
+            outs[i] = None  # (a last, shorter batch: its own result tensors)
+        pipe.snn_pipeline(lambda j: xs[j][: cur["range"][1] - cur["range"][0]], before=before, after=after, index=i, out=outs, want_power=True)
+    pipe.synchronize()
+    am = am_host.numpy().astype(np.int64)
+    return am, pw_host.numpy()[np.arange(hi - lo), am]
+
+
 def _template_sweep(beamf, bf_mat, doa_list, time_test, sig_test, snr_db_trial, num_sim, seed, mode, rank, world_size, group,
-                    localizer, batch_trials):
+                    localizer, batch_trials, streams=4, scan_lane_cus=4):
     """The Monte-Carlo loop shared by the noisy-target and the speech sweep (target_snn_localization.py:447-467 / :224-245):
     per trial `doa = rand(1)[0] * 2 pi`, apply_to_template at `snr_db_trial[trial]`, power, arg-max, pi-periodic error.
     Trials are processed in batches of `batch_trials` (host memory: a speech trial is 18.6 MB)."""
     total = len(snr_db_trial)
     lo, hi = shard_range(total, rank, world_size)
+    pipelined = mode == "throughput" and localizer is None and streams > 0 and hi > lo
     localizer = localizer or device_localizer(beamf, bf_mat, max_batch=batch_trials)
     M = len(beamf.geometry)
     doa_all = np.zeros(total)
@@ -136,7 +200,13 @@ def _template_sweep(beamf, bf_mat, doa_list, time_test, sig_test, snr_db_trial, 
 
         rng = np.random.RandomState(seed)
         doa_all[:] = rng.rand(total) * 2 * np.pi
-        for s0 in range(lo, hi, batch_trials):
+        if pipelined:
+            # the default localizer: several batches in flight, no host synchronisation between them (same bits)
+            a, p = _throughput_pipelined(beamf, bf_mat, time_test, sig_test, doa_all, snr_db_trial, lo, hi, batch_trials, seed, streams,
+                                         scan_lane_cus)
+            argmax_parts.append(a)
+            pmax_parts.append(p)
+        for s0 in (() if pipelined else range(lo, hi, batch_trials)):
             s1 = min(hi, s0 + batch_trials)
             # noise-free array signals synthesised on the device (bit-exact with the host np.interp path), noise from the
             # Philox kernel, numbered by GLOBAL trial: the same draw for any sharding
@@ -157,7 +227,7 @@ def _template_sweep(beamf, bf_mat, doa_list, time_test, sig_test, snr_db_trial, 
 
 def noisy_target_sweep(beamf, bf_mat, doa_list, snr_db_vec=None, num_sim=100, seed=0, mode="parity", rank=0, world_size=1,
                        group=None, freq_design=2000.0, test_duration=100e-3, snr_gain_due_to_bandwidth=None, localizer=None,
-                       batch_trials=1100):
+                       batch_trials=1100, streams=4):
     """paper_plots/target_snn_localization.py:435-467.  Returns dict(doa, argmax, err, pmax: [num_snr, num_sim];
     mae_deg [num_snr]) on every rank."""
     fs = beamf.fs
@@ -168,7 +238,7 @@ def noisy_target_sweep(beamf, bf_mat, doa_list, snr_db_vec=None, num_sim=100, se
     sig_test = np.sin(2 * np.pi * freq_design * time_test)
     snr_trial = np.repeat(snr_db_vec - 10 * np.log10(snr_gain_due_to_bandwidth), num_sim)  # :449
     res = _template_sweep(beamf, bf_mat, doa_list, time_test, sig_test, snr_trial, num_sim, seed, mode, rank, world_size, group,
-                          localizer, batch_trials)
+                          localizer, batch_trials, streams)
     res["snr_db_vec"] = snr_db_vec
     return res
 
@@ -191,13 +261,17 @@ def speech_source(fs, flac_path=None, pcm16=None, rate=None):
 
 
 def speech_target_sweep(beamf, bf_mat, doa_list, source, snr_db_vec=None, num_sim=20, seed=0, mode="parity", rank=0, world_size=1,
-                        group=None, localizer=None, batch_trials=25):
+                        group=None, localizer=None, batch_trials=None, streams=4):
     """The speech accuracy sweep of paper_plots/target_snn_localization.py:213-245: `source` = (time_fs, sig_test) from
-    `speech_source`, 11 SNRs x 20 trials, NO bandwidth correction of the SNR (`snr_db_target = snr_db`, :227)."""
+    `speech_source`, 11 SNRs x 20 trials, NO bandwidth correction of the SNR (`snr_db_target = snr_db`, :227).
+    batch_trials: trials per device batch (default: 25 in parity mode -- a trial is 18.6 MB on the host --, 125 in throughput mode,
+    where the batches are synthesised on the device and `streams` of them are in flight; streams=0: one batch at a time)."""
+    if batch_trials is None:
+        batch_trials = 125 if mode == "throughput" else 25
     snr_db_vec = np.asarray(np.linspace(-10, 20, 11) if snr_db_vec is None else snr_db_vec, dtype=np.float64)
     time_fs, sig_test = source
     res = _template_sweep(beamf, bf_mat, doa_list, np.asarray(time_fs, dtype=np.float64), np.asarray(sig_test, dtype=np.float64),
-                          np.repeat(snr_db_vec, num_sim), num_sim, seed, mode, rank, world_size, group, localizer, batch_trials)
+                          np.repeat(snr_db_vec, num_sim), num_sim, seed, mode, rank, world_size, group, localizer, batch_trials, streams)
     res["snr_db_vec"] = snr_db_vec
     return res
 

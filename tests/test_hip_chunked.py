@@ -193,7 +193,7 @@ def test_stream_pipeline_scan_lane(cfg2, torch):
         for i in range(3):
             for key in ("spikes", "power", "argmax"):
                 np.testing.assert_array_equal(outs[i][key].cpu().numpy(), ref_np[i][key], err_msg=f"chunk={chunk} plan={i} {key}")
-        del pipe
+        del pipe  # (its masked streams belong to the process-wide pool and stay)
     with pytest.raises(ValueError):
         runtime.StreamPipeline(plans, scan_lane=32)
 
@@ -201,11 +201,16 @@ def test_stream_pipeline_scan_lane(cfg2, torch):
 def test_cu_range_stream_arguments(torch):
     from haghighatshoarmuir2024_amd import _lib, runtime
 
+    y = torch.arange(1000, device="cuda")
     s = runtime.CuRangeStream(None, 0, 4)
+    s.stream.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(s.stream):
-        y = torch.arange(1000, device="cuda").sum()
+        y.add_(1)  # (nothing is ALLOCATED under the stream: it is destroyed below)
     s.stream.synchronize()
-    assert int(y.item()) == 499500
+    assert int(y.sum().item()) == 500500
+    s.close()
+    a, b = runtime.cu_range_streams(None, 4, 32, 2)
+    assert runtime.cu_range_streams(None, 4, 32, 1)[0] is a and a is not b  # the pool hands out the same streams again
     for lo, hi in ((4, 4), (-1, 3), (0, 33), (5, 2)):
         with pytest.raises(_lib.MiclocError):
             runtime.CuRangeStream(None, lo, hi)

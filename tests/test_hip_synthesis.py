@@ -123,6 +123,36 @@ def test_throughput_sweep_is_sharding_invariant(cfg2, geo):
     np.testing.assert_array_equal(res["argmax"], full["argmax"])  # batch split 7 vs 1100: same draws, same results
     np.testing.assert_array_equal(res["pmax"], full["pmax"])
     assert full["mae_deg"][0] > full["mae_deg"][2] and full["mae_deg"][2] < 3.0
+    # the default localizer keeps several batches in flight (sweep._throughput_pipelined); streams=0 is one batch at a time through
+    # synthesize_batch / add_noise_ / localize_batch: the same draws, the same bits
+    serial = noisy_target_sweep(bf, cfg2["bf_mat"], cfg2["doa_list"], **kw, batch_trials=7, streams=0)
+    np.testing.assert_array_equal(serial["argmax"], full["argmax"])
+    np.testing.assert_array_equal(serial["pmax"], full["pmax"])
+    piped = noisy_target_sweep(bf, cfg2["bf_mat"], cfg2["doa_list"], **kw, batch_trials=9, streams=3)  # 60 trials: 6 batches of 9 and one of 6
+    np.testing.assert_array_equal(piped["argmax"], full["argmax"])
+    np.testing.assert_array_equal(piped["pmax"], full["pmax"])
+
+
+def test_long_recording_sweep_pipelined_on_the_scan_lane(cfg2, geo):
+    """speech_target_sweep in throughput mode on a long source (the encoder is time-chunked): batches in flight on streams restricted
+    to compute units [4, 32) of every XCD, their serial scans on the lane -- identical to one batch at a time."""
+    from haghighatshoarmuir2024_amd.snn_beamformer import SNNBeamformer
+    from haghighatshoarmuir2024_amd.sweep import speech_target_sweep
+
+    fs = 48_000
+    tau = 1 / (2 * np.pi * 2000)
+    bf = SNNBeamformer(geo, 10e-3, [1000.0, 2000.0], np.asarray([tau, tau]), bipolar_spikes=True, fs=fs)
+    T = 70_000
+    t = np.arange(T) / fs
+    rng = np.random.RandomState(5)
+    src = np.sin(2 * np.pi * 1500 * t) * (0.5 + 0.5 * np.sin(2 * np.pi * 3 * t)) + 0.05 * rng.randn(T)
+    kw = dict(snr_db_vec=[0.0, 20.0], num_sim=11, seed=9, mode="throughput", batch_trials=5)
+    assert bf.plan().encoder_chunks(5, len(np.arange(t.min(), t.max(), step=1 / fs))) > 1
+    serial = speech_target_sweep(bf, cfg2["bf_mat"], cfg2["doa_list"], (t, src), **kw, streams=0)
+    piped = speech_target_sweep(bf, cfg2["bf_mat"], cfg2["doa_list"], (t, src), **kw, streams=3)  # 22 trials: 4 batches of 5 and one of 2
+    np.testing.assert_array_equal(piped["argmax"], serial["argmax"])
+    np.testing.assert_array_equal(piped["pmax"], serial["pmax"])
+    assert piped["mae_deg"][1] < 5.0
 
 
 def test_fused_synthesis_and_noise_equals_the_two_calls(geo):
