@@ -277,13 +277,15 @@ def speech_target_sweep(beamf, bf_mat, doa_list, source, snr_db_vec=None, num_si
 
 
 def xylo_target_sweep(demo, snr_db_vec=None, num_sim=100, seed=0, mode="parity", rank=0, world_size=1, group=None,
-                      test_duration=1000e-3, snr_gain_due_to_bandwidth=None, batch_trials=50, device_delays=None, peak=None):
+                      test_duration=1000e-3, snr_gain_due_to_bandwidth=None, batch_trials=None, device_delays=None, peak=None):
     """The Xylo accuracy sweep of paper_plots/target_xylo_localization.py:540-608 (and its `_unipolar` twin): chirp test
     signal over the design band (:549-560), per trial `signal_from_template` -> AWGN -> `spike_encoding` -> `xylo_process`
     -> spike rate -> `find_peak_location(win_size)` with win_size = 2 * ((num_grid // 32) // 2) + 1 (:600-603) -> error.
 
     PARITY UNPINNED for the integer-LIF stage (rockpool / XyloSim absent: xylo_snn_localization.py module docstring);
-    everything around it follows the reference's arithmetic.  `demo` is a xylo_snn_localization.Demo with one band."""
+    everything around it follows the reference's arithmetic.  `demo` is a xylo_snn_localization.Demo with one band.
+    batch_trials: trials per device batch -- default 50 in parity mode (host arrays of 2.7 MB per trial), 1100 in throughput mode: the
+    integer LIF is one serial chain per trial, a launch takes as long for 50 trials as for 1100."""
     from . import synthesis
     from .utils import find_peak_location
     from .xylo_snn_localization import signal_from_template
@@ -304,6 +306,8 @@ def xylo_target_sweep(demo, snr_db_vec=None, num_sim=100, seed=0, mode="parity",
     total = len(snr_db_vec) * num_sim
     snr_trial = np.repeat(snr_db_vec - 10 * np.log10(snr_gain_due_to_bandwidth), num_sim)
     lo, hi = shard_range(total, rank, world_size)
+    if batch_trials is None:
+        batch_trials = 1100 if mode == "throughput" else 50
     if device_delays is None:
         device_delays = mode == "throughput"
     doa_all = np.zeros(total)
