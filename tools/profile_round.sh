@@ -35,6 +35,11 @@ bash tools/dev/ab_lib.sh tools/_variants/libmicloc_hip_stht_valu.so "--steps 40 
 python3 tools/dev/xylo_lif_bench.py > $OUT/xylo_lif_forms.txt 2>/dev/null
 bash tools/dev/xylo_lif_modes.sh static queue:4 static queue:4 > $OUT/xylo_step_lif_forms.txt 2>/dev/null
 python3 tools/dev/design_cfg5_time.py 48 240 > $OUT/design_config5.txt 2>/dev/null
+# round 4, late: the product sweeps (whole call, one GPU), the speech step under its schedules (ONE masked configuration per process) and
+# the STHT's input reads at two recording lengths
+(python3 tools/dev/speech_sweep_time.py 91; python3 tools/dev/xylo_sweep_time.py) 2>/dev/null | grep -v amdgpu.ids > $OUT/product_sweeps.txt
+(for c in "3 graph" "4 32block" "5 32block" "4 24block"; do set -- $c; python3 tools/dev/speech_lane.py 30 $1 $2 2>/dev/null | grep "graph\|scan on"; done) > $OUT/speech_schedules.txt
+(bash tools/dev/stht_fetch_ab.sh; STHT_T=48000 bash tools/dev/stht_fetch_ab.sh) 2>/dev/null | grep -v amdgpu.ids > $OUT/stht_fetch.txt
 python3 tools/summarize_profiles.py trace $OUT/trace $OUT/kernel_trace_summary_by_shape.csv
 python3 tools/summarize_profiles.py trace $OUT/trace_g449 $OUT/kernel_trace_summary_grid449.csv
 python3 tools/summarize_profiles.py trace $OUT/trace_speech $OUT/kernel_trace_summary_speech.csv
