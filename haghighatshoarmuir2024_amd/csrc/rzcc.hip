@@ -597,7 +597,7 @@ struct RzStream {
 // launches: speech 13.1 -> 12.2 ms for scan + chunks) and costs where one workgroup per CU runs at the pace of its slowest
 // wave (sweep shape: 0.417 -> 0.445 ms), so only chunked launches carry it.
 template <int N, bool WANT_PRE, bool WANT_SPIKES, int RING = RZ_RING, bool WRITER = false, int SW = 64>
-__global__ __launch_bounds__(448, (WANT_PRE && WANT_SPIKES) ? 2 : 4) void bandpass_rzcc_fast_kernel(const double *__restrict__ h,
+__global__ __launch_bounds__(WRITER ? 512 : 448, (WANT_PRE && WANT_SPIKES) ? 2 : 4) void bandpass_rzcc_fast_kernel(const double *__restrict__ h,
                                                                   double *__restrict__ pre,
                                                                   int8_t *__restrict__ spikes,
                                                                   int *__restrict__ flag_count,
@@ -631,6 +631,17 @@ __global__ __launch_bounds__(448, (WANT_PRE && WANT_SPIKES) ? 2 : 4) void bandpa
     constexpr int QN = 8;
     __shared__ int spq[WRITER ? 2 : 1][WRITER ? QN : 1][SW];
     __shared__ int qwPub[2][SW];
+    // Clusters of four to eight candidates on their way to the RESOLVER wave (chunked launches, like the writer).  The greedy selection
+    // inside such a cluster is ~80 instructions per kept peak for ONE lane -- and the whole select wave sits through it whenever one of
+    // its 64 streams closes one (config 4, order-1 band-pass: two thirds of the select waves' time).  The select waves only push a
+    // descriptor (stream, polarity, first ring slot, count); one tile later the resolver wave takes eight descriptors at a time, one
+    // cluster per group of eight lanes, one candidate per lane: arg-max by three exchange steps, one compare per lane to remove the
+    // neighbours -- the same greedy rule, the same ties (later wins), every lane busy.  A full queue (or a longer cluster) is
+    // resolved in place as before.
+    constexpr bool RESOLVER = WRITER;
+    constexpr int QC = 64;
+    __shared__ int cq[RESOLVER ? 2 : 1][RESOLVER ? QC : 1];
+    __shared__ int cqn[2];
 
     // 0: loader, 1: filter, 2: detect, 3: select maxima, 4: select minima.  Launches that do not store the filtered signal
     // have a second loader wave in front (even / odd tiles, four tiles of global loads in flight instead of two: with
@@ -773,6 +784,59 @@ __global__ __launch_bounds__(448, (WANT_PRE && WANT_SPIKES) ? 2 : 4) void bandpa
             __syncthreads();
         }
         drain();
+        return;
+    }
+
+    if (RESOLVER && wave == 6) {
+        // ------------------------------------ resolver -------------------------------------------------
+        const int grp = lane >> 3, j = lane & 7;
+        const int stride = bipolar ? 2 : 1;
+        auto drain = [&](int buf) {
+            int n = cqn[RESOLVER ? buf : 0];
+            n = n < QC ? n : QC;
+            n = __builtin_amdgcn_readfirstlane(n);
+            for (int it = 0; it * 8 < n; ++it) {
+                const int di = it * 8 + grp;
+                const bool have = di < n;
+                const int desc = have ? cq[RESOLVER ? buf : 0][RESOLVER ? di : 0] : 0;
+                const int st = desc & 63, pol = (desc >> 6) & 1, cnt = (desc >> 7) & 15, s0 = (desc >> 11) & (RING - 1);
+                bool alive = have && j < cnt;
+                const int slot = (s0 + j * stride) & (RING - 1);
+                const int P = ringP[WANT_SPIKES ? slot : 0][st] >> 1;
+                const double V = ringV[WANT_SPIKES ? slot : 0][st] * (pol ? -1.0 : 1.0);
+                const int sg = base + st;  // (a pushed descriptor belongs to an active stream)
+                const int bb = sg / C;
+                int8_t *spd = spikes + (size_t)bb * T * C + (sg - bb * C);
+                const int8_t mk = pol ? (int8_t)-1 : (int8_t)1;
+                while (__any(alive)) {
+                    // arg-max over the group's live candidates, the later one on a tie; dead lanes carry index -1
+                    double bv = V;
+                    int bi = alive ? j : -1, bp = P;
+#pragma unroll
+                    for (int off = 1; off < 8; off <<= 1) {
+                        const double ov = __shfl_xor(bv, off, 8);
+                        const int oi = __shfl_xor(bi, off, 8), op = __shfl_xor(bp, off, 8);
+                        const bool take = oi >= 0 && (bi < 0 || ov > bv || (ov == bv && oi > bi));
+                        bv = take ? ov : bv;
+                        bi = take ? oi : bi;
+                        bp = take ? op : bp;
+                    }
+                    if (bi >= 0) {
+                        if (j == bi) spd[(size_t)bp * C] = mk;
+                        const int d = P - bp;
+                        if ((d < 0 ? -d : d) < w) alive = false;  // (the kept one included: distance 0)
+                    }
+                }
+            }
+            if (lane == 0) cqn[RESOLVER ? buf : 0] = 0;
+        };
+        if (lane < 2) cqn[lane] = 0;
+        __syncthreads();
+        for (int k = 0; k < NSTEP; ++k) {
+            if (k >= 3) drain((k - 1) & 1);  // what the select waves pushed during the previous tile
+            __syncthreads();
+        }
+        drain((NSTEP - 1) & 1);
         return;
     }
 
@@ -957,6 +1021,8 @@ __global__ __launch_bounds__(448, (WANT_PRE && WANT_SPIKES) ? 2 : 4) void bandpa
     auto word_at = [&](int i) { return &ringP[i & (RING - 1)][lane]; };
     auto val_at = [&](int i) { return &ringV[i & (RING - 1)][lane]; };
     int widx = 0, w1 = 0, w2 = 0;  // queue write index now / at the last barrier / at the one before
+    int qbuf = -1;                 // resolver queue of the current tile (-1: resolve in place)
+    int pend_lo = 0x7fffffff;      // first list index of the clusters pushed during the current tile: they stay in the ring one more tile
     auto emit = [&](int pos) {
         if (WRITER && widx - w2 < QN) {
             spq[WRITER ? mypol : 0][WRITER ? (widx & (QN - 1)) : 0][lane] = pos;
@@ -998,7 +1064,16 @@ __global__ __launch_bounds__(448, (WANT_PRE && WANT_SPIKES) ? 2 : 4) void bandpa
             }
         } else {
             // (collecting the clusters of three or more candidates in a per-lane queue and resolving them once per tile instead of
-            // once per trip was measured and rejected: select waves 3300 -> 4200 cycles per tile on config 4)
+            // once per trip -- in THIS wave -- was measured and rejected: select waves 3300 -> 4200 cycles per tile on config 4)
+            const int cnt = (e - s + stride - 1) / stride;
+            if (RESOLVER && qbuf >= 0 && cnt <= 8) {
+                const int slot = atomicAdd(&cqn[qbuf], 1);
+                if (slot < QC) {
+                    cq[RESOLVER ? qbuf : 0][RESOLVER ? slot : 0] = lane | (mypol << 6) | (cnt << 7) | ((s & (RING - 1)) << 11);
+                    pend_lo = s < pend_lo ? s : pend_lo;
+                    return;
+                }
+            }
             resolve_cluster(s, e, stride, w, emit, word_at, val_at, sgn);
         }
     };
@@ -1019,6 +1094,8 @@ __global__ __launch_bounds__(448, (WANT_PRE && WANT_SPIKES) ? 2 : 4) void bandpa
         if (k >= 2 && mine) {
             const int n = nPub[lane];  // candidates published by the detect wave before the last barrier
             if (ovPub[lane]) dead = true;
+            qbuf = RESOLVER ? (k & 1) : -1;
+            pend_lo = 0x7fffffff;
             if (i_next < 0 && n > 0) i_next = bipolar ? (polPub[lane] ^ mypol) : 0;
             // one candidate per lane and trip.  (Fetching the words of the next four candidates up front was measured and
             // rejected: most tiles bring one new candidate per lane, the three extra reads and selects cost more than the
@@ -1039,8 +1116,13 @@ __global__ __launch_bounds__(448, (WANT_PRE && WANT_SPIKES) ? 2 : 4) void bandpa
                     i_next = i + stride;
                 }
             }
-            // everything from the open cluster on must survive in the ring; without one, everything not yet examined
-            oldPub[mypol][lane] = dead ? 0x7fffffff : (s_open >= 0 ? s_open : (i_next >= 0 ? i_next : 0));
+            // everything from the open cluster on must survive in the ring; without one, everything not yet examined -- and what the
+            // resolver wave reads during the next tile
+            {
+                const int keep = s_open >= 0 ? s_open : (i_next >= 0 ? i_next : 0);
+                oldPub[mypol][lane] = dead ? 0x7fffffff : (pend_lo < keep ? pend_lo : keep);
+            }
+            qbuf = -1;
         }
         if (WRITER && mine) {
             qwPub[mypol][lane] = widx;
@@ -1385,7 +1467,7 @@ static void launch_rz_spikes(const IirCoef &coef, const double *h, int nlanes, i
     const int nblk = (nlanes + SW - 1) / SW;
     dim3 grid(nblk * g.P);
     if (g.P > 1)
-        hipLaunchKernelGGL((bandpass_rzcc_fast_kernel<N, false, true, RZ_RING, true, SW>), grid, dim3(448), 0, stream, h, nullptr,
+        hipLaunchKernelGGL((bandpass_rzcc_fast_kernel<N, false, true, RZ_RING, true, SW>), grid, dim3(512), 0, stream, h, nullptr,
                            spikes, flag_count, flag_list, coef, nlanes, C, T, Ts, w, bipolar, xin, M, shift, g, nblk, ckd, cki,
                            RzStream{});
     else

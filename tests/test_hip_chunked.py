@@ -214,3 +214,41 @@ def test_cu_range_stream_arguments(torch):
     for lo, hi in ((4, 4), (-1, 3), (0, 33), (5, 2)):
         with pytest.raises(_lib.MiclocError):
             runtime.CuRangeStream(None, lo, hi)
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("MICLOC_RANDOM_SEEDS", "16"))))
+def test_chunked_random_configurations_vs_oracle(torch, seed):
+    """Randomised configurations through the CHUNKED encoder (writer + resolver waves: clusters of four to eight candidates are resolved
+    cooperatively by a wave of their own) against the oracle, spikes bit for bit: wide robust widths and low filter orders make dense
+    candidate trains -- clusters of every size, full resolver queues, ring overflows -- and quantised inputs make exact ties."""
+    from haghighatshoarmuir2024_amd.runtime import Plan
+    from scipy.signal import butter
+
+    rng = np.random.default_rng(7000 + seed)
+    M = int(rng.choice([1, 3, 7, 12]))
+    kernel = rng.standard_normal(int(rng.choice([8, 30, 64])))
+    kernel[::2] = 0.0
+    order = int(rng.choice([1, 1, 2]))
+    b, a = butter(order, [0.02 + 0.1 * rng.random(), 0.3 + 0.15 * rng.random()], btype="bandpass")
+    w = int(rng.choice([3, 5, 8, 12, 24, 40]))
+    bipolar = bool(rng.random() < 0.7)
+    T = int(rng.choice([700, 1500, 3001]))
+    B = int(rng.choice([1, 3, 6]))
+    chunk = int(rng.choice([16 * (-(-w // 16) + 1), 96, 160, 400]))
+    t = np.arange(T)[None, :, None]
+    kind = seed % 4
+    if kind == 0:
+        x = rng.standard_normal((B, T, M))
+    elif kind == 1:
+        x = np.sin(0.05 * t + rng.random((B, 1, M)) * 6.28) + 0.3 * rng.standard_normal((B, T, M))
+    elif kind == 2:
+        x = np.round(2 * rng.standard_normal((B, T, M)))
+    else:
+        x = rng.standard_normal((B, T, M)) * (1.0 + 10.0 * (t % 500 < 50))
+    p = Plan(M, kernel, b, a, w, bipolar)
+    p.set_encoder_chunk(chunk)
+    assert p.encoder_chunks(B, T) > 1
+    got = p.snn_pipeline(p.to_device(x), want_spikes=True, want_power=False)["spikes"].cpu().numpy()
+    for i in range(B):
+        want = O.snn_chain(x[i], kernel, b, a, w, bipolar, np.ones(1), np.zeros((2 * M, 1)), want=("spikes",))["spikes"]
+        np.testing.assert_array_equal(got[i], want, err_msg=f"seed={seed} M={M} w={w} bip={bipolar} T={T} chunk={chunk} order={order}")
