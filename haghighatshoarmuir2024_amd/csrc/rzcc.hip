@@ -642,6 +642,7 @@ __global__ __launch_bounds__(WRITER ? 512 : 448, (WANT_PRE && WANT_SPIKES) ? 2 :
     constexpr int QC = 64;
     __shared__ int cq[RESOLVER ? 2 : 1][RESOLVER ? QC : 1];
     __shared__ int cqn[2];
+    __shared__ size_t spOff[RESOLVER ? SW : 1];
 
     // 0: loader, 1: filter, 2: detect, 3: select maxima, 4: select minima.  Launches that do not store the filtered signal
     // have a second loader wave in front (even / odd tiles, four tiles of global loads in flight instead of two: with
@@ -804,23 +805,29 @@ __global__ __launch_bounds__(WRITER ? 512 : 448, (WANT_PRE && WANT_SPIKES) ? 2 :
                 const int slot = (s0 + j * stride) & (RING - 1);
                 const int P = ringP[WANT_SPIKES ? slot : 0][st] >> 1;
                 const double V = ringV[WANT_SPIKES ? slot : 0][st] * (pol ? -1.0 : 1.0);
-                const int sg = base + st;  // (a pushed descriptor belongs to an active stream)
-                const int bb = sg / C;
-                int8_t *spd = spikes + (size_t)bb * T * C + (sg - bb * C);
+                int8_t *spd = spikes + spOff[RESOLVER ? st : 0];  // (a pushed descriptor belongs to an active stream)
                 const int8_t mk = pol ? (int8_t)-1 : (int8_t)1;
                 while (__any(alive)) {
-                    // arg-max over the group's live candidates, the later one on a tie; dead lanes carry index -1
+                    // arg-max over the group's live candidates, the later one on a tie; dead lanes carry index -1.  Three exchange
+                    // steps inside the group of eight lanes by DPP (neighbour, other pair, mirrored half): every lane ends with the
+                    // group's best
                     double bv = V;
                     int bi = alive ? j : -1, bp = P;
-#pragma unroll
-                    for (int off = 1; off < 8; off <<= 1) {
-                        const double ov = __shfl_xor(bv, off, 8);
-                        const int oi = __shfl_xor(bi, off, 8), op = __shfl_xor(bp, off, 8);
+                    auto step = [&](auto ctrl) {
+                        constexpr int CTRL = decltype(ctrl)::value;
+                        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(bv), CTRL, 0xf, 0xf, false);
+                        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(bv), CTRL, 0xf, 0xf, false);
+                        const double ov = __hiloint2double(hi, lo);
+                        const int oi = __builtin_amdgcn_update_dpp(0, bi, CTRL, 0xf, 0xf, false);
+                        const int op = __builtin_amdgcn_update_dpp(0, bp, CTRL, 0xf, 0xf, false);
                         const bool take = oi >= 0 && (bi < 0 || ov > bv || (ov == bv && oi > bi));
                         bv = take ? ov : bv;
                         bi = take ? oi : bi;
                         bp = take ? op : bp;
-                    }
+                    };
+                    step(std::integral_constant<int, 0xB1>{});   // quad_perm [1, 0, 3, 2]
+                    step(std::integral_constant<int, 0x4E>{});   // quad_perm [2, 3, 0, 1]
+                    step(std::integral_constant<int, 0x141>{});  // row_half_mirror: lane i <-> 7 - i of each eight
                     if (bi >= 0) {
                         if (j == bi) spd[(size_t)bp * C] = mk;
                         const int d = P - bp;
@@ -831,6 +838,10 @@ __global__ __launch_bounds__(WRITER ? 512 : 448, (WANT_PRE && WANT_SPIKES) ? 2 :
             if (lane == 0) cqn[RESOLVER ? buf : 0] = 0;
         };
         if (lane < 2) cqn[lane] = 0;
+        {
+            const int bb = lane_c / C;  // where a stream's spikes go (one division per stream, here, not one per descriptor)
+            spOff[RESOLVER ? lane : 0] = (size_t)bb * T * C + (lane_c - bb * C);
+        }
         __syncthreads();
         for (int k = 0; k < NSTEP; ++k) {
             if (k >= 3) drain((k - 1) & 1);  // what the select waves pushed during the previous tile

@@ -56,7 +56,7 @@ v = np.array(list(buf), dtype=np.float64).reshape(3, 8)
 P = plan.encoder_chunks(B, T)
 ntile = (T + 15) // 16
 print(f"{cfg} B={B} T={T} chunk={chunk} P={P}: stage {e0.elapsed_time(e1):.3f} ms (incl. zero fill, scan, fallback)")
-names = ["loader0", "loader1", "filter", "detect", "select+", "select-", "writer", "-"]
+names = ["loader0", "loader1", "filter", "detect", "select+", "select-", "writer", "resolver"]
 for w in range(8):
     if v[2, w] == 0:
         continue
