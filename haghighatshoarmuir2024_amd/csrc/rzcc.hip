@@ -561,6 +561,8 @@ __global__ __launch_bounds__(192) void rzcc_scan_kernel(const double *__restrict
 //   wave D (detect)  tile k-1: local maxima / minima of the cumulative sum -> candidate ring
 //   waves S0, S1 (select) tile k-2: walk the new candidates of one polarity each, close clusters, min-distance
 //                    greedy, scatter spikes
+//   chunked launches add wave W (writer, tile k-3: stores the spike bytes the select waves queued) and wave R (resolver,
+//                    tile k-3: the greedy selection inside clusters of four to eight candidates, eight clusters at a time)
 // Each stage is a different wave of the workgroup, i.e. a different SIMD of the CU, so the serial chain of
 // one stream costs max(stage) instructions per time step instead of their sum.
 // ---------------------------------------------------------------------------------------------------
@@ -593,7 +595,7 @@ struct RzStream {
 // RING: candidate ring entries per stream (power of two).  A whole tile of appends (RZ_MT) is reserved before every tile, so
 // the usable depth is RING - RZ_MT.  Measured on the speech workload: RING = 32 (three workgroups per CU instead of two)
 // overflows so often that the unit fallback takes 3x the time saved -- 64 it is.
-// WRITER: a seventh wave that stores the spikes (see spq below).  It pays off where the launch is occupancy bound (chunked
+// WRITER: a seventh wave that stores the spikes (see spq below) and an eighth that resolves the longer clusters (see cq below).  It pays off where the launch is occupancy bound (chunked
 // launches: speech 13.1 -> 12.2 ms for scan + chunks) and costs where one workgroup per CU runs at the pace of its slowest
 // wave (sweep shape: 0.417 -> 0.445 ms), so only chunked launches carry it.
 template <int N, bool WANT_PRE, bool WANT_SPIKES, int RING = RZ_RING, bool WRITER = false, int SW = 64>
