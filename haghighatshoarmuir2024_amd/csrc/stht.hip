@@ -410,6 +410,221 @@ __global__ __launch_bounds__(SM_THREADS, 2) void stht_mfma_kernel(const double *
     }
 }
 
+// ---- the walking form of the matrix-core kernel ---------------------------------------------------------------------------
+// Both output parities see the SAME staged row index: u_p[i] = sum_j g[j] x[2 (i - j) + p - klo], so with row r of the staged
+// array holding the frame pair x[2 r - klo], x[2 r - klo + 1] of a stream, the two parities of a stream are two COLUMNS of one
+// array and one Toeplitz product serves both.  A workgroup is then 8 streams x 2 parities (the 16 matrix rows) and one staged
+// array holds everything a tile needs -- so a workgroup can WALK consecutive tiles of its streams: the newest 4 NK - 16 rows of a
+// tile are the halo of the next one (copied inside LDS), only TI new rows per tile come from memory, and they are requested before
+// the multiply of the tile in front of them.  Column c of the array is matrix row c: parity (c >> 2) & 1 of stream
+// (c & 3) + 4 (c >> 3), so that lane (q, lc) ends with both parities of streams q and q + 4 and stores 16 bytes per stream as before.
+// The multiply is the one of the kernel above (same k order, same operands): bit for bit the same results.
+template <int NTW, int NKT>
+__global__ __launch_bounds__(SM_THREADS, 4) void stht_walk_kernel(const double *__restrict__ x, double *__restrict__ h,
+                                                                  const double *__restrict__ taps, int J, int klo, int NK_rt, int T, int M,
+                                                                  int Ts, int nstreams, int ntile, int tpw)
+{
+    const int NK = NKT ? NKT : NK_rt;
+    typedef double double4_t __attribute__((ext_vector_type(4)));
+    typedef double double2_t __attribute__((ext_vector_type(2)));
+    extern __shared__ __attribute__((aligned(16))) double Xs[];
+    constexpr int TI = SM_WAVES * NTW * 16;  // outputs per parity and tile
+    const int HR = 4 * NK - 16;              // halo rows
+    const int R = TI + HR;
+    double *XS = Xs, *G = Xs + (size_t)R * 16;
+    const int tid = threadIdx.x;
+    // XCD-aware order as above; the unit is (group of 8 streams, segment of tpw tiles)
+    const int nseg = gridDim.x, ngrp = gridDim.y;
+    const int vid = xcd_walk(blockIdx.x + nseg * blockIdx.y, nseg * ngrp);
+    const int bw = nseg <= 16 ? 1 : SM_BAND;
+    const int band = vid / (bw * nseg), rem = vid - band * (bw * nseg);
+    const int inband = ngrp - band * bw < bw ? ngrp - band * bw : bw;
+    const int seg = rem / inband, grp = band * bw + (rem - seg * inband);
+    const int t_lo = seg * tpw, t_hi = (t_lo + tpw) < ntile ? (t_lo + tpw) : ntile;
+
+    for (int idx = tid; idx < 4 * NK + 16; idx += SM_THREADS) {
+        const int j = idx - 15;
+        G[idx] = (j >= 0 && j < J) ? taps[j] : 0.0;
+    }
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l = tid & 63, lc = l & 15, q = l >> 4;
+    const int irel = wv * NTW * 16;
+    auto multiply = [&](double4_t *acc, int lq, int llc) {  // (lane coordinates passed in: see the opaque move in the tile loop)
+        constexpr int GK = 2;
+        const double *ap0 = XS + (size_t)(irel + 4 * NK - 1 - lq) * 16 + llc;
+        const double *bp0 = G + llc + lq;
+        auto fetch = [&](int g, double (&av)[GK][NTW], double (&bv)[GK]) {
+            const double *pa = ap0 - (size_t)(64 * GK) * (g + 1), *pb = bp0 + 4 * GK * g;
+#pragma unroll
+            for (int u = 0; u < GK; ++u) {
+                bv[u] = pb[4 * u];
+#pragma unroll
+                for (int tt = 0; tt < NTW; ++tt) av[u][tt] = pa[(GK - u) * 64 + tt * 256];
+            }
+        };
+        auto mult = [&](const double (&av)[GK][NTW], const double (&bv)[GK]) {
+#pragma unroll
+            for (int u = 0; u < GK; ++u)
+#pragma unroll
+                for (int tt = 0; tt < NTW; ++tt) acc[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][tt], bv[u], acc[tt], 0, 0, 0);
+        };
+        const int NG = NK / GK;
+        if constexpr (NKT > 0) {
+            static_assert(NKT % (2 * GK) == 0, "whole pairs of groups");
+            double a0[GK][NTW], b0[GK], a1[GK][NTW], b1[GK];
+            fetch(0, a0, b0);
+#pragma unroll
+            for (int g = 0; g < NKT / GK; g += 2) {
+                fetch(g + 1, a1, b1);
+                __builtin_amdgcn_sched_barrier(0);
+                mult(a0, b0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (g + 2 < NKT / GK) fetch(g + 2, a0, b0);
+                __builtin_amdgcn_sched_barrier(0);
+                mult(a1, b1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else if (NG > 0) {
+            double a0[GK][NTW], b0[GK], a1[GK][NTW], b1[GK];
+            fetch(0, a0, b0);
+            for (int g = 0;; g += 2) {
+                if (g + 1 < NG) fetch(g + 1, a1, b1);
+                mult(a0, b0);
+                if (g + 1 >= NG) break;
+                if (g + 2 < NG) fetch(g + 2, a0, b0);
+                mult(a1, b1);
+                if (g + 2 >= NG) break;
+            }
+        }
+        const double *ap = ap0 - (size_t)(64 * GK) * NG, *bp = bp0 + 4 * GK * NG;
+        for (int s = GK * NG; s < NK; ++s) {
+            const double bn = *bp;
+#pragma unroll
+            for (int tt = 0; tt < NTW; ++tt) acc[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[tt * 256], bn, acc[tt], 0, 0, 0);
+            ap -= 64;
+            bp += 4;
+        }
+    };
+
+    // this thread's column of the staged array
+    const int c = tid & 15, par = (c >> 2) & 1, sc = (c & 3) + 4 * (c >> 3);
+    const int sg = grp * 8 + sc;
+    const bool valid = sg < nstreams;
+    const int bs = valid ? sg / M : 0, ms = valid ? sg - bs * M : 0;
+    const double *xs = x + (size_t)bs * T * M + ms;
+    constexpr int RP = SM_THREADS / 16;  // rows per pass
+    const int r0 = tid >> 4;
+    auto time_of = [&](int I0, int rho) { return 2 * (I0 - HR + rho) + par - klo; };  // input time of staged row rho of the tile at I0
+    auto load = [&](int I0, int rho) {
+        int ta = time_of(I0, rho);
+        ta = ta < 0 ? 0 : (ta >= T ? T - 1 : ta);
+        return xs[(size_t)ta * M];
+    };
+    auto put = [&](int I0, int rho, double v) {
+        const int ta = time_of(I0, rho);
+        XS[rho * 16 + c] = (valid && ta >= 0 && ta < T) ? v : 0.0;
+    };
+    // the first tile of the walk: the whole window
+    {
+        const int I0 = t_lo * TI;
+        constexpr int NB = 16;
+        for (int rb = r0; rb < R; rb += RP * NB) {
+            double v[NB];
+#pragma unroll
+            for (int i = 0; i < NB; ++i) v[i] = load(I0, rb + RP * i < R ? rb + RP * i : R - 1);
+#pragma unroll
+            for (int i = 0; i < NB; ++i)
+                if (rb + RP * i < R) put(I0, rb + RP * i, v[i]);
+        }
+    }
+    __syncthreads();
+    constexpr int NEWB = TI / RP;  // new rows per thread and tile (8)
+    const int C2 = 2 * M;
+    for (int t = t_lo; t < t_hi; ++t) {
+        const int I0 = t * TI;
+        const bool more = t + 1 < t_hi;
+        // (the row and column of this thread pass through an opaque move once per tile: everything derived from them -- eight
+        // addresses, eight edge predicates -- is then recomputed per tile instead of being kept in registers across the multiply,
+        // where the loop-invariant copies cost 92 bytes of scratch)
+        int r0 = tid >> 4, c = tid & 15, lq = q, llc = lc;
+        asm volatile("" : "+v"(r0), "+v"(c), "+v"(lq), "+v"(llc));
+        const int par = (c >> 2) & 1;
+        auto time_of = [&](int I0_, int rho) { return 2 * (I0_ - HR + rho) + par - klo; };
+        auto load = [&](int I0_, int rho) {
+            int ta = time_of(I0_, rho);
+            ta = ta < 0 ? 0 : (ta >= T ? T - 1 : ta);
+            return xs[(size_t)ta * M];
+        };
+        auto put = [&](int I0_, int rho, double v) {
+            const int ta = time_of(I0_, rho);
+            XS[rho * 16 + c] = (valid && ta >= 0 && ta < T) ? v : 0.0;
+        };
+        double vnew[NEWB];
+        // the next tile's new rows: in flight during the multiply.  Interior tiles (all of a thread's eight frames inside the recording)
+        // are one pointer and constant strides; the others clamp frame by frame
+        const int tn0 = time_of(I0 + TI, HR + r0);
+        const bool inside = tn0 >= 0 && tn0 + 2 * RP * (NEWB - 1) < T;
+        if (more) {
+            if (inside) {
+                const double *pl = xs + (size_t)tn0 * M;
+                const size_t st = (size_t)2 * RP * M;
+#pragma unroll
+                for (int i = 0; i < NEWB; ++i) vnew[i] = pl[st * i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < NEWB; ++i) vnew[i] = load(I0 + TI, HR + r0 + RP * i);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const bool active = 2 * (I0 + irel) < Ts;  // (wave-uniform)
+        if (active) {
+            double4_t acc[NTW];
+#pragma unroll
+            for (int tt = 0; tt < NTW; ++tt) acc[tt] = double4_t{0.0, 0.0, 0.0, 0.0};
+            multiply(acc, lq, llc);
+            asm volatile("" : "+v"(lq), "+v"(llc));
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int sigma = grp * 8 + lq + 4 * k;
+                if (sigma >= nstreams) continue;
+                const int b = sigma / M, m = sigma - b * M;
+                double *row = h + ((size_t)b * C2 + M + m) * Ts;
+#pragma unroll
+                for (int tt = 0; tt < NTW; ++tt) {
+                    const int to = 2 * (I0 + irel + 16 * tt + llc);
+                    if (to < Ts) *reinterpret_cast<double2 *>(row + to) = make_double2(acc[tt][2 * k], acc[tt][2 * k + 1]);
+                }
+            }
+        }
+        if (!more) break;
+        __builtin_amdgcn_sched_barrier(0);
+        // slide: the newest HR rows become the halo (source rows [TI, R), destination rows [0, HR): disjoint as HR <= TI, so the
+        // copy needs no barrier of its own); the new rows overwrite [HR, R) once every wave has finished reading
+        const int ncopy = HR * 8;  // 16-byte pairs: at most four per thread (the launcher takes this kernel for HR <= 256 only)
+        double2_t hc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + SM_THREADS * i;
+            hc[i] = e < ncopy ? *reinterpret_cast<const double2_t *>(XS + (size_t)TI * 16 + 2 * e) : double2_t{0.0, 0.0};
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + SM_THREADS * i;
+            if (e < ncopy) *reinterpret_cast<double2_t *>(XS + 2 * e) = hc[i];
+        }
+        if (inside) {
+            double *pd = XS + (size_t)(HR + r0) * 16 + c;
+#pragma unroll
+            for (int i = 0; i < NEWB; ++i) pd[(size_t)RP * 16 * i] = valid ? vnew[i] : 0.0;
+        } else {
+#pragma unroll
+            for (int i = 0; i < NEWB; ++i) put(I0 + TI, HR + r0 + RP * i, vnew[i]);
+        }
+        __syncthreads();
+    }
+}
+
 // in-phase rows beside the matrix-core form: h[b][m][t] = x[b][(t - shift) mod T][m] (np.roll), zero in the row padding.
 // 64 frames x M microphones per workgroup through an LDS tile: row-major reads, planar writes, both coalesced.
 __global__ __launch_bounds__(256) void stht_inphase_kernel(const double *__restrict__ x, double *__restrict__ h, int shift, int T, int M, int Ts)
@@ -465,10 +680,27 @@ hipError_t launch_stht(const SthtTaps &tp, const double *x, double *h, int B, in
             const int nstreams = B * M;
             dim3 grid((Ts / 2 + TI - 1) / TI, (nstreams + 15) / 16);
             const size_t lds = stht_mfma_lds(J, ntw);
+            if (!VARIANT_STHT_ONE_TILE && ntw == 2 && 4 * NK - 16 <= 256) {
+                // the walking form (halos up to 256 rows: four 16-byte copies per thread).  Tiles per workgroup: as many as leave
+                // one workgroup per slot of the chip (512), at most 16 -- a single trial still spreads over its ten tiles, the
+                // sweep's 963 groups walk their ten tiles each.  Measured on the sweep shape (step, ms): 3 / 4 / 5 / 10 tiles per
+                // workgroup 1.545 / 1.483 / 1.475 / 1.466 against 1.50-1.51 with one tile per workgroup; T = 48 000: 16 / 32 / 64
+                // tiles 3.18 / 3.25 / 4.15 ms against 3.30.
+                const int ntile = (Ts / 2 + TI - 1) / TI, ngrp8 = (nstreams + 7) / 8;
+                int tpw = (int)(((long long)ntile * ngrp8) / 512);
+                tpw = tpw < 1 ? 1 : (tpw > 16 ? 16 : tpw);
+                tpw = tpw > ntile ? ntile : tpw;
+                auto kw = NK == 64 ? &stht_walk_kernel<2, 64> : &stht_walk_kernel<2, 0>;
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kw), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (e != hipSuccess) return e;
+                hipLaunchKernelGGL(kw, dim3((ntile + tpw - 1) / tpw, ngrp8), dim3(SM_THREADS), lds, stream, x, h, tp.taps, J, tp.klo, NK, T, M,
+                                   Ts, nstreams, ntile, tpw);
+            } else {
             auto k = ntw == 2 ? (NK == 64 ? &stht_mfma_kernel<2, 64> : &stht_mfma_kernel<2, 0>) : &stht_mfma_kernel<1, 0>;
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return e;
             hipLaunchKernelGGL(k, grid, dim3(SM_THREADS), lds, stream, x, h, tp.taps, J, tp.klo, NK, T, M, Ts, nstreams);
+            }
             if (write_re)
                 hipLaunchKernelGGL(stht_inphase_kernel, dim3((Ts + 63) / 64, B), dim3(256), (size_t)64 * M * sizeof(double), stream, x, h,
                                    tp.shift, T, M, Ts);
