@@ -419,7 +419,8 @@ __global__ __launch_bounds__(SM_THREADS, 2) void stht_mfma_kernel(const double *
 // the multiply of the tile in front of them.  Column c of the array is matrix row c: parity (c >> 2) & 1 of stream
 // (c & 3) + 4 (c >> 3), so that lane (q, lc) ends with both parities of streams q and q + 4 and stores 16 bytes per stream as before.
 // The multiply is the one of the kernel above (same k order, same operands): bit for bit the same results.
-template <int NTW, int NKT>
+// NCP: 16-byte pairs of the halo a thread copies per tile (4: halos up to 256 rows, 8: up to 512)
+template <int NTW, int NKT, int NCP = 4>
 __global__ __launch_bounds__(SM_THREADS, 4) void stht_walk_kernel(const double *__restrict__ x, double *__restrict__ h,
                                                                   const double *__restrict__ taps, int J, int klo, int NK_rt, int T, int M,
                                                                   int Ts, int nstreams, int ntile, int tpw)
@@ -600,16 +601,16 @@ __global__ __launch_bounds__(SM_THREADS, 4) void stht_walk_kernel(const double *
         __builtin_amdgcn_sched_barrier(0);
         // slide: the newest HR rows become the halo (source rows [TI, R), destination rows [0, HR): disjoint as HR <= TI, so the
         // copy needs no barrier of its own); the new rows overwrite [HR, R) once every wave has finished reading
-        const int ncopy = HR * 8;  // 16-byte pairs: at most four per thread (the launcher takes this kernel for HR <= 256 only)
-        double2_t hc[4];
+        const int ncopy = HR * 8;  // 16-byte pairs: at most NCP per thread (the launcher's choice)
+        double2_t hc[NCP];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NCP; ++i) {
             const int e = tid + SM_THREADS * i;
             hc[i] = e < ncopy ? *reinterpret_cast<const double2_t *>(XS + (size_t)TI * 16 + 2 * e) : double2_t{0.0, 0.0};
         }
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NCP; ++i) {
             const int e = tid + SM_THREADS * i;
             if (e < ncopy) *reinterpret_cast<double2_t *>(XS + 2 * e) = hc[i];
         }
@@ -680,7 +681,7 @@ hipError_t launch_stht(const SthtTaps &tp, const double *x, double *h, int B, in
             const int nstreams = B * M;
             dim3 grid((Ts / 2 + TI - 1) / TI, (nstreams + 15) / 16);
             const size_t lds = stht_mfma_lds(J, ntw);
-            if (!VARIANT_STHT_ONE_TILE && ntw == 2 && 4 * NK - 16 <= 256) {
+            if (!VARIANT_STHT_ONE_TILE && 4 * NK - 16 <= 512) {
                 // the walking form (halos up to 256 rows: four 16-byte copies per thread).  Tiles per workgroup: as many as leave
                 // one workgroup per slot of the chip (512), at most 16 -- a single trial still spreads over its ten tiles, the
                 // sweep's 963 groups walk their ten tiles each.  Measured on the sweep shape (step, ms): 3 / 4 / 5 / 10 tiles per
@@ -690,7 +691,9 @@ hipError_t launch_stht(const SthtTaps &tp, const double *x, double *h, int B, in
                 int tpw = (int)(((long long)ntile * ngrp8) / 512);
                 tpw = tpw < 1 ? 1 : (tpw > 16 ? 16 : tpw);
                 tpw = tpw > ntile ? ntile : tpw;
-                auto kw = NK == 64 ? &stht_walk_kernel<2, 64> : &stht_walk_kernel<2, 0>;
+                const bool wide = 4 * NK - 16 > 256;  // (J = 480, the 96 kHz kernel: 480 halo rows, one tile per wave)
+                auto kw = ntw == 2 ? (NK == 64 ? &stht_walk_kernel<2, 64, 4> : (wide ? &stht_walk_kernel<2, 0, 8> : &stht_walk_kernel<2, 0, 4>))
+                                   : (wide ? &stht_walk_kernel<1, 0, 8> : &stht_walk_kernel<1, 0, 4>);
                 hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kw), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 if (e != hipSuccess) return e;
                 hipLaunchKernelGGL(kw, dim3((ntile + tpw - 1) / tpw, ngrp8), dim3(SM_THREADS), lds, stream, x, h, tp.taps, J, tp.klo, NK, T, M,
