@@ -30,6 +30,8 @@ hipcc -O3 --offload-arch=gfx950 -o /tmp/store_bw tools/store_bw.hip > /dev/null 
 #   stht_valu  the STHT on the vector ALU (round 2's kernel) instead of the matrix cores
 bash tools/dev/ab_lib.sh tools/_variants/libmicloc_hip_ws_k4.so "--steps 40 --warmup 4" > $OUT/ablation_kstep.txt 2>&1
 bash tools/dev/ab_lib.sh tools/_variants/libmicloc_hip_stht_valu.so "--steps 40 --warmup 4" > $OUT/ablation_stht.txt 2>&1
+#   stht_one_tile  the matrix-core STHT with one time tile per workgroup (round 3) instead of the walk
+bash tools/dev/ab_lib.sh tools/_variants/libmicloc_hip_stht_one_tile.so "--steps 40 --warmup 4" > $OUT/ablation_stht_walk.txt 2>&1
 # round 4: the complex Beamformer's contraction alone, the Xylo LIF launch forms, config 5's design
 (python3 tools/c128_time.py 360 1100 0; python3 tools/c128_time.py 449 1100 0; python3 tools/c128_time.py 360 1100 1; python3 tools/c128_time.py 57 1100 1) > $OUT/c128_time.txt 2>/dev/null
 python3 tools/dev/xylo_lif_bench.py > $OUT/xylo_lif_forms.txt 2>/dev/null
