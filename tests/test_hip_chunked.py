@@ -252,3 +252,28 @@ def test_chunked_random_configurations_vs_oracle(torch, seed):
     for i in range(B):
         want = O.snn_chain(x[i], kernel, b, a, w, bipolar, np.ones(1), np.zeros((2 * M, 1)), want=("spikes",))["spikes"]
         np.testing.assert_array_equal(got[i], want, err_msg=f"seed={seed} M={M} w={w} bip={bipolar} T={T} chunk={chunk} order={order}")
+
+
+def test_resolver_queue_overflow_falls_back_in_place(torch):
+    """Every stream of a workgroup carries the SAME signal, so all 64 close their clusters in the same tile: far more descriptors than
+    the resolver queue holds (64 per tile and workgroup) -- the surplus is resolved in place by the select waves, the result is the
+    oracle's bit for bit."""
+    from haghighatshoarmuir2024_amd.runtime import Plan
+    from scipy.signal import butter
+
+    rng = np.random.default_rng(99)
+    M, B, T = 7, 10, 2500
+    kernel = np.zeros(32)
+    kernel[1::2] = rng.standard_normal(16)
+    b, a = butter(1, [0.05, 0.4], btype="bandpass")
+    one = rng.standard_normal(T)
+    x = np.repeat(np.repeat(one[None, :, None], B, axis=0), M, axis=2)  # [B, T, M]: identical everywhere
+    for w, bipolar in ((12, True), (30, True), (12, False)):
+        p = Plan(M, kernel, b, a, w, bipolar)
+        p.set_encoder_chunk(400)
+        assert p.encoder_chunks(B, T) > 1
+        got = p.snn_pipeline(p.to_device(x), want_spikes=True, want_power=False)["spikes"].cpu().numpy()
+        want = O.snn_chain(x[0], kernel, b, a, w, bipolar, np.ones(1), np.zeros((2 * M, 1)), want=("spikes",))["spikes"]
+        assert np.abs(want).sum() > 50
+        for i in range(B):
+            np.testing.assert_array_equal(got[i], want, err_msg=f"w={w} bipolar={bipolar} trial={i}")
