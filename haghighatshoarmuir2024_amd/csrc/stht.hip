@@ -681,7 +681,7 @@ hipError_t launch_stht(const SthtTaps &tp, const double *x, double *h, int B, in
             const int nstreams = B * M;
             dim3 grid((Ts / 2 + TI - 1) / TI, (nstreams + 15) / 16);
             const size_t lds = stht_mfma_lds(J, ntw);
-            if (!VARIANT_STHT_ONE_TILE && 4 * NK - 16 <= 512) {
+            if (!VARIANT_STHT_ONE_TILE && 4 * NK - 16 <= 512 && (nstreams + 7) / 8 <= 65535) {
                 // the walking form (halos up to 256 rows: four 16-byte copies per thread).  Tiles per workgroup: as many as leave
                 // one workgroup per slot of the chip (512), at most 16 -- a single trial still spreads over its ten tiles, the
                 // sweep's 963 groups walk their ten tiles each.  Measured on the sweep shape (step, ms): 3 / 4 / 5 / 10 tiles per
