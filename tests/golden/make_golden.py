@@ -668,6 +668,148 @@ def gen_synth_xylo():
     save("synth_xylo.npz", **out)
 
 
+def gen_bf_mat_unipolar_hf():
+    """The two remaining design frequencies of config 1 (paper_plots/array_resolution_snn.py:118-146): 3.6 kHz (robust width 3,
+    band [1800, 7200]) and 8 kHz (robust width 1, band [4000, 16000]: every local extremum of the running sum is a spike)."""
+    out = {}
+    for f in (3600, 8000):
+        geometry = CenterCircularArray(radius=4.5e-2, num_mic=7)
+        fs = 48_000
+        tau = 1 / (2 * np.pi * f)
+        beamf = SNNBeamformer(geometry, 10e-3, [f / 2, 2 * f], [tau, tau], bipolar_spikes=False, fs=fs)
+        time_temp = np.arange(0, 0.4, step=1 / fs)
+        sig_temp = np.sin(2 * np.pi * f * time_temp)
+        doa_list = np.linspace(-np.pi, np.pi, 32 * 7 + 1)
+        covs = []
+        orig_svd = np.linalg.svd
+
+        def svd_spy(mat, *a, **k):
+            covs.append(np.array(mat, copy=True))
+            return orig_svd(mat, *a, **k)
+
+        np.linalg.svd = svd_spy
+        try:
+            bf_mat = quiet(beamf.design_from_template, template=(time_temp, sig_temp), doa_list=doa_list)
+        finally:
+            np.linalg.svd = orig_svd
+        assert len(covs) == 225
+        out[f"bf_mat_f{f}"] = bf_mat
+        sel = np.arange(0, 225, 32)
+        out[f"cov_sel_f{f}"] = np.asarray(covs)[sel]
+        out[f"robust_width_f{f}"] = np.int64(beamf.spk_encoder.robust_width)
+        out["cov_idx"] = sel
+        out["doa_list"] = doa_list
+    save("bf_mat_sin225_unipolar_hf.npz", **out)
+
+
+def gen_beamformer_c128_g449():
+    """the complex Beamformer at the sweep's own grid, G = 64*7+1 = 449 (micloc/beamformer.py:73-192 design from the
+    1 s chirp, :194-292 one noisy trial)."""
+    radius, num_mic, fs = 4.5e-2, 7, 48_000
+    freq_design = 2_000
+    freq_range = [0.5 * freq_design, freq_design]
+    geometry = CenterCircularArray(radius=radius, num_mic=num_mic)
+    beamf = Beamformer(geometry=geometry, kernel_duration=10.0e-3, freq_range=freq_range, fs=fs)
+    t, s = chirp_template(fs, freq_range)
+    doa_list = np.linspace(-np.pi, np.pi, 64 * num_mic + 1)
+    bf_mat, cov_list = quiet(beamf.design_from_template, template=(t, s), doa_list=doa_list)
+    time_test = np.arange(0, 100e-3, step=1 / fs)
+    sig_test = np.sin(2 * np.pi * freq_design * time_test)
+    np.random.seed(4490)
+    doa = np.random.rand(1)[0] * 2 * np.pi
+    cap = {}
+    orig = beamf.apply_to_signal
+
+    def spy(bf_mat, sig_in):
+        cap["sig"] = np.array(sig_in, copy=True)
+        return orig(bf_mat=bf_mat, sig_in=sig_in)
+
+    beamf.apply_to_signal = spy
+    try:
+        y = beamf.apply_to_template(bf_mat=bf_mat, template=(time_test, sig_test, doa), snr_db=0.0)
+    finally:
+        del beamf.apply_to_signal
+    power = np.mean(np.abs(y) ** 2, axis=0)
+    row_idx = np.array([0, 1, 239, 240, 241, 1000, 4798])
+    sel = np.arange(0, 449, 64)
+    save("beamformer_c128_g449.npz", bf_mat=bf_mat, cov_sel=np.asarray(cov_list)[sel], cov_idx=sel, doa_list=doa_list, doa=np.float64(doa),
+         seed=np.int64(4490), sig_in=cap["sig"], y_rows=y[row_idx], row_idx=row_idx, power=power, argmax=np.int64(np.argmax(power)),
+         snr_db=np.float64(0.0))
+
+
+def stress_bf_mat(C=128, G=1440, seed=5):
+    """The stress case's seeded unit-norm bf_mat.  Uniform draws and an element-wise column norm: no libm call and no BLAS
+    reduction in it, so tests rebuild the same bits from the seed on any machine (the fixture stores its SHA-256)."""
+    W = np.random.RandomState(seed).random_sample((C, G)) - 0.5
+    return W / np.sqrt(np.add.reduce(W * W, axis=0))
+
+
+def gen_stress_case():
+    """SURVEY 8c.7, BASELINE config 5 at its real shape: Random2DArray(0.2, 64) after np.random.seed(1), 96 kHz (L = 960, robust
+    width 24, 71-tap neuron kernel), G = 1440, one noisy 0.1 s trial: the reference's apply_to_template synthesises the 2 kHz
+    sine at the array and adds noise (its own draw order); the samples are then quantised like a 16-bit converter (steps of
+    2^-12, stored as int16) and that array goes through the reference's apply_to_signal."""
+    import hashlib
+
+    np.random.seed(1)
+    geometry = Random2DArray(radius=0.2, num_mic=64)
+    fs = 96_000
+    fr = [1000.0, 2000.0]
+    tau = 1 / (2 * np.pi * fr[1])
+    beamf = SNNBeamformer(geometry, 10e-3, fr, [tau, tau], bipolar_spikes=True, fs=fs)
+    G = 1440
+    bf_mat = stress_bf_mat(128, G, 5)
+    time_test = np.arange(0, 100e-3, step=1 / fs)
+    sig_test = np.sin(2 * np.pi * 2000 * time_test)
+    doa = 2.2222
+    cap = {}
+
+    def spy(bf_mat, sig_in_vec):
+        cap["time"] = np.array(sig_in_vec[0], copy=True)
+        cap["sig"] = np.array(sig_in_vec[1], copy=True)
+        return np.zeros((1, 1))
+
+    beamf.apply_to_signal = spy
+    try:
+        np.random.seed(64)
+        beamf.apply_to_template(bf_mat=bf_mat, template=(time_test, sig_test, doa), snr_db=0.0)
+    finally:
+        del beamf.apply_to_signal
+    q = np.rint(cap["sig"] * 4096.0)
+    assert np.abs(q).max() < 32768
+    sig_q = q.astype(np.int16)
+    sig = sig_q.astype(np.float64) / 4096.0
+    time_vec = cap["time"]
+    assert sig.shape == (9599, 64)
+    # noise-free synthesis rows of the 64-microphone random array (pins delays + interpolation at this geometry)
+    clean = {}
+
+    def spy2(bf_mat, sig_in_vec):
+        clean["sig"] = np.array(sig_in_vec[1], copy=True)
+        return np.zeros((1, 1))
+
+    beamf.apply_to_signal = spy2
+    try:
+        np.random.seed(64)
+        beamf.apply_to_template(bf_mat=bf_mat, template=(time_test, sig_test, doa), snr_db=3000.0)
+    finally:
+        del beamf.apply_to_signal
+    out = capture_chain(beamf, bf_mat, time_vec, sig)
+    y = out["y"]
+    assert y.shape == (9599, G)
+    power = np.mean(np.abs(y) ** 2, axis=0)
+    row_idx = np.array([0, 479, 480, 481, 5000, 9598])
+    pre_idx = np.concatenate([np.arange(0, 64), np.arange(470, 500), np.arange(950, 1000), np.arange(9599 - 32, 9599)])
+    clean_idx = np.array([0, 1, 50, 100, 1000, 9598])
+    spikes = out["spikes"].astype(np.int8)
+    save("stress_case.npz", r_vec=geometry.r_vec, theta_vec=geometry.theta_vec, fs=np.int64(fs), doa=np.float64(doa), geometry_seed=np.int64(1),
+         noise_seed=np.int64(64), snr_db=np.float64(0.0), bf_seed=np.int64(5), G=np.int64(G),
+         bf_mat_sha256=np.frombuffer(hashlib.sha256(np.ascontiguousarray(bf_mat).tobytes()).digest(), dtype=np.uint8),
+         sig_q=sig_q, sig_scale=np.float64(1 / 4096.0), time_vec=time_vec, spikes=spikes, n_spikes=np.int64((spikes != 0).sum()),
+         pre_enc_rows=out["pre_enc"][pre_idx], pre_idx=pre_idx, power=power, argmax=np.int64(np.argmax(power)), y_rows=y[row_idx], row_idx=row_idx,
+         clean_rows=clean["sig"][clean_idx], clean_idx=clean_idx)
+
+
 GENS = {
     "kat_init": gen_kat_init,
     "bf_mat_chirp": gen_bf_mat_chirp,
@@ -684,6 +826,9 @@ GENS = {
     "sweep_full": gen_sweep_full,
     "speech_sweep": gen_speech_sweep,
     "synth_xylo": gen_synth_xylo,
+    "bf_mat_unipolar_hf": gen_bf_mat_unipolar_hf,
+    "beamformer_c128_g449": gen_beamformer_c128_g449,
+    "stress_case": gen_stress_case,
 }
 
 if __name__ == "__main__":

@@ -24,6 +24,20 @@ def test_geometries_match_reference():
     rnd = Random2DArray(radius=0.2, num_mic=16)
     np.testing.assert_array_equal(rnd.r_vec, k["rand_r"])
     np.testing.assert_array_equal(rnd.theta_vec, k["rand_theta"])
+    # BASELINE config 5's array: 64 microphones after np.random.seed(1) (stress_case.npz, from the reference), and the host
+    # synthesis at that geometry against the reference's noise-free rows
+    zs = golden("stress_case.npz")
+    np.random.seed(int(zs["geometry_seed"]))
+    rnd64 = Random2DArray(radius=0.2, num_mic=64)
+    np.testing.assert_array_equal(rnd64.r_vec, zs["r_vec"])
+    np.testing.assert_array_equal(rnd64.theta_vec, zs["theta_vec"])
+    from haghighatshoarmuir2024_amd.snn_beamformer import synthesize_array_signal
+
+    fs = int(zs["fs"])
+    tt = np.arange(0, 100e-3, step=1 / fs)
+    t64, x64 = synthesize_array_signal(rnd64, fs, tt, np.sin(2 * np.pi * 2000 * tt), float(zs["doa"]))
+    np.testing.assert_array_equal(t64, zs["time_vec"])
+    np.testing.assert_allclose(x64[zs["clean_idx"]], zs["clean_rows"], rtol=0, atol=1e-100)
     for i, th in enumerate(k["thetas"]):
         np.testing.assert_array_equal(g.delays(th, normalized=True), k["ccirc_delays_norm"][i])
         np.testing.assert_array_equal(g.delays(th, normalized=False), k["ccirc_delays_raw"][i])

@@ -195,3 +195,104 @@ def test_filterbank_spike_encoding(cfg2):
     s = O.rzcc(filt, cfg2["robust_width"], True)
     spikes_in = np.hstack([(s > 0), (s < 0)]).astype(np.int8)
     np.testing.assert_array_equal(spikes_in, z["spikes_in"])
+
+
+# ---- round 5: the pins SURVEY 8c still lacked (config 5 at its real shape, the complex Beamformer at G = 449, config 1's
+# ---- 3.6 kHz / 8 kHz designs) -------------------------------------------------------------------------------------------
+def stress_bf_mat(C=128, G=1440, seed=5):
+    """tests/golden/make_golden.py::stress_bf_mat: uniform draws, element-wise column norm -- no libm, no BLAS reduction."""
+    W = np.random.RandomState(seed).random_sample((C, G)) - 0.5
+    return W / np.sqrt(np.add.reduce(W * W, axis=0))
+
+
+def stress_case_inputs():
+    import hashlib
+
+    z = golden("stress_case.npz")
+    fs = int(z["fs"])
+    W = stress_bf_mat(128, int(z["G"]), int(z["bf_seed"]))
+    assert hashlib.sha256(np.ascontiguousarray(W).tobytes()).digest() == z["bf_mat_sha256"].tobytes(), "bf_mat is not the generator's"
+    x = z["sig_q"].astype(np.float64) * float(z["sig_scale"])
+    b, a = O.bandpass(fs, [1000.0, 2000.0])
+    tau = 1 / (2 * np.pi * 2000.0)
+    return dict(z=z, fs=fs, W=W, x=x, b=b, a=a, ker=O.stht_kernel(fs, 10e-3), w=O.robust_width(fs, 2000.0),
+                nir=O.neuron_kernel(z["time_vec"], [tau, tau]))
+
+
+def test_stress_case_config5_real_shape():
+    """BASELINE config 5 at M = 64 / 96 kHz / G = 1440: the oracle against ONE trial of the real reference
+    (ref:micloc/snn_beamformer.py:283-370 on a Random2DArray(0.2, 64) recording)."""
+    s = stress_case_inputs()
+    z, x = s["z"], s["x"]
+    assert x.shape == (9599, 64) and len(s["ker"]) == 960 and s["w"] == 24 and len(s["nir"]) == 71
+    out = O.snn_chain(x, s["ker"], s["b"], s["a"], s["w"], True, s["nir"], s["W"], want=("pre_enc", "spikes", "y", "power"))
+    np.testing.assert_array_equal(out["spikes"], z["spikes"])
+    assert int((out["spikes"] != 0).sum()) == int(z["n_spikes"])
+    np.testing.assert_allclose(out["pre_enc"][z["pre_idx"]], z["pre_enc_rows"], rtol=0, atol=1e-11)
+    np.testing.assert_allclose(out["y"][z["row_idx"]], z["y_rows"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(out["power"], z["power"], rtol=1e-10, atol=0)
+    assert out["argmax"] == int(z["argmax"])
+    # the noise-free synthesis at this geometry (delays of 64 random microphones + np.interp)
+    fs = s["fs"]
+    time_test = np.arange(0, 100e-3, step=1 / fs)
+    t, clean = O.synth_template(z["r_vec"], z["theta_vec"], time_test, np.sin(2 * np.pi * 2000 * time_test), float(z["doa"]), fs)
+    np.testing.assert_array_equal(t, z["time_vec"])
+    np.testing.assert_allclose(clean[z["clean_idx"]], z["clean_rows"], rtol=0, atol=1e-100)
+
+
+def test_beamformer_c128_g449(cfg2):
+    """The complex Beamformer at the sweep's own grid (ref:micloc/beamformer.py:260-292), and the covariances its
+    design decomposes (ref:micloc/beamformer.py:112-150: conj(h)^T h / T' of the un-band-passed STHT output, transient dropped)."""
+    z = golden("beamformer_c128_g449.npz")
+    assert z["bf_mat"].shape == (7, 449) and z["bf_mat"].dtype == np.complex128
+    out = O.beamformer_chain(z["sig_in"], cfg2["kernel"], cfg2["b"], cfg2["a"], z["bf_mat"])
+    np.testing.assert_allclose(out["y"][z["row_idx"]], z["y_rows"], rtol=0, atol=1e-11)
+    np.testing.assert_allclose(out["power"], z["power"], rtol=1e-10)
+    assert out["argmax"] == int(z["argmax"])
+    fs = 48_000
+    t = np.arange(0, 1.0, step=1 / fs)
+    period = t[-1]
+    s = np.sin(2 * np.pi * np.cumsum(1000 + 1000 * (t % period) / period) / fs)
+    tt = np.arange(t.min(), t.max(), step=1 / fs)
+    ss = np.interp(tt, t, s)
+    for k, g in enumerate(z["cov_idx"][:3]):
+        d = O.delays(cfg2["r_vec"], cfg2["theta_vec"], z["doa_list"][g], True)
+        x = np.stack([np.interp(np.maximum(tt - dm, tt.min()), tt, ss) for dm in d], axis=1)
+        re, im = O.stht(x, cfg2["kernel"])
+        h = (re + 1j * im)[min(len(cfg2["kernel"]), x.shape[0] // 2):]
+        np.testing.assert_allclose(h.conj().T @ h / h.shape[0], z["cov_sel"][k], rtol=0, atol=1e-11)
+
+
+@pytest.mark.parametrize("f", [3600, 8000])
+def test_unipolar_design_covariances_high_frequencies(f):
+    """Config 1's designs at 3.6 kHz (robust width 3) and 8 kHz (robust width 1: every extremum of the running sum is a spike)
+    (ref:paper_plots/array_resolution_snn.py:118-146, ref:micloc/snn_beamformer.py:139-191): the oracle's chain on the delayed
+    template gives the covariance the reference decomposes; its secular-equation vector then equals the reference's column."""
+    z = golden("bf_mat_sin225_unipolar_hf.npz")
+    k = golden("kat_init.npz")
+    fs = 48_000
+    w = O.robust_width(fs, 2 * f)
+    assert w == int(z[f"robust_width_f{f}"]) == {3600: 3, 8000: 1}[f]
+    b, a = O.bandpass(fs, [f / 2, 2 * f])
+    ker = O.stht_kernel(fs, 10e-3)
+    tau = 1 / (2 * np.pi * f)
+    t = np.arange(0, 0.4, step=1 / fs)
+    tt = np.arange(t.min(), t.max(), step=1 / fs)
+    ss = np.interp(tt, t, np.sin(2 * np.pi * f * t))
+    nir = O.neuron_kernel(tt, [tau, tau])
+    for j, g in enumerate(z["cov_idx"][:4]):
+        d = O.delays(k["ccirc_r"], k["ccirc_theta"], z["doa_list"][g], True)
+        x = np.stack([np.interp(np.maximum(tt - dm, tt.min()), tt, ss) for dm in d], axis=1)
+        v = O.snn_chain(x, ker, b, a, w, False, nir, np.eye(14), want=("vmem",))["vmem"]
+        v = v[len(tt) // 4:]
+        C = v.T @ v / v.shape[0]
+        np.testing.assert_allclose(C, z[f"cov_sel_f{f}"][j], rtol=0, atol=1e-12)
+        # the conditional singular vector (ref:micloc/snn_beamformer.py:372-422) of that covariance
+        U, D, _ = np.linalg.svd(C)
+        theta = U.T @ np.ones(14)
+        lo, hi = D[1], D[0]
+        while (hi - lo) / lo >= 1e-8:
+            mid = (lo + hi) / 2
+            lo, hi = (mid, hi) if np.sum(theta**2 / (D - mid)) < 0.0 else (lo, mid)
+        vec = U @ (theta / (D - (lo + hi) / 2))
+        np.testing.assert_allclose(vec / np.linalg.norm(vec), z[f"bf_mat_f{f}"][:, g], rtol=0, atol=1e-7)
