@@ -348,9 +348,12 @@ int micloc_stream_create_cu_range(int device, int cu_lo, int cu_hi, void **strea
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return MICLOC_ERR_INVALID;
     // gfx950: 8 XCDs; bit i of the mask is compute unit i / 8 of XCD i % 8 (measured: tools/dev/cu_mask_probe.hip), and an XCD
     // whose bits are all clear is NOT excluded -- it runs the stream on all of its compute units -- so a range is given per XCD
+    // The layout was measured on the unpartitioned device (SPX: 256 compute units in 8 XCDs) and holds for that only: a partition
+    // (CPX: 32 compute units, one XCD) has the same arch name and a mask that means something else -- refuse, callers fall back to
+    // ordinary streams (runtime.StreamPipeline / sweep: scan_lane = 0).
     constexpr int NXCD = 8;
     const int ncu = prop.multiProcessorCount;
-    if (ncu <= 0 || ncu % NXCD) return MICLOC_ERR_INVALID;
+    if (ncu != 256) return MICLOC_ERR_INVALID;
     const int per = ncu / NXCD;
     if (cu_lo < 0 || cu_hi > per || cu_lo >= cu_hi) return MICLOC_ERR_INVALID;
     std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);

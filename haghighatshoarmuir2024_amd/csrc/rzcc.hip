@@ -908,7 +908,10 @@ __global__ __launch_bounds__(WRITER ? 512 : 448, (WANT_PRE && WANT_SPIKES) ? 2 :
                 const int tloc = (m_lo + m) * RZ_MT;  // local time of the tile: input indexing and the ragged end
                 const int tbase = tloc + tb0;         // absolute time: candidate positions
                 const int steps = (T - tloc) < RZ_MT ? (T - tloc) : RZ_MT;
-                // Ring space for a whole tile of appends?  oldPub lags by one barrier and only grows: conservative.
+                // Ring space for a whole tile of appends?  oldPub may be the value a select wave published before the last barrier or
+                // the one it is publishing during this step (no ordering between the two waves inside a step): either is a lower bound
+                // of what the select waves AND the resolver wave still read -- the select waves keep a queued cluster protected through
+                // two publications (pend_prev below), i.e. until the barrier behind the resolver's pass over it.
                 {
                     const int o0 = oldPub[0][lane], o1 = oldPub[1][lane];
                     const int oldest = bipolar ? (o0 < o1 ? o0 : o1) : o0;
@@ -1108,6 +1111,9 @@ __global__ __launch_bounds__(WRITER ? 512 : 448, (WANT_PRE && WANT_SPIKES) ? 2 :
             const int n = nPub[lane];  // candidates published by the detect wave before the last barrier
             if (ovPub[lane]) dead = true;
             qbuf = RESOLVER ? (k & 1) : -1;
+            // the clusters queued during the previous tile are read by the resolver wave during THIS one: they stay protected in this
+            // step's publication too (the detect wave may already see it at the top of this very step)
+            const int pend_prev = pend_lo;
             pend_lo = 0x7fffffff;
             if (i_next < 0 && n > 0) i_next = bipolar ? (polPub[lane] ^ mypol) : 0;
             // one candidate per lane and trip.  (Fetching the words of the next four candidates up front was measured and
@@ -1132,8 +1138,9 @@ __global__ __launch_bounds__(WRITER ? 512 : 448, (WANT_PRE && WANT_SPIKES) ? 2 :
             // everything from the open cluster on must survive in the ring; without one, everything not yet examined -- and what the
             // resolver wave reads during the next tile
             {
-                const int keep = s_open >= 0 ? s_open : (i_next >= 0 ? i_next : 0);
-                oldPub[mypol][lane] = dead ? 0x7fffffff : (pend_lo < keep ? pend_lo : keep);
+                int keep = s_open >= 0 ? s_open : (i_next >= 0 ? i_next : 0);
+                keep = pend_lo < keep ? pend_lo : keep;
+                oldPub[mypol][lane] = dead ? 0x7fffffff : (pend_prev < keep ? pend_prev : keep);
             }
             qbuf = -1;
         }

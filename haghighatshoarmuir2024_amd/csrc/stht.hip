@@ -599,8 +599,11 @@ __global__ __launch_bounds__(SM_THREADS, 4) void stht_walk_kernel(const double *
         }
         if (!more) break;
         __builtin_amdgcn_sched_barrier(0);
-        // slide: the newest HR rows become the halo (source rows [TI, R), destination rows [0, HR): disjoint as HR <= TI, so the
-        // copy needs no barrier of its own); the new rows overwrite [HR, R) once every wave has finished reading
+        // slide: the newest HR rows become the halo (source rows [TI, R), destination rows [0, HR)).  The two ranges OVERLAP whenever
+        // HR > TI (the 480-tap instantiation: HR = 480, TI = 128); the copy is correct because every thread reads ALL of its NCP pairs
+        // into registers before the barrier below and writes them behind it -- do not turn it into an LDS-to-LDS copy or drop the
+        // barrier.  (The launcher guarantees NCP * SM_THREADS >= 8 * HR: every pair of the halo has a thread.)  The new rows overwrite
+        // [HR, R) once every wave has finished reading.
         const int ncopy = HR * 8;  // 16-byte pairs: at most NCP per thread (the launcher's choice)
         double2_t hc[NCP];
 #pragma unroll
@@ -692,6 +695,8 @@ hipError_t launch_stht(const SthtTaps &tp, const double *x, double *h, int B, in
                 tpw = tpw < 1 ? 1 : (tpw > 16 ? 16 : tpw);
                 tpw = tpw > ntile ? ntile : tpw;
                 const bool wide = 4 * NK - 16 > 256;  // (J = 480, the 96 kHz kernel: 480 halo rows, one tile per wave)
+                // the slide copies the halo through registers, NCP 16-byte pairs per thread: every pair needs a thread
+                if ((4 * NK - 16) * 8 > (wide ? 8 : 4) * SM_THREADS) return hipErrorInvalidValue;
                 auto kw = ntw == 2 ? (NK == 64 ? &stht_walk_kernel<2, 64, 4> : (wide ? &stht_walk_kernel<2, 0, 8> : &stht_walk_kernel<2, 0, 4>))
                                    : (wide ? &stht_walk_kernel<1, 0, 8> : &stht_walk_kernel<1, 0, 4>);
                 hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kw), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

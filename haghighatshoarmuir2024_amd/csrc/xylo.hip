@@ -455,8 +455,11 @@ __global__ __launch_bounds__(XP_WAVES * 64) void xylo_lif_pk_kernel(const int8_t
                 __syncthreads();
                 if (tid == 0) __hip_atomic_store(&qctl[XQ_CTL + b], chunk + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
             } else {
-                if (act0) rate[(size_t)b * N + n0] = total0;
-                if (act1) rate[(size_t)b * N + n1] = total1;
+                // a worker that gave up waiting (never seen) went on from an unwritten state: whatever is finished after that is marked,
+                // not returned as plausible counts (the host side raises at its next synchronisation point, XyloNetwork.check)
+                const bool broken = __hip_atomic_load(&qctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+                if (act0) rate[(size_t)b * N + n0] = broken ? -1 : total0;
+                if (act1) rate[(size_t)b * N + n1] = broken ? -1 : total1;
             }
         }
     }

@@ -30,33 +30,56 @@ def doa_error(doa_est, doa_true):
     return np.arcsin(np.abs(np.sin(doa_est - doa_true)))
 
 
-def gather_shards(local, total, rank, world_size, group=None, bounds=None):
-    """All-gather equal-dtype 1-d arrays from contiguous shards; returns the full-length arrays on every rank.
-    `local` is a dict name -> 1-d numpy array (this rank's shard).  Uses torch.distributed when world_size > 1.
-    `bounds(r) -> (lo, hi)` overrides the default `shard_range(total, r, world_size)` partition."""
+def gather_shards(local, total, rank, world_size, group=None, bounds=None, stats=None):
+    """The sweep's one exchange step: all-gather the per-trial result arrays of contiguous shards; returns the
+    full-length arrays on every rank.  `local` is a dict name -> 1-d numpy array (this rank's shard; any mix of dtypes).
+    ONE collective whatever the number of arrays: every rank packs its arrays into a struct-of-arrays byte record (each array
+    padded to the widest shard and to 8 bytes), one `all_gather_into_tensor` moves the records (RCCL over xGMI when the group is
+    "nccl": one host -> device copy, one collective, one device -> host copy), every rank unpacks.  `bounds(r) -> (lo, hi)`
+    overrides the default `shard_range(total, r, world_size)` partition.  `stats` (a dict, optional) receives `exchange_ms` (wall
+    time of pack + collective + unpack), `bytes_per_rank` and `collectives`."""
+    import time
+
     if bounds is None:
         bounds = lambda r: shard_range(total, r, world_size)  # noqa: E731
     if world_size == 1:
+        if stats is not None:
+            stats.update(exchange_ms=0.0, bytes_per_rank=0, collectives=0)
         return {k: np.asarray(v) for k, v in local.items()}
     import torch
     import torch.distributed as dist
 
+    t0 = time.perf_counter()
     backend = dist.get_backend(group)
     dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
-    width = max(bounds(r)[1] - bounds(r)[0] for r in range(world_size))  # padded shard length
+    spans = [bounds(r) for r in range(world_size)]
+    width = max(hi - lo for lo, hi in spans)  # padded shard length (items)
+    keys = list(local)
+    arrs = {k: np.ascontiguousarray(local[k]) for k in keys}
+    n_local = spans[rank][1] - spans[rank][0]
+    for k in keys:
+        if arrs[k].ndim != 1 or len(arrs[k]) != n_local:
+            raise ValueError(f"gather_shards: '{k}' has shape {arrs[k].shape}, this rank's shard holds {n_local} items")
+    # record layout: the arrays one behind the other, each `width` items of its dtype, 8-byte aligned
+    offs, off = {}, 0
+    for k in keys:
+        offs[k] = off
+        off += (width * arrs[k].dtype.itemsize + 7) & ~7
+    rec = np.zeros(max(off, 8), dtype=np.uint8)
+    for k in keys:
+        v = arrs[k]
+        rec[offs[k] : offs[k] + v.nbytes] = v.view(np.uint8)
+    buf = torch.from_numpy(rec).to(dev)
+    full = torch.empty(len(rec) * world_size, dtype=torch.uint8, device=dev)
+    dist.all_gather_into_tensor(full, buf, group=group)
+    full = full.cpu().numpy().reshape(world_size, len(rec))
     out = {}
-    for k, v in local.items():
-        v = np.asarray(v)
-        buf = torch.zeros(width, dtype=torch.from_numpy(v[:0].copy()).dtype, device=dev)
-        buf[: len(v)] = torch.from_numpy(np.ascontiguousarray(v)).to(dev)
-        full = torch.empty(width * world_size, dtype=buf.dtype, device=dev)
-        dist.all_gather_into_tensor(full, buf, group=group)
-        full = full.cpu().numpy().reshape(world_size, width)
-        parts = []
-        for r in range(world_size):
-            lo, hi = bounds(r)
-            parts.append(full[r, : hi - lo])
+    for k in keys:
+        dt = arrs[k].dtype
+        parts = [full[r, offs[k] : offs[k] + (hi - lo) * dt.itemsize].view(dt) for r, (lo, hi) in enumerate(spans)]
         out[k] = np.concatenate(parts)
+    if stats is not None:
+        stats.update(exchange_ms=(time.perf_counter() - t0) * 1e3, bytes_per_rank=int(len(rec)), collectives=1)
     return out
 
 
@@ -122,7 +145,12 @@ def _throughput_pipelined(beamf, bf_mat, time_test, sig_test, doa_all, snr_db_tr
     G = plans[0].G
     Bmax = min(batch_trials, hi - lo)
     chunked = plans[0].encoder_chunks(Bmax, T) > 1
-    pipe = runtime.StreamPipeline(plans, scan_lane=scan_lane_cus if (chunked and nplans > 1) else 0)
+    try:
+        pipe = runtime.StreamPipeline(plans, scan_lane=scan_lane_cus if (chunked and nplans > 1) else 0)
+    except (ValueError, RuntimeError):  # (MiclocError is a RuntimeError)
+        # no compute-unit masks here (a partitioned device, fewer compute units per XCD than the lane wants, a driver that refuses
+        # them): ordinary streams -- slower on long recordings, the same results
+        pipe = runtime.StreamPipeline(plans, scan_lane=0)
     # per plan: input batch and noise workspace (a batch in flight owns them until its stream has moved on); per batch: result rows
     xs = [torch.empty((Bmax, T, M), dtype=torch.float64, device=dev) for _ in plans]
     wss = [runtime.awgn_workspace(Bmax, T, M, dev) for _ in plans]
@@ -218,11 +246,13 @@ def _template_sweep(beamf, bf_mat, doa_list, time_test, sig_test, snr_db_trial, 
 
     argmax = np.concatenate(argmax_parts) if argmax_parts else np.zeros(0, dtype=np.int64)
     pmax = np.concatenate(pmax_parts) if pmax_parts else np.zeros(0)
-    full = gather_shards({"argmax": argmax, "pmax": pmax}, total, rank, world_size, group)
+    # the one exchange step: {argmax i64, pmax f64} per trial in ONE all-gather (the DoAs come from the shared stream: every rank has them)
+    exchange = {}
+    full = gather_shards({"argmax": argmax, "pmax": pmax}, total, rank, world_size, group, stats=exchange)
     err = doa_error(np.asarray(doa_list)[full["argmax"]], doa_all)
     shape = (total // num_sim, num_sim)
     return dict(doa=doa_all.reshape(shape), argmax=full["argmax"].reshape(shape), pmax=full["pmax"].reshape(shape), err=err.reshape(shape),
-                mae_deg=np.mean(err.reshape(shape), axis=1) * 180 / np.pi)
+                mae_deg=np.mean(err.reshape(shape), axis=1) * 180 / np.pi, exchange=exchange)
 
 
 def noisy_target_sweep(beamf, bf_mat, doa_list, snr_db_vec=None, num_sim=100, seed=0, mode="parity", rank=0, world_size=1,
@@ -319,8 +349,10 @@ def xylo_target_sweep(demo, snr_db_vec=None, num_sim=100, seed=0, mode="parity",
     def flush(x):
         if peak == "device":  # find_peak_location on the device (exact integer window sums): only indices come back
             idx_parts.extend(int(v) for v in demo.peak_batch(x, win_size).cpu().numpy())
+            demo.network().check()  # (the copy above synchronised: a broken ticket-queue launch raises here)
             return
         rate = demo.rate_batch(x).cpu().numpy()  # [B, G]: mean(spikes_out) * fs per DoA
+        demo.network().check()
         for p in rate:
             mx = p.max()
             p = p / mx if mx > 0 else p  # :595 (an all-silent output divides 0 by 0 in the reference)

@@ -123,6 +123,7 @@ class XyloNetwork:
         ds = np.ascontiguousarray(spec["dash_syn"], dtype=np.uint8)
         dm = np.ascontiguousarray(spec["dash_mem"], dtype=np.uint8)
         th = np.ascontiguousarray(spec["threshold"], dtype=np.int16)
+        self.last_scratch = None
         self.nbytes = self.lib.micloc_xylo_workspace_bytes(self.Cin, self.N)
         self.ws = torch.empty(int(self.nbytes), dtype=torch.uint8, device=self.device)
         vp = ctypes.c_void_p
@@ -162,6 +163,12 @@ class XyloNetwork:
         st = (ctypes.c_int * 2)()
         _lib.check(self.lib.micloc_xylo_sweep_status(runtime._ptr(self.last_scratch), st, runtime._stream(self.device)), "xylo_sweep_status")
         return dict(tickets=int(st[0]), gave_up=int(st[1]))
+
+    def check(self):
+        """Raise if a worker of the last ticket-queue launch gave up waiting for its predecessor (a broken launch: its counts are
+        marked -1, never plausible numbers).  Synchronises; callers use it where they synchronise anyway (results to the host)."""
+        if getattr(self, "last_scratch", None) is not None and self.queue_status()["gave_up"]:
+            raise _lib.MiclocError("xylo ticket queue: a worker gave up waiting for its predecessor's state; the counts of this launch are invalid")
 
 
 class Demo:

@@ -83,6 +83,9 @@ def test_gather_shards_uneven_world3(tmp_path):
         got = np.load(tmp_path / f"g{r}.npz")
         np.testing.assert_array_equal(got["a"], np.arange(7) * 10)
         np.testing.assert_array_equal(got["b"], np.arange(7) * 0.5)
+        np.testing.assert_array_equal(got["c"], np.arange(7, dtype=np.int32) - 3)
+        np.testing.assert_array_equal(got["d"], (np.arange(7) % 3).astype(np.int8))
+        assert got["c"].dtype == np.int32 and got["d"].dtype == np.int8
 
 
 def _gather_worker(rank, world, port, out_dir):
@@ -96,7 +99,11 @@ def _gather_worker(rank, world, port, out_dir):
 
     dist.init_process_group("gloo", rank=rank, world_size=world)
     lo, hi = shard_range(7, rank, world)
-    full = gather_shards({"a": np.arange(lo, hi, dtype=np.int64) * 10, "b": np.arange(lo, hi, dtype=np.float64) * 0.5}, 7, rank, world)
+    stats = {}
+    full = gather_shards({"a": np.arange(lo, hi, dtype=np.int64) * 10, "b": np.arange(lo, hi, dtype=np.float64) * 0.5,
+                          "c": np.arange(lo, hi, dtype=np.int32) - 3, "d": (np.arange(lo, hi) % 3).astype(np.int8)}, 7, rank, world, stats=stats)
+    # ONE collective for all four arrays: a record of 3 items per array (the widest shard), each array padded to 8 bytes
+    assert stats["collectives"] == 1 and stats["bytes_per_rank"] == 24 + 24 + 16 + 8 and stats["exchange_ms"] > 0
     np.savez(os.path.join(out_dir, f"g{rank}.npz"), **full)
     dist.barrier()
     dist.destroy_process_group()

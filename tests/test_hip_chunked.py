@@ -277,3 +277,34 @@ def test_resolver_queue_overflow_falls_back_in_place(torch):
         assert np.abs(want).sum() > 50
         for i in range(B):
             np.testing.assert_array_equal(got[i], want, err_msg=f"w={w} bipolar={bipolar} trial={i}")
+
+
+@pytest.mark.parametrize("w", [5, 8, 12])
+def test_resolver_under_ring_pressure(torch, w):
+    """Bursts of alternating increments (a candidate every other sample: four to eight per polarity and burst -- the clusters the
+    resolver wave takes) separated by monotone runs a little longer than w, so that clusters close tile after tile while the detect
+    wave keeps appending a full tile of candidates: the candidate ring runs close to full with queued clusters in it.  A cluster queued
+    in tile k is read by the resolver wave during tile k + 1; the select waves must keep it protected in BOTH publications of the
+    oldest needed entry the detect wave can see during that tile (the second one used to drop it).  Spikes == oracle."""
+    from haghighatshoarmuir2024_amd import runtime
+
+    rng = np.random.default_rng(500 + w)
+    B, T, C = 6, 6000, 32
+    x = np.empty((B, T, C))
+    for b in range(B):
+        for c in range(C):
+            parts, n = [], 0
+            while n < T:
+                L = int(rng.integers(8, 17))  # burst: L alternating increments
+                burst = (0.5 + rng.random(L)) * np.where(np.arange(L) % 2 == 0, 1.0, -1.0) * (1 if rng.random() < 0.5 else -1)
+                q = w + int(rng.integers(0, 4))  # quiet run: the sum moves one way, no candidate for q steps
+                quiet = (0.05 + 0.1 * rng.random(q)) * (1 if rng.random() < 0.5 else -1)
+                parts += [burst, quiet]
+                n += L + q
+            x[b, :, c] = np.concatenate(parts)[:T]
+    for bipolar in (True, False):
+        want = np.stack([O.rzcc(x[b], w, bipolar) for b in range(B)])
+        assert np.abs(want).sum() > 1000
+        for chunk in (400, 1008):
+            got = runtime.rzcc_encode(x, w, bipolar, chunk_frames=chunk).cpu().numpy()
+            np.testing.assert_array_equal(got, want, err_msg=f"w={w} bipolar={bipolar} chunk={chunk}")
