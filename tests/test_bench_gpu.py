@@ -19,7 +19,7 @@ def _run(extra, env_extra):
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         env.pop(k, None)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--repeats", "2", "--no-cpu-baseline",
-                        "--no-other-configs"] + extra, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, env=env)
+                        "--no-other-configs", "--sustained-seconds", "0.4"] + extra, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, env=env)
     assert p.returncode == 0, p.stderr.decode(errors="replace")[-2000:]
     lines = [ln for ln in p.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
     assert lines, p.stdout.decode(errors="replace")[-2000:]
@@ -38,7 +38,33 @@ def test_bench_rccl_one_rank_group_and_contract():
     assert r["bound"] == "mfma" and r["kernel"] == "beamform_ws_kernel" and 0.3 < r["frac"] < 1.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert len(d["mae_deg_per_snr"]) == 11 and d["mae_deg_per_snr"][0] > d["mae_deg_per_snr"][-1]
+    # SURVEY 8d's clock beside the driver's, inside `config`; the sustained region beside the K-step regions
+    assert d["config"]["value_e2e"] == d["value_e2e"] and d["config"]["e2e_ms_per_step"] > d["ms_per_step"] * 0.9
+    sus = d["sustained"]
+    assert sus["seconds"] >= 0.4 and sus["steps"] >= 4 * sus["segment_steps"] and len(sus["ms_per_step_segments"]) >= 4
+    assert abs(sus["ms_per_step"] - sus["seconds"] / sus["steps"] * 1e3) < 1e-9 and "value_source" in d
+    assert sus["telemetry_source"].startswith("amdsmi"), sus["telemetry_source"]  # the GPU box lets an ordinary user read the clocks
+    tw = sus["telemetry"]["whole"]
+    assert tw and 500 <= tw["sclk_mhz_mean"] <= 2600 and 50 < tw["socket_w_mean"] < 1500
+    # the exchange step: ONE all_gather_into_tensor of {doa, p_max, argmax} per trial, timed; the MAE recomputed from the gathered
+    # trials on the host is the device's (micloc_doa_error_f64) -- same arithmetic, another summation order
+    ex = d["exchange"]
+    assert ex["collectives"] == 1 and ex["bytes_per_rank"] == 3 * 8 * d["config"]["trials_per_gpu"] and d["exchange_ms"] == ex["exchange_ms"] > 0
+    assert max(abs(a - b) for a, b in zip(ex["mae_deg_per_snr_from_gathered_trials"], ex["mae_deg_per_snr_device_same_batch"])) < 1e-9
+    assert len(d["config"]["device_uuid_per_rank"]) == 1 and len(d["ms_per_step_per_rank"]) == 1
     # the same run without a process group gives the same contract and rccl_ranks == 0
     d0 = _run([], {})
     assert d0["rccl_ranks"] == 0 and d0["n_gpus"] == 1
     assert d0["mae_deg_per_snr"] == d["mae_deg_per_snr"]  # same batch, same arithmetic, gathered or not
+
+
+def test_bench_stress_share_of_baseline_total_under_rccl():
+    """BASELINE config 5 the way the 8-GPU run starts it (--config stress --baseline-total; here 64 trials on one rank): the general
+    beamforming kernel, the strong-scaling bookkeeping and the exchange step under a one-rank RCCL group."""
+    d = _run(["--config", "stress", "--baseline-total", "--trials", "64", "--sustained-seconds", "0"], {"MICLOC_FORCE_DIST": "1"})
+    assert d["rccl_ranks"] == 1 and d["n_gpus"] == 1 and d["scaling"] == "strong"
+    c = d["config"]
+    assert c["trials_per_gpu"] == 64 and c["num_mic"] == 64 and c["num_doa"] == 1440 and c["frames_per_trial"] == 9599
+    assert d["roofline"]["kernel"] == "beamform_gen_kernel" and 0.3 < d["roofline"]["frac"] < 1.0
+    assert d["exchange"]["collectives"] == 1 and d["exchange_ms"] > 0 and len(d["ms_per_step_per_rank"]) == 1
+    assert len(c["device_uuid_per_rank"]) == 1 and "sustained" not in d

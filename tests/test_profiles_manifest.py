@@ -1,0 +1,70 @@
+"""profiles/rNN/MANIFEST.json (round 5 on): every committed profile file names the commit, box and command it came from, and the
+recorded source hashes really are that commit's files -- so a number quoted from profiles/ can be tied to the kernels that produced
+it, and bench.py's committed-profile fallback for `roofline.traffic` can refuse a stale summary (CPU only; needs the git history)."""
+import glob
+import hashlib
+import json
+import os
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+
+def _manifests():
+    return sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "MANIFEST.json")))
+
+
+def test_manifest_tool_records_sources(tmp_path):
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_manifest
+
+    rels = make_manifest.tracked_sources()
+    assert "haghighatshoarmuir2024_amd/csrc/beamform.hip" in rels and "bench.py" in rels
+    make_manifest.record_sources(str(tmp_path))
+    src = json.load(open(tmp_path / "SOURCES.json"))
+    assert src["bench.py"] == hashlib.sha256(open(os.path.join(ROOT, "bench.py"), "rb").read()).hexdigest()
+    assert "host" in json.load(open(tmp_path / "BOX.json"))
+
+
+def test_bench_refuses_a_profile_without_a_matching_manifest_entry():
+    import sys
+
+    sys.path.insert(0, ROOT)
+    import bench
+
+    # round 4's summary has no manifest: its traffic figure may be read, but bench.py's fallback does not accept it
+    assert bench.manifest_entry("profiles/r4/pmc_summary.csv") is None
+    assert bench.source_sha256("haghighatshoarmuir2024_amd/csrc/beamform.hip") is not None
+    assert bench.source_sha256("no/such/file") is None
+
+
+@pytest.mark.parametrize("mpath", _manifests() or [None])
+def test_every_profile_file_is_tied_to_a_commit(mpath):
+    if mpath is None:
+        pytest.skip("no profiles/r*/MANIFEST.json yet")
+    man = json.load(open(mpath))
+    d = os.path.dirname(mpath)
+    listed = set(man["files"])
+    present = {f for f in os.listdir(d) if os.path.isfile(os.path.join(d, f)) and f != "MANIFEST.json"}
+    assert present <= listed, f"files without a manifest entry: {sorted(present - listed)}"
+    have_git = os.path.isdir(os.path.join(ROOT, ".git"))
+    for f, e in man["files"].items():
+        assert e["command"] and e["box"].get("host"), f
+        assert e["git_sha"], f"{f}: taken on uncommitted sources {e.get('uncommitted_sources')}"
+        if have_git:
+            rc = subprocess.run(["git", "-C", ROOT, "merge-base", "--is-ancestor", e["git_sha"], "HEAD"]).returncode
+            assert rc == 0, f"{f}: {e['git_sha']} is not an ancestor of HEAD"
+    if have_git:
+        # spot-check one entry per distinct commit: the recorded hashes are that commit's files
+        seen = set()
+        for f, e in man["files"].items():
+            if e["git_sha"] in seen:
+                continue
+            seen.add(e["git_sha"])
+            for rel, h in e["sources_sha256"].items():
+                blob = subprocess.run(["git", "-C", ROOT, "show", f"{e['git_sha']}:{rel}"], stdout=subprocess.PIPE).stdout
+                assert hashlib.sha256(blob).hexdigest() == h, (f, rel)
