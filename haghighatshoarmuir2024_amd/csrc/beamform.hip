@@ -359,10 +359,11 @@ __device__ __forceinline__ void ws_stage2_y(const double *Vl, const double *__re
 // wave; the double-buffered form takes 100 and runs two per CU: 1.13 against 1.07 ms per launch, step 1.63 against 1.59 ms).
 // Four DoA tiles per wave (G > 384) do not fit 80 registers and run as two passes of two.
 constexpr int WS_KV_WAVES = 6;
-template <int NGW, int NT, bool WANT_Y, int KM, int KV>
+// SPARSE: the LIF stage event by event on the vector ALU instead of as a dense Toeplitz product on the matrix cores (below).
+template <int NGW, int NT, bool WANT_Y, int KM, int KV, bool SPARSE = false>
 __global__ __launch_bounds__(BF_THREADS, WANT_Y ? 2 : (KV ? WS_KV_WAVES : (NT == 2 ? 6 : 4))) void beamform_ws_kernel(
     const int8_t *__restrict__ spikes, const double *__restrict__ ntab_g, int NK, const double *__restrict__ Wp, int GT, int C,
-    int T, double *__restrict__ partial, int G, double *__restrict__ y, const int *__restrict__ chunk_range)
+    int T, double *__restrict__ partial, int G, double *__restrict__ y, const int *__restrict__ chunk_range, int n_nir)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int Gp = 16 * GT;
@@ -380,6 +381,140 @@ __global__ __launch_bounds__(BF_THREADS, WANT_Y ? 2 : (KV ? WS_KV_WAVES : (NT ==
     constexpr int TILES = CH / 16;
     const int cs = chunk * CH;
 
+    if constexpr (SPARSE) {
+        // ---- event-driven LIF (round 5) ----------------------------------------------------------------------------------------------
+        // vmem[t][c] = sum_tau nir[tau] s[t - tau][c] is a sum over the SPIKES of the last n frames: the encoder keeps 7 % of the raster
+        // (two polarities, at least `robust_width` frames apart each), so of the 35 products per output that the Toeplitz form multiplies
+        // on the matrix cores (13 k-steps x 16 channel rows: 0.11 ms of the launch's 0.70 ms of matrix pipe) 2.4 are not zero.  A product
+        // with a zero spike leaves the fma chain's accumulator untouched (acc + (+-0) == acc, and acc is never -0), so skipping them is
+        // exact: the chain below visits the spikes of the window in chronological order -- the order of the oracle's tau-descending
+        // chain -- and adds sign * nir[t - s] with one fma each: the same bits as the dense product.
+        // A unit = one channel x 64 consecutive frames, lane = frame.  The unit's spikes (rows [f0 - H, f0 + 63] of the channel: two
+        // byte loads per lane from the TRANSPOSED int8 tile, two ballots) are walked on the scalar unit; per spike every lane reads
+        // nir[lane + H - j] from a zero-padded table (one LDS read at a per-lane base minus 8 j) and adds it -- two vector
+        // instructions per spike instead of 26 matrix instructions per wave, no int8 -> fp64 conversion while staging, one barrier less.
+        //   LDS: [ V fragments [tiles][256] ][ nir table, 126 + n ][ int8 tile [channel][RS] ]
+        const int H = n_nir - 1;  // frames of history a membrane value depends on (n <= 65: two ballot words cover 64 + H rows)
+        const int R = CH + H;
+        int RS4 = (R + 3) / 4 + 1;
+        RS4 |= 1;  // odd number of dwords per channel row: the 16 channels of a staged frame land in 16 different banks
+        const int RS = 4 * RS4;
+        double *Vl = reinterpret_cast<double *>(smem);
+        double *Pt = Vl + TILES * 256;
+        int8_t *Sb = reinterpret_cast<int8_t *>(Pt + 126 + n_nir);
+        constexpr int CPAD = (KM == 4 && KV == 0) ? 16 : 4 * KM + KV;  // channels stage 2 reads (rows >= C must be zero)
+        for (int e = tid; e < 126 + n_nir; e += BF_THREADS) Pt[e] = (e >= 63 && e < 63 + n_nir) ? ntab_g[e - 48] : 0.0;  // Pt[i] = nir[i - 63]
+        {
+            const int8_t *sb = spikes + (size_t)b * (chunk_range ? chunk_range[3] : T) * C;
+            const int tau0 = cs - H;
+            const int c = tid & 15;
+            constexpr int RP = BF_THREADS / 16;
+            const int rr = tid >> 4;
+            if (c < C) {
+                int8_t *d = Sb + c * RS;
+                if (tau0 >= 0 && tau0 + R <= T) {
+                    const int8_t *p = sb + (size_t)(tau0 + rr) * C + c;
+                    int rho = rr;
+                    for (; rho + 5 * RP < R; rho += 6 * RP) {
+                        int8_t v[6];
+#pragma unroll
+                        for (int i = 0; i < 6; ++i) v[i] = p[(size_t)i * RP * C];
+#pragma unroll
+                        for (int i = 0; i < 6; ++i) d[rho + i * RP] = v[i];
+                        p += (size_t)6 * RP * C;
+                    }
+                    for (; rho < R; rho += RP) {
+                        d[rho] = *p;
+                        p += (size_t)RP * C;
+                    }
+                } else {
+                    for (int rho = rr; rho < R; rho += RP) {
+                        const int tau = tau0 + rho;
+                        d[rho] = (tau >= 0 && tau < T) ? sb[(size_t)tau * C + c] : (int8_t)0;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        constexpr int NB = CH / 64;
+        static_assert(CH % 64 == 0, "a unit is 64 frames");
+        // A wave's units are walked TOGETHER, one spike of every unit per round: NU independent LDS reads in flight, then NU fmas (a
+        // unit alone is a chain of read -> add -> read: ~130 cycles per spike, 8 000 per wave, and a workgroup's stage 2 cannot start
+        // before its slowest wave is through).  A unit that has run out of spikes keeps issuing with a zero factor (acc + 0 * nir ==
+        // acc exactly) so that the round is straight-line code; the loop ends when every unit's masks are empty.
+        constexpr int NU = (CPAD * NB + BF_WAVES - 1) / BF_WAVES;
+        const char *pl = reinterpret_cast<const char *>(Pt) + 8 * (l + H + 63);
+        unsigned long long m0[NU], m1[NU], g0[NU], g1[NU];
+        int bv0[NU], bv1[NU];
+        double acc[NU];
+        bool ternary = true;
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+            const int u = wv + BF_WAVES * i;
+            const int c = u / NB, blk = u - c * NB;
+            const bool live = u < CPAD * NB && c < C && cs + 64 * blk < T;  // (wave-uniform)
+            const int8_t *row = Sb + (live ? c : 0) * RS + 64 * blk;
+            const int b0 = live ? row[l] : 0;
+            const int b1 = (live && l < H) ? row[64 + l] : 0;
+            bv0[i] = b0;
+            bv1[i] = b1;
+            m0[i] = __builtin_amdgcn_ballot_w64(b0 != 0);
+            m1[i] = __builtin_amdgcn_ballot_w64(b1 != 0);
+            g0[i] = __builtin_amdgcn_ballot_w64(b0 < 0);
+            g1[i] = __builtin_amdgcn_ballot_w64(b1 < 0);
+            ternary = ternary && __builtin_amdgcn_ballot_w64((unsigned)(b0 + 1) > 2u || (unsigned)(b1 + 1) > 2u) == 0;
+            acc[i] = 0.0;
+        }
+        auto any_left = [&]() {
+            unsigned long long a = 0;
+#pragma unroll
+            for (int i = 0; i < NU; ++i) a |= m0[i] | m1[i];
+            return a != 0;
+        };
+        if (ternary) {
+            // spike at bit j of a unit: row f0 - H + j, distance to this lane's frame d = l + H - j, nir[d] = Pt[d + 63] = *(pl - 8 j)
+            while (any_left()) {
+                double nv[NU], sg[NU];
+#pragma unroll
+                for (int i = 0; i < NU; ++i) {
+                    const bool h0 = m0[i] != 0, h = h0 || m1[i] != 0;
+                    const unsigned long long m = h0 ? m0[i] : m1[i], g = h0 ? g0[i] : g1[i];
+                    const int jj = h ? __builtin_ctzll(m) : 0;
+                    sg[i] = h ? (((g >> jj) & 1) ? -1.0 : 1.0) : 0.0;
+                    nv[i] = *reinterpret_cast<const double *>(pl - 8 * (jj + (h0 ? 0 : 64) * (h ? 1 : 0)));
+                    if (h0)
+                        m0[i] = m & (m - 1);
+                    else
+                        m1[i] = m & (m - 1);
+                }
+#pragma unroll
+                for (int i = 0; i < NU; ++i) acc[i] = __builtin_fma(sg[i], nv[i], acc[i]);
+            }
+        } else {
+            // a raster that is not the encoder's (any int8 value): the value itself, broadcast from its lane; one unit after the other
+#pragma unroll
+            for (int i = 0; i < NU; ++i) {
+                while (m0[i]) {
+                    const int j = __builtin_ctzll(m0[i]);
+                    m0[i] &= m0[i] - 1;
+                    acc[i] = __builtin_fma(*reinterpret_cast<const double *>(pl - 8 * j), (double)__builtin_amdgcn_readlane(bv0[i], j), acc[i]);
+                }
+                while (m1[i]) {
+                    const int j = __builtin_ctzll(m1[i]);
+                    m1[i] &= m1[i] - 1;
+                    acc[i] = __builtin_fma(*reinterpret_cast<const double *>(pl - 8 * (64 + j)), (double)__builtin_amdgcn_readlane(bv1[i], j), acc[i]);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+            const int u = wv + BF_WAVES * i;
+            const int c = u / NB, blk = u - c * NB;
+            if (u < CPAD * NB && cs + 64 * blk < T)  // fragment order: [tile][channel][frame & 15]
+                Vl[(4 * blk + q) * 256 + c * 16 + lc] = (cs + 64 * blk + l < T) ? acc[i] : 0.0;
+        }
+        __syncthreads();
+    }
     // [ union{ spike tile as fp64 [R][16] , V fragments [32 tiles][4 k-steps][64 lanes] } ][ nir table ]
     // The spikes are converted to fp64 once, while they are staged (each row feeds ~3 time tiles of the Toeplitz
     // product): the LIF loop is then LDS reads + MFMAs only.  VALU instructions do not overlap MFMAs on a gfx950 SIMD
@@ -390,6 +525,7 @@ __global__ __launch_bounds__(BF_THREADS, WANT_Y ? 2 : (KV ? WS_KV_WAVES : (NT ==
     double *ntab = S + (R * 16 > TILES * 256 ? R * 16 : TILES * 256);
     const int ntab_len = 4 * NK + 16;
 
+    if constexpr (!SPARSE) {
     for (int e = tid; e < ntab_len; e += BF_THREADS) ntab[e] = ntab_g[e];
     {
         const int8_t *sb = spikes + (size_t)b * (chunk_range ? chunk_range[3] : T) * C;  // ([3]: frames per trial of a raster window)
@@ -490,6 +626,7 @@ __global__ __launch_bounds__(BF_THREADS, WANT_Y ? 2 : (KV ? WS_KV_WAVES : (NT ==
         }
     }
     __syncthreads();
+    }  // !SPARSE
 
     // ---- stage 2: this wave's DoA tiles against every time tile of the chunk --------------------------------
     int ntile = (T - cs + 15) >> 4;
@@ -533,6 +670,18 @@ static size_t ws_lds_bytes(const NeuronTab &nt, int NT, int Gy = 0)
     return ((tile > vfrag ? tile : vfrag) + (Gy ? ((tab + 1) & ~(size_t)1) + (size_t)16 * Gy : tab)) * sizeof(double);
 }
 
+// LDS of the event-driven LIF form: V fragments, the padded nir table, the transposed int8 tile (16 rows of RS bytes)
+static size_t ws_sparse_lds_bytes(const NeuronTab &nt, int NT)
+{
+    const int R = BF_WAVES * NT * 16 + nt.n - 1;
+    const int RS4 = ((R + 3) / 4 + 1) | 1;
+    return (size_t)BF_WAVES * NT * 256 * sizeof(double) + (size_t)(126 + nt.n) * sizeof(double) + (size_t)16 * 4 * RS4;
+}
+
+// The event-driven LIF stage serves power-only launches whose neuron kernel spans at most 65 frames (two ballot words per unit),
+// unless the plan says the raster is dense (NeuronTab::sparse: robust width >= 4 -- a polarity keeps at most one frame in four).
+static bool ws_sparse(const NeuronTab &nt) { return VARIANT_WS_SPARSE_LIF && nt.sparse && nt.n >= 1 && nt.n <= 65; }
+
 template <int NGW, int NT, bool WANT_Y, int KM = 4, int KV = 0>
 static hipError_t launch_ws_n(const BeamformW &W, const NeuronTab &nt, const int8_t *spikes, int B, int T,
                               double *partial, double *y, hipStream_t stream)
@@ -554,14 +703,24 @@ static hipError_t launch_ws_n(const BeamformW &W, const NeuronTab &nt, const int
 #undef WS_K
         }
     }
+    dim3 grid((T + BF_WAVES * NT * 16 - 1) / (BF_WAVES * NT * 16), B), block(BF_THREADS);
+    if constexpr (!WANT_Y && NT == 2) {
+        if (ws_sparse(nt)) {
+            const size_t lds = ws_sparse_lds_bytes(nt, NT);
+            auto k = &beamform_ws_kernel<NGW, NT, false, KM, KV, true>;
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(k, grid, block, lds, stream, spikes, nt.tab, nt.NK, W.Wp, W.GT, W.C, T, partial, W.G, y, W.chunk_range, nt.n);
+            return hipGetLastError();
+        }
+    }
     const size_t lds = ws_lds_bytes(nt, NT, WANT_Y ? W.G : 0);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     auto k = &beamform_ws_kernel<NGW, NT, WANT_Y, KM, KV>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        160 * 1024);
     if (e != hipSuccess) return e;
-    dim3 grid((T + BF_WAVES * NT * 16 - 1) / (BF_WAVES * NT * 16), B), block(BF_THREADS);
-    hipLaunchKernelGGL(k, grid, block, lds, stream, spikes, nt.tab, nt.NK, W.Wp, W.GT, W.C, T, partial, W.G, y, W.chunk_range);
+    hipLaunchKernelGGL(k, grid, block, lds, stream, spikes, nt.tab, nt.NK, W.Wp, W.GT, W.C, T, partial, W.G, y, W.chunk_range, nt.n);
     return hipGetLastError();
 }
 
