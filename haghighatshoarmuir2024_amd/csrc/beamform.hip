@@ -438,80 +438,79 @@ __global__ __launch_bounds__(BF_THREADS, WANT_Y ? 2 : (KV ? WS_KV_WAVES : (NT ==
         __syncthreads();
         constexpr int NB = CH / 64;
         static_assert(CH % 64 == 0, "a unit is 64 frames");
-        // A wave's units are walked TOGETHER, one spike of every unit per round: NU independent LDS reads in flight, then NU fmas (a
-        // unit alone is a chain of read -> add -> read: ~130 cycles per spike, 8 000 per wave, and a workgroup's stage 2 cannot start
-        // before its slowest wave is through).  A unit that has run out of spikes keeps issuing with a zero factor (acc + 0 * nir ==
-        // acc exactly) so that the round is straight-line code; the loop ends when every unit's masks are empty.
-        constexpr int NU = (CPAD * NB + BF_WAVES - 1) / BF_WAVES;
-        const char *pl = reinterpret_cast<const char *>(Pt) + 8 * (l + H + 63);
-        unsigned long long m0[NU], m1[NU], g0[NU], g1[NU];
-        int bv0[NU], bv1[NU];
-        double acc[NU];
-        bool ternary = true;
-#pragma unroll
-        for (int i = 0; i < NU; ++i) {
-            const int u = wv + BF_WAVES * i;
+        // MEASURED (profiles/r5/ws_lif_ablation.txt, same box, stage alone, us per launch): dense product 1004, this form 1004; with the
+        // LIF work removed (wrong results, timing only): dense without its matrix instructions 862, this form without the spike walk
+        // 885, without the whole stage 852.  The walk costs what the 26 matrix instructions per wave cost: it is ~650 instructions per
+        // wave, every vector one of them queues behind the 64-cycle matrix instructions of the co-resident workgroups' stage 2, and a
+        // workgroup's own stage 2 cannot start before its slowest wave is through -- fewer matrix-pipe cycles, but a longer stage.
+        // Hence a variant build (ws_sparse_lif), not the product.
+        // One wave issues one instruction of ANY kind per ~4.4 cycles, and the scalar instructions of the waves of a SIMD queue up
+        // behind each other: what a spike costs is its instruction count (the first form of this loop -- twelve scalar instructions per
+        // spike: 1025 us -- and a form that walked the seven units of a wave side by side -- 130 per round: 1240 us -- were slower
+        // still).  Per spike: find it (s_ff1), clear it (s_bitset0), its sign as the high word of +-1.0 (s_bitcmp1 + s_cselect), the
+        // table offset (s_lshl), the lanes' address (v_sub), the read, the fma; the read of spike k + 1 is issued before the fma of
+        // spike k waits for its own.
+        const char *pl = reinterpret_cast<const char *>(Pt) + 8 * (l + H + 63);  // this lane's nir[d = l + H - j] at j = 0
+        for (int u = wv; u < CPAD * NB; u += BF_WAVES) {  // (wave-uniform)
             const int c = u / NB, blk = u - c * NB;
-            const bool live = u < CPAD * NB && c < C && cs + 64 * blk < T;  // (wave-uniform)
-            const int8_t *row = Sb + (live ? c : 0) * RS + 64 * blk;
-            const int b0 = live ? row[l] : 0;
-            const int b1 = (live && l < H) ? row[64 + l] : 0;
-            bv0[i] = b0;
-            bv1[i] = b1;
-            m0[i] = __builtin_amdgcn_ballot_w64(b0 != 0);
-            m1[i] = __builtin_amdgcn_ballot_w64(b1 != 0);
-            g0[i] = __builtin_amdgcn_ballot_w64(b0 < 0);
-            g1[i] = __builtin_amdgcn_ballot_w64(b1 < 0);
-            ternary = ternary && __builtin_amdgcn_ballot_w64((unsigned)(b0 + 1) > 2u || (unsigned)(b1 + 1) > 2u) == 0;
-            acc[i] = 0.0;
-        }
-        auto any_left = [&]() {
-            unsigned long long a = 0;
-#pragma unroll
-            for (int i = 0; i < NU; ++i) a |= m0[i] | m1[i];
-            return a != 0;
-        };
-        if (ternary) {
-            // spike at bit j of a unit: row f0 - H + j, distance to this lane's frame d = l + H - j, nir[d] = Pt[d + 63] = *(pl - 8 j)
-            while (any_left()) {
-                double nv[NU], sg[NU];
-#pragma unroll
-                for (int i = 0; i < NU; ++i) {
-                    const bool h0 = m0[i] != 0, h = h0 || m1[i] != 0;
-                    const unsigned long long m = h0 ? m0[i] : m1[i], g = h0 ? g0[i] : g1[i];
-                    const int jj = h ? __builtin_ctzll(m) : 0;
-                    sg[i] = h ? (((g >> jj) & 1) ? -1.0 : 1.0) : 0.0;
-                    nv[i] = *reinterpret_cast<const double *>(pl - 8 * (jj + (h0 ? 0 : 64) * (h ? 1 : 0)));
-                    if (h0)
-                        m0[i] = m & (m - 1);
-                    else
-                        m1[i] = m & (m - 1);
+            const int f0 = cs + 64 * blk;
+            if (f0 >= T) continue;
+            double acc = 0.0;
+            if (c < C) {
+                const int8_t *row = Sb + c * RS + 64 * blk;
+                const int b0 = row[l];
+                const int b1 = l < H ? row[64 + l] : 0;
+                const unsigned long long m0 = __builtin_amdgcn_ballot_w64(b0 != 0), m1 = __builtin_amdgcn_ballot_w64(b1 != 0);
+                const unsigned long long g0 = __builtin_amdgcn_ballot_w64(b0 < 0), g1 = __builtin_amdgcn_ballot_w64(b1 < 0);
+                const bool ternary = __builtin_amdgcn_ballot_w64((unsigned)(b0 + 1) > 2u || (unsigned)(b1 + 1) > 2u) == 0;
+                if (ternary) {
+                    // spike at bit j of a word: row f0 - H + j (+ 64), distance to this lane's frame d = l + H - j, nir[d] = *(base - 8 j)
+                    const unsigned kneg = 0xbff00000u, kpos = 0x3ff00000u;  // high words of -1.0 / +1.0 (in scalar registers)
+                    auto walk = [&](unsigned long long mm, const unsigned long long gg, const char *base) {
+                        if (!mm) return;
+                        auto pop = [&](unsigned &hi) {
+                            const int j = __builtin_ctzll(mm);
+                            asm("s_bitset0_b64 %0, %1" : "+s"(mm) : "s"(j));
+                            asm("s_bitcmp1_b64 %1, %2\n\ts_cselect_b32 %0, %3, %4" : "=s"(hi) : "s"(gg), "s"(j), "s"(kneg), "s"(kpos) : "scc");
+                            return *reinterpret_cast<const double *>(base - 8 * j);
+                        };
+                        // two spikes per trip, each with its own registers: the read of one is in flight while the other is added
+                        unsigned hiA, hiB;
+                        double nvA = pop(hiA), nvB;
+                        for (;;) {
+                            if (!mm) {
+                                acc = __builtin_fma(__hiloint2double((int)hiA, 0), nvA, acc);
+                                break;
+                            }
+                            nvB = pop(hiB);
+                            acc = __builtin_fma(__hiloint2double((int)hiA, 0), nvA, acc);
+                            if (!mm) {
+                                acc = __builtin_fma(__hiloint2double((int)hiB, 0), nvB, acc);
+                                break;
+                            }
+                            nvA = pop(hiA);
+                            acc = __builtin_fma(__hiloint2double((int)hiB, 0), nvB, acc);
+                        }
+                    };
+                    walk(m0, g0, pl);
+                    walk(m1, g1, pl - 512);
+                } else {
+                    // a raster that is not the encoder's (any int8 value): the value itself, broadcast from its lane
+                    unsigned long long mm = m0;
+                    while (mm) {
+                        const int j = __builtin_ctzll(mm);
+                        mm &= mm - 1;
+                        acc = __builtin_fma(*reinterpret_cast<const double *>(pl - 8 * j), (double)__builtin_amdgcn_readlane(b0, j), acc);
+                    }
+                    mm = m1;
+                    while (mm) {
+                        const int j = __builtin_ctzll(mm);
+                        mm &= mm - 1;
+                        acc = __builtin_fma(*reinterpret_cast<const double *>(pl - 8 * (64 + j)), (double)__builtin_amdgcn_readlane(b1, j), acc);
+                    }
                 }
-#pragma unroll
-                for (int i = 0; i < NU; ++i) acc[i] = __builtin_fma(sg[i], nv[i], acc[i]);
             }
-        } else {
-            // a raster that is not the encoder's (any int8 value): the value itself, broadcast from its lane; one unit after the other
-#pragma unroll
-            for (int i = 0; i < NU; ++i) {
-                while (m0[i]) {
-                    const int j = __builtin_ctzll(m0[i]);
-                    m0[i] &= m0[i] - 1;
-                    acc[i] = __builtin_fma(*reinterpret_cast<const double *>(pl - 8 * j), (double)__builtin_amdgcn_readlane(bv0[i], j), acc[i]);
-                }
-                while (m1[i]) {
-                    const int j = __builtin_ctzll(m1[i]);
-                    m1[i] &= m1[i] - 1;
-                    acc[i] = __builtin_fma(*reinterpret_cast<const double *>(pl - 8 * (64 + j)), (double)__builtin_amdgcn_readlane(bv1[i], j), acc[i]);
-                }
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < NU; ++i) {
-            const int u = wv + BF_WAVES * i;
-            const int c = u / NB, blk = u - c * NB;
-            if (u < CPAD * NB && cs + 64 * blk < T)  // fragment order: [tile][channel][frame & 15]
-                Vl[(4 * blk + q) * 256 + c * 16 + lc] = (cs + 64 * blk + l < T) ? acc[i] : 0.0;
+            Vl[(4 * blk + q) * 256 + c * 16 + lc] = (f0 + l < T) ? acc : 0.0;  // fragment order: [tile][channel][frame & 15]
         }
         __syncthreads();
     }
