@@ -637,29 +637,33 @@ __global__ __launch_bounds__(BF_THREADS, WANT_Y ? 2 : (KV ? WS_KV_WAVES : (NT ==
                                 partial ? pout : nullptr);
         return;
     }
-    // NGW = ceil(GT / 8): every wave owns NGW or NGW - 1 DoA tiles (wave-uniform choice of the instantiation)
+    // NGW = ceil(GT / 8): every wave owns NGW or NGW - 1 DoA tiles (wave-uniform choice of the instantiation).  (G = 360: 23 tiles,
+    // seven waves own three and one owns two.  Rotating the lighter share over the waves with the workgroup index -- in case the same
+    // SIMD of a compute unit were the light one in all of its workgroups -- was measured: 1007 against 999 us, G = 449: 1227 against
+    // 1212; profiles/r5/ws_owner_rotation.txt.  Not that.)
+    const int wo = wv;
     if constexpr (KM < 4 || NGW == 4) {  // (16 channels with four DoA tiles per wave: the two-pass form as well -- 8 B of scratch otherwise)
         constexpr bool LEAN = (KV > 0 || NGW == 4) && WS_KV_WAVES >= 6;
         if constexpr (LEAN && NGW == 4) {
             // four DoA tiles per wave do not fit 80 registers: two passes of two over the parked fragments (the LDS reads
             // double, the MFMAs do not) keep three workgroups per CU
-            ws_stage2_kv<2, TILES, KM, KV, true>(Vl, Wp, Gp, wv, l, ntile, pout, 0);
-            if (wv + BF_WAVES * 3 < GT)
-                ws_stage2_kv<2, TILES, KM, KV, true>(Vl, Wp, Gp, wv, l, ntile, pout, 2);
+            ws_stage2_kv<2, TILES, KM, KV, true>(Vl, Wp, Gp, wo, l, ntile, pout, 0);
+            if (wo + BF_WAVES * 3 < GT)
+                ws_stage2_kv<2, TILES, KM, KV, true>(Vl, Wp, Gp, wo, l, ntile, pout, 2);
             else
-                ws_stage2_kv<1, TILES, KM, KV, true>(Vl, Wp, Gp, wv, l, ntile, pout, 2);
+                ws_stage2_kv<1, TILES, KM, KV, true>(Vl, Wp, Gp, wo, l, ntile, pout, 2);
             return;
         }
-        if (wv + BF_WAVES * (NGW - 1) < GT)
-            ws_stage2_kv<NGW, TILES, KM, KV, LEAN>(Vl, Wp, Gp, wv, l, ntile, pout);
+        if (wo + BF_WAVES * (NGW - 1) < GT)
+            ws_stage2_kv<NGW, TILES, KM, KV, LEAN>(Vl, Wp, Gp, wo, l, ntile, pout);
         else
-            ws_stage2_kv<NGW - 1, TILES, KM, KV, LEAN>(Vl, Wp, Gp, wv, l, ntile, pout);
+            ws_stage2_kv<NGW - 1, TILES, KM, KV, LEAN>(Vl, Wp, Gp, wo, l, ntile, pout);
         return;
     }
-    if (wv + BF_WAVES * (NGW - 1) < GT)
-        ws_stage2<NGW, TILES, NT != 2>(Vl, Wp, Gp, wv, l, ntile, pout);
+    if (wo + BF_WAVES * (NGW - 1) < GT)
+        ws_stage2<NGW, TILES, NT != 2>(Vl, Wp, Gp, wo, l, ntile, pout);
     else
-        ws_stage2<NGW - 1, TILES, NT != 2>(Vl, Wp, Gp, wv, l, ntile, pout);
+        ws_stage2<NGW - 1, TILES, NT != 2>(Vl, Wp, Gp, wo, l, ntile, pout);
 }
 
 static size_t ws_lds_bytes(const NeuronTab &nt, int NT, int Gy = 0)
