@@ -1442,6 +1442,81 @@ __global__ __launch_bounds__(256 * S) void power_argmax_kernel(const double *__r
     if (threadIdx.x == 0 && argmax) argmax[b] = si[0] == 0x7fffffff ? 0 : si[0];
 }
 
+// Long recordings (speech: 1298 chunk rows of 368 doubles per trial, 125 trials = 478 MB of partial sums): one workgroup per trial
+// leaves half the chip idle and every thread with a chain of dependent row reads (0.33 ms per launch, 1.4 TB/s).  The reduction is
+// independent per DoA column, so the columns of a trial are split over workgroups of 64 columns x 4 slices (the SAME order of
+// additions per column: chunk sums ascending inside blocks of PA_BLOCK, block sums ascending onto the total), and a second, tiny
+// kernel takes the first maximum of every trial's row of `power`.
+__global__ __launch_bounds__(256) void power_columns_kernel(const double *__restrict__ partial, int T, int nchunks, int Gp, int G,
+                                                             int complex_pairs, int Ghp, double *__restrict__ power)
+{
+    constexpr int S = 4, U = 4, W = 64;
+    __shared__ double ps[U][S][W];
+    const int b = blockIdx.y;
+    const int col = threadIdx.x & (W - 1);
+    const int slice = threadIdx.x >> 6;
+    const int g = blockIdx.x * W + col;
+    const double *pb = partial + (size_t)b * nchunks * Gp;
+    const int nblocks = (nchunks + PA_BLOCK - 1) / PA_BLOCK;
+    double total = 0.0;
+    for (int blk0 = 0; blk0 < nblocks; blk0 += S * U) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int blk = blk0 + S * u + slice;
+            double s = 0.0;
+            if (g < G && blk < nblocks) {
+                const int c_hi = (blk + 1) * PA_BLOCK < nchunks ? (blk + 1) * PA_BLOCK : nchunks;
+                for (int ch = blk * PA_BLOCK; ch < c_hi; ++ch) {
+                    s += pb[(size_t)ch * Gp + g];
+                    if (complex_pairs) s += pb[(size_t)ch * Gp + Ghp + g];
+                }
+            }
+            ps[u][slice][col] = s;
+        }
+        __syncthreads();
+        if (slice == 0) {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int v = 0; v < S; ++v)
+                    if (blk0 + S * u + v < nblocks) total += ps[u][v][col];
+        }
+        __syncthreads();
+    }
+    if (slice == 0 && g < G) power[(size_t)b * G + g] = total / (double)T;
+}
+
+__global__ __launch_bounds__(256) void argmax_rows_kernel(const double *__restrict__ power, int G, int32_t *__restrict__ argmax)
+{
+    __shared__ double sv[256];
+    __shared__ int si[256];
+    const int b = blockIdx.x, col = threadIdx.x;
+    double best = -1.0;
+    int bi = 0x7fffffff;
+    for (int g = col; g < G; g += 256) {  // ascending per thread: its first maximum
+        const double p = power[(size_t)b * G + g];
+        if (p > best) {
+            best = p;
+            bi = g;
+        }
+    }
+    sv[col] = best;
+    si[col] = bi;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (col < s) {
+            const double ov = sv[col + s];
+            const int oi = si[col + s];
+            if (ov > sv[col] || (ov == sv[col] && oi < si[col])) {
+                sv[col] = ov;
+                si[col] = oi;
+            }
+        }
+        __syncthreads();
+    }
+    if (col == 0) argmax[b] = si[0] == 0x7fffffff ? 0 : si[0];
+}
+
 // ---- streaming: the same reduction with O(1) state -----------------------------------------------------------------
 // acc [B][2][G]: running total and the sum of the open block; ctl: {chunks done, chunks of the open block}.  The chunk
 // range [lo, hi) of this call (window-relative, decided on the device by the caller's horizon kernel) is read from
@@ -1513,7 +1588,11 @@ hipError_t launch_stream_accumulate(const double *partial, int B, int nwin, int 
 hipError_t launch_power_argmax(const double *partial, int B, int T, int nchunks, int Gp, int G, int complex_pairs,
                                int Ghalf_pad, double *power, int32_t *argmax, hipStream_t stream)
 {
-    if (nchunks >= 128)
+    if (nchunks >= 128 && power && argmax && B <= 65535) {
+        hipLaunchKernelGGL(power_columns_kernel, dim3((G + 63) / 64, B), dim3(256), 0, stream, partial, T, nchunks, Gp, G, complex_pairs,
+                           Ghalf_pad, power);
+        hipLaunchKernelGGL(argmax_rows_kernel, dim3(B), dim3(256), 0, stream, power, G, argmax);
+    } else if (nchunks >= 128)
         hipLaunchKernelGGL(power_argmax_kernel<4>, dim3(B), dim3(1024), 0, stream, partial, T, nchunks, Gp, G, complex_pairs, Ghalf_pad,
                            power, argmax);
     else
