@@ -438,7 +438,7 @@ __global__ __launch_bounds__(BF_THREADS, WANT_Y ? 2 : (KV ? WS_KV_WAVES : (NT ==
         __syncthreads();
         constexpr int NB = CH / 64;
         static_assert(CH % 64 == 0, "a unit is 64 frames");
-        // MEASURED (profiles/r5/ws_lif_ablation.txt, same box, stage alone, us per launch): dense product 1004, this form 1004; with the
+        // MEASURED (profiles/r5/experiments/ws_lif_ablation.txt, same box, stage alone, us per launch): dense product 1004, this form 1004; with the
         // LIF work removed (wrong results, timing only): dense without its matrix instructions 862, this form without the spike walk
         // 885, without the whole stage 852.  The walk costs what the 26 matrix instructions per wave cost: it is ~650 instructions per
         // wave, every vector one of them queues behind the 64-cycle matrix instructions of the co-resident workgroups' stage 2, and a
@@ -640,7 +640,7 @@ __global__ __launch_bounds__(BF_THREADS, WANT_Y ? 2 : (KV ? WS_KV_WAVES : (NT ==
     // NGW = ceil(GT / 8): every wave owns NGW or NGW - 1 DoA tiles (wave-uniform choice of the instantiation).  (G = 360: 23 tiles,
     // seven waves own three and one owns two.  Rotating the lighter share over the waves with the workgroup index -- in case the same
     // SIMD of a compute unit were the light one in all of its workgroups -- was measured: 1007 against 999 us, G = 449: 1227 against
-    // 1212; profiles/r5/ws_owner_rotation.txt.  Not that.)
+    // 1212; profiles/r5/experiments/ws_owner_rotation.txt.  Not that.)
     const int wo = wv;
     if constexpr (KM < 4 || NGW == 4) {  // (16 channels with four DoA tiles per wave: the two-pass form as well -- 8 B of scratch otherwise)
         constexpr bool LEAN = (KV > 0 || NGW == 4) && WS_KV_WAVES >= 6;
