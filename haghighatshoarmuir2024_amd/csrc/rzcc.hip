@@ -213,13 +213,16 @@ __device__ __forceinline__ void resolve_cluster(int s, int e, int stride, int w,
 constexpr int RZ_MT = 16;  // time steps per tile of the wave pipeline (one barrier per tile)
 
 // ---- detect-stage helper ------------------------------------------------------------------------------------------
-// v = 2 v + (lane's bit of m): one step of building a per-lane bit word out of wave-level compare masks (one VALU
-// instruction: add with carry-in)
-__device__ __forceinline__ int add_lane_mask2(int v, uint64_t m)
+// One step of BOTH words of the detect wave: r = 2 r + (a > b), f = 2 f + (a < b), ordered compares, through VCC inside one asm
+// block.  With the compare outside (a builtin writing an SGPR pair that the add-with-carry reads and overwrites) the compiler put an
+// s_nop behind every add-with-carry -- 30 of the wave's ~440 issue slots per tile; a compare writing VCC straight behind an
+// add-with-carry that wrote it is an ordinary write after write.
+__device__ __forceinline__ void rise_fall_step(unsigned &r, unsigned &f, double a, double b)
 {
-    uint64_t carry_out;
-    asm("v_addc_co_u32_e64 %0, %1, %0, %0, %2" : "+v"(v), "=s"(carry_out) : "s"(m));
-    return v;
+    asm("v_cmp_gt_f64 vcc, %2, %3\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\tv_cmp_lt_f64 vcc, %2, %3\n\tv_addc_co_u32_e32 %1, vcc, %1, %1, vcc"
+        : "+v"(r), "+v"(f)
+        : "v"(a), "v"(b)
+        : "vcc");
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -965,8 +968,7 @@ __global__ __launch_bounds__(WRITER ? 512 : 448, (WANT_PRE && WANT_SPIKES) ? 2 :
 #pragma unroll
                 for (int jj = RZ_MT - 1; jj >= 0; --jj) {
                     const double pj = jj ? c[jj ? jj - 1 : 0] : prev;
-                    Rw = (unsigned)add_lane_mask2((int)Rw, __builtin_amdgcn_fcmp(c[jj], pj, 2));  // ordered >
-                    Fw = (unsigned)add_lane_mask2((int)Fw, __builtin_amdgcn_fcmp(c[jj], pj, 4));  // ordered <
+                    rise_fall_step(Rw, Fw, c[jj], pj);  // ordered > / ordered <
                 }
                 const unsigned vmask = (1u << steps) - 1u;
                 Rw &= vmask;
