@@ -674,7 +674,7 @@ static size_t ws_lds_bytes(const NeuronTab &nt, int NT, int Gy = 0)
 }
 
 // LDS of the event-driven LIF form: V fragments, the padded nir table, the transposed int8 tile (16 rows of RS bytes)
-static size_t ws_sparse_lds_bytes(const NeuronTab &nt, int NT)
+[[maybe_unused]] static size_t ws_sparse_lds_bytes(const NeuronTab &nt, int NT)
 {
     const int R = BF_WAVES * NT * 16 + nt.n - 1;
     const int RS4 = ((R + 3) / 4 + 1) | 1;
@@ -683,7 +683,7 @@ static size_t ws_sparse_lds_bytes(const NeuronTab &nt, int NT)
 
 // The event-driven LIF stage serves power-only launches whose neuron kernel spans at most 65 frames (two ballot words per unit),
 // unless the plan says the raster is dense (NeuronTab::sparse: robust width >= 4 -- a polarity keeps at most one frame in four).
-static bool ws_sparse(const NeuronTab &nt) { return VARIANT_WS_SPARSE_LIF && nt.sparse && nt.n >= 1 && nt.n <= 65; }
+[[maybe_unused]] static bool ws_sparse(const NeuronTab &nt) { return VARIANT_WS_SPARSE_LIF && nt.sparse && nt.n >= 1 && nt.n <= 65; }
 
 template <int NGW, int NT, bool WANT_Y, int KM = 4, int KV = 0>
 static hipError_t launch_ws_n(const BeamformW &W, const NeuronTab &nt, const int8_t *spikes, int B, int T,
@@ -707,7 +707,7 @@ static hipError_t launch_ws_n(const BeamformW &W, const NeuronTab &nt, const int
         }
     }
     dim3 grid((T + BF_WAVES * NT * 16 - 1) / (BF_WAVES * NT * 16), B), block(BF_THREADS);
-    if constexpr (!WANT_Y && NT == 2) {
+    if constexpr (VARIANT_WS_SPARSE_LIF && !WANT_Y && NT == 2) {  // (the event-driven instantiations exist in the variant build only)
         if (ws_sparse(nt)) {
             const size_t lds = ws_sparse_lds_bytes(nt, NT);
             auto k = &beamform_ws_kernel<NGW, NT, false, KM, KV, true>;
