@@ -20,7 +20,7 @@ def patch(body, decl_after):
 
 # loaders (rz_loader_np only: the spikes-only launches)
 a = s.index("template <int NP, int PHASE, int SW, typename XT>")
-b = s.index("template <int N>\n__global__ __launch_bounds__(192) void rzcc_scan_kernel")
+b = s.index("template <int N, unsigned ZMASK = 0u>\n__global__ __launch_bounds__(192) void rzcc_scan_kernel")
 body = s[a:b]
 body = patch(body, "    constexpr int phase = PHASE;")
 # flush at the end of the function: before its closing brace
@@ -65,8 +65,7 @@ if "noresolve" in abl:
 if "nodetectloop" in abl:
     s = s.replace("                while (__any(Ew != 0u)) {\n                    if (Ew) {", "                while (false) {\n                    if (Ew) {")
 if "noA" in abl:   # detect: no fp64 compares (rise / fall words constant)
-    old = """                    Rw = (unsigned)add_lane_mask2((int)Rw, __builtin_amdgcn_fcmp(c[jj], pj, 2));  // ordered >
-                    Fw = (unsigned)add_lane_mask2((int)Fw, __builtin_amdgcn_fcmp(c[jj], pj, 4));  // ordered <"""
+    old = "                    rise_fall_step(Rw, Fw, c[jj], pj);  // ordered > / ordered <"
     assert old in s
     s = s.replace(old, "                    Rw = 0x1111u + (unsigned)(pj > 1e300); Fw = 0x4444u;")
 if "noC" in abl:   # detect: no events appended
