@@ -670,3 +670,72 @@ print("ok")
     env = dict(os.environ)
     r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert r.returncode == 0 and b"ok" in r.stdout, r.stderr.decode()[-2000:]
+
+
+def test_event_driven_lif_variant_is_exact():
+    """The `ws_sparse_lif` variant library (beamform_ws_kernel's LIF stage walked spike by spike instead of multiplied densely: round 5's
+    experiment, as fast as the product's form, not faster -- DESIGN.md 4.3) gives the oracle's membrane sums bit for bit: power equal
+    to the product's to the last bit on the reference's trials, on odd channel counts, ragged lengths, a neuron kernel at the walk's
+    limit (65 taps), a DENSE raster and a raster that is not ternary (the general path broadcasts the value from its lane)."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    variant = os.path.join(root, "tools", "_variants", "libmicloc_hip_ws_sparse_lif.so")
+    mk = subprocess.run([sys.executable, os.path.join(root, "tools", "dev", "make_variant.py"), "ws_sparse_lif"], stdout=subprocess.PIPE,
+                        stderr=subprocess.PIPE, timeout=900)
+    assert mk.returncode == 0 and os.path.exists(variant), mk.stderr.decode()[-2000:]
+    code = r"""
+import numpy as np, sys, os
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from haghighatshoarmuir2024_amd import _lib
+if sys.argv[1] == "variant":
+    _lib.LIB_PATH = %r
+import torch
+from oracle import oracle as O
+from haghighatshoarmuir2024_amd.runtime import Plan
+fs = 48000
+ker = O.stht_kernel(fs, 10e-3)
+b, a = O.bandpass(fs, [1000.0, 2000.0])
+rng = np.random.RandomState(3)
+out = {}
+cases = [(7, 360, 4799, 35, "enc"), (7, 449, 700, 35, "enc"), (3, 40, 1000, 20, "enc"), (5, 100, 257, 65, "enc"), (8, 33, 513, 7, "enc"),
+         (7, 64, 900, 35, "dense"), (6, 50, 600, 35, "int8"), (1, 17, 300, 3, "dense")]
+for (M, G, T, n, kind) in cases:
+    p = Plan(M, ker, b, a, 12, True)
+    nir = np.abs(rng.randn(n)) / n
+    p.set_neuron_kernel(nir)
+    W = rng.randn(2 * M, G)
+    p.set_bf_mat(W)
+    B = 3
+    if kind == "enc":
+        x = np.sin(2 * np.pi * 1700 * np.arange(T) / fs)[None, :, None] + 0.8 * rng.randn(B, T, M)
+        spikes = p.snn_pipeline(p.to_device(x), want_spikes=True, want_power=False)["spikes"]
+    elif kind == "dense":
+        spikes = torch.from_numpy(rng.randint(-1, 2, size=(B, T, 2 * M)).astype(np.int8)).cuda()
+    else:
+        spikes = torch.from_numpy(rng.randint(-5, 6, size=(B, T, 2 * M)).astype(np.int8)).cuda()
+    r = p.lif_beamform(spikes, want_power=True)
+    power = r["power"].cpu().numpy()
+    s = spikes.cpu().numpy()
+    for i in range(B):
+        v = O.lif_fir(s[i], nir)
+        y = O.beamform(v, W)
+        ref = np.mean(y * y, axis=0)
+        assert np.allclose(power[i], ref, rtol=1e-12, atol=0), (M, G, T, n, kind)
+    out[str((M, G, T, n, kind))] = power
+np.savez(sys.argv[2], **out)
+print("ok")
+""" % (root, os.path.dirname(os.path.abspath(__file__)), variant)
+    import tempfile
+
+    with tempfile.TemporaryDirectory() as d:
+        got = {}
+        for which in ("product", "variant"):
+            path = os.path.join(d, which + ".npz")
+            r = subprocess.run([sys.executable, "-c", code, which, path], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+            assert r.returncode == 0 and b"ok" in r.stdout, (which, r.stderr.decode()[-2000:])
+            got[which] = dict(np.load(path))
+        assert set(got["product"]) == set(got["variant"]) and len(got["product"]) == 8
+        for k in got["product"]:
+            np.testing.assert_array_equal(got["product"][k], got["variant"][k], err_msg=k)  # bit for bit
