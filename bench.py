@@ -1437,6 +1437,13 @@ def run(args):
             result["exchange_ms"] = exchange["exchange_ms"]
         if sustained is not None:
             result["sustained"] = sustained
+            tw = (sustained.get("telemetry") or {}).get("whole")
+            if tw and roof.get("unit") == "TFLOP/s":
+                # the datasheet peak assumes the 2.4 GHz boost clock; the chip reports what it actually held during the long region
+                pk = FP64_MFMA_PEAK_TFLOPS * tw["sclk_mhz_mean"] / 2400.0
+                roof["peak_at_measured_clock"] = pk
+                roof["frac_at_measured_clock"] = roof["achieved"] / pk
+                roof["measured_clock_mhz"] = tw["sclk_mhz_mean"]
             result["config"]["sustained_ms_per_step"] = sustained["ms_per_step"]
             if sustained["ratio_to_timed_regions"] > 1.02:
                 # the long run is more than 2 % slower than the K-step regions (clock / power management): the honest number is the value
