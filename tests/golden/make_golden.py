@@ -810,6 +810,56 @@ def gen_stress_case():
          clean_rows=clean["sig"][clean_idx], clean_idx=clean_idx)
 
 
+def _design_with_covs(beamf, template, doa_list):
+    covs = []
+    orig_svd = np.linalg.svd
+
+    def svd_spy(mat, *a, **k):
+        covs.append(np.array(mat, copy=True))
+        return orig_svd(mat, *a, **k)
+
+    np.linalg.svd = svd_spy
+    try:
+        bf_mat = quiet(beamf.design_from_template, template=template, doa_list=doa_list)
+    finally:
+        np.linalg.svd = orig_svd
+    return bf_mat, np.asarray(covs)
+
+
+def gen_design_other_geometries():
+    """Two more callers of design_from_template from SURVEY 8b's call surface, on the geometries they use:
+    paper_plots/array_resolution_random_snn.py:100-170 (np.random.seed(1), Random2DArray(4.5e-2, 13): 26 channels, 833 DoAs shifted by
+    pi, 0.6 s sine, unipolar) and paper_plots/array_resolution_linear_snn.py:120-190 (LinearArray(2 r / 7, 7, r), DoAs in [0, pi], a sine
+    with 1 % frequency jitter -- drawn here after np.random.seed(1) and rounded to float32 so that the fixture stores the template in
+    half the bytes and the tests feed the reference's exact input)."""
+    fs, f = 48_000, 2000
+    tau = 1 / (2 * np.pi * f)
+    out = {}
+    np.random.seed(1)
+    geometry = Random2DArray(radius=4.5e-2, num_mic=13)
+    beamf = SNNBeamformer(geometry, 10e-3, [f / 2, 2 * f], [tau, tau], bipolar_spikes=False, fs=fs)
+    time_temp = np.arange(0, 0.6, step=1 / fs)
+    doa_list = np.linspace(-np.pi, np.pi, 64 * 13 + 1) + np.pi
+    bf_mat, covs = _design_with_covs(beamf, (time_temp, np.sin(2 * np.pi * f * time_temp)), doa_list)
+    assert covs.shape == (833, 26, 26)
+    sel = np.arange(0, 833, 119)
+    out.update(rand_r=geometry.r_vec, rand_theta=geometry.theta_vec, rand_doa_list=doa_list, rand_bf_mat=bf_mat, rand_cov_sel=covs[sel],
+               rand_cov_idx=sel)
+    radius, num_mic = 4.5e-2, 7
+    geometry = LinearArray(spacing=2 * radius / num_mic, num_mic=num_mic, radius=radius)
+    beamf = SNNBeamformer(geometry, 10e-3, [f / 2, 2 * f], [tau, tau], bipolar_spikes=False, fs=fs)
+    np.random.seed(1)
+    freq_inst = f * (1 + 0.01 * np.random.randn(len(time_temp)))
+    sig_temp = np.sin(2 * np.pi * np.cumsum(freq_inst) / fs).astype(np.float32)
+    doa_list = np.linspace(0, np.pi, 64 * num_mic + 1)
+    bf_mat, covs = _design_with_covs(beamf, (time_temp, sig_temp.astype(np.float64)), doa_list)
+    sel = np.arange(0, 449, 64)
+    out.update(lin_r=geometry.r_vec, lin_theta=geometry.theta_vec, lin_doa_list=doa_list, lin_template_f32=sig_temp, lin_bf_mat=bf_mat,
+               lin_cov_sel=covs[sel], lin_cov_idx=sel)
+    out["freq_design"] = np.int64(f)
+    save("design_other_geometries.npz", **out)
+
+
 GENS = {
     "kat_init": gen_kat_init,
     "bf_mat_chirp": gen_bf_mat_chirp,
@@ -829,6 +879,7 @@ GENS = {
     "bf_mat_unipolar_hf": gen_bf_mat_unipolar_hf,
     "beamformer_c128_g449": gen_beamformer_c128_g449,
     "stress_case": gen_stress_case,
+    "design_other_geometries": gen_design_other_geometries,
 }
 
 if __name__ == "__main__":

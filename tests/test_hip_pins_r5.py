@@ -177,3 +177,47 @@ def test_config1_designs_high_frequencies(f, torch):
     sig = np.ascontiguousarray(np.transpose(np.interp(td.ravel(), tt, ss).reshape(td.shape), (0, 2, 1)))
     cov = bf.membrane_covariance_batch(sig, time_vec=tt, t_start=sig.shape[1] // 4).cpu().numpy()
     np.testing.assert_allclose(cov, z[f"cov_sel_f{f}"], rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("which", ["rand", "lin"])
+def test_designs_on_other_geometries(which, torch):
+    """The complete designs of array_resolution_random_snn.py (13 random microphones after np.random.seed(1): 26 channels -- two channel
+    tiles of the covariance kernel, the 26 x 26 two-sided Jacobi -- 833 DoAs shifted by pi) and array_resolution_linear_snn.py
+    (LinearArray, 449 DoAs in [0, pi], jittered template), host LAPACK and device Jacobi, against the reference's bf_mat and the beam
+    pattern the scripts plot (ref:paper_plots/array_resolution_random_snn.py:100-170, array_resolution_linear_snn.py:120-190)."""
+    from micloc.array_geometry import LinearArray, Random2DArray
+    from micloc.snn_beamformer import SNNBeamformer
+
+    z = golden("design_other_geometries.npz")
+    fs, f = 48_000, int(z["freq_design"])
+    tau = 1 / (2 * np.pi * f)
+    t = np.arange(0, 0.6, step=1 / fs)
+    if which == "rand":
+        np.random.seed(1)
+        geo = Random2DArray(radius=4.5e-2, num_mic=13)
+        s = np.sin(2 * np.pi * f * t)
+    else:
+        geo = LinearArray(spacing=2 * 4.5e-2 / 7, num_mic=7, radius=4.5e-2)
+        s = z["lin_template_f32"].astype(np.float64)
+    np.testing.assert_array_equal(geo.r_vec, z[f"{which}_r"])
+    np.testing.assert_array_equal(geo.theta_vec, z[f"{which}_theta"])
+    M = len(geo)
+    bf = SNNBeamformer(geo, 10e-3, [f / 2, 2 * f], [tau, tau], bipolar_spikes=False, fs=fs)
+    ref = z[f"{which}_bf_mat"]
+    refc = ref[:M] + 1j * ref[M:]
+    for svd in ("host", "device"):
+        W = bf.design_from_template((t, s), z[f"{which}_doa_list"], svd=svd)
+        assert W.shape == ref.shape
+        np.testing.assert_allclose(W, ref, rtol=0, atol=2e-7)
+        Wc = W[:M] + 1j * W[M:]
+        np.testing.assert_allclose(np.abs(Wc.conj().T @ Wc), np.abs(refc.conj().T @ refc), rtol=0, atol=1e-6)
+    # the covariances the reference decomposed, from the device chain
+    idx = z[f"{which}_cov_idx"]
+    delays = geo.delays(z[f"{which}_doa_list"][idx], normalized=True)
+    delays = delays - delays.min(axis=1, keepdims=True)
+    tt = np.arange(t.min(), t.max(), step=1 / fs)
+    ss = np.interp(tt, t, s)
+    td = np.maximum(tt.reshape(1, 1, -1) - delays[:, :, None], tt.min())
+    sig = np.ascontiguousarray(np.transpose(np.interp(td.ravel(), tt, ss).reshape(td.shape), (0, 2, 1)))
+    cov = bf.membrane_covariance_batch(sig, time_vec=tt, t_start=sig.shape[1] // 4).cpu().numpy()
+    np.testing.assert_allclose(cov, z[f"{which}_cov_sel"], rtol=0, atol=1e-12)

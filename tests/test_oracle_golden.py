@@ -296,3 +296,44 @@ def test_unipolar_design_covariances_high_frequencies(f):
             lo, hi = (mid, hi) if np.sum(theta**2 / (D - mid)) < 0.0 else (lo, mid)
         vec = U @ (theta / (D - (lo + hi) / 2))
         np.testing.assert_allclose(vec / np.linalg.norm(vec), z[f"bf_mat_f{f}"][:, g], rtol=0, atol=1e-7)
+
+
+def _secular_vector(C):
+    """ref:micloc/snn_beamformer.py:372-422 restated: the singular vector of C conditioned on being orthogonal to the all-one vector."""
+    U, D, _ = np.linalg.svd(C)
+    theta = U.T @ np.ones(C.shape[0])
+    lo, hi = D[1], D[0]
+    while (hi - lo) / lo >= 1e-8:
+        mid = (lo + hi) / 2
+        lo, hi = (mid, hi) if np.sum(theta**2 / (D - mid)) < 0.0 else (lo, mid)
+    vec = U @ (theta / (D - (lo + hi) / 2))
+    return vec / np.linalg.norm(vec)
+
+
+@pytest.mark.parametrize("which", ["rand", "lin"])
+def test_designs_on_other_geometries(which):
+    """design_from_template as two more scripts of SURVEY 8b's call surface use it: a 13-microphone Random2DArray (26 channels, DoAs
+    shifted by pi; ref:paper_plots/array_resolution_random_snn.py:100-170) and a 7-microphone LinearArray with DoAs in [0, pi] and a
+    frequency-jittered template (ref:paper_plots/array_resolution_linear_snn.py:120-190): the oracle's chain on the delayed template
+    reproduces the covariances the reference decomposed (1e-12) and their conditional singular vectors its bf_mat columns."""
+    z = golden("design_other_geometries.npz")
+    fs, f = 48_000, int(z["freq_design"])
+    b, a = O.bandpass(fs, [f / 2, 2 * f])
+    ker = O.stht_kernel(fs, 10e-3)
+    w = O.robust_width(fs, 2 * f)
+    tau = 1 / (2 * np.pi * f)
+    t = np.arange(0, 0.6, step=1 / fs)
+    s = np.sin(2 * np.pi * f * t) if which == "rand" else z["lin_template_f32"].astype(np.float64)
+    tt = np.arange(t.min(), t.max(), step=1 / fs)
+    ss = np.interp(tt, t, s)
+    nir = O.neuron_kernel(tt, [tau, tau])
+    r_vec, th_vec = z[f"{which}_r"], z[f"{which}_theta"]
+    C2 = 2 * len(r_vec)
+    assert C2 == {"rand": 26, "lin": 14}[which] and z[f"{which}_bf_mat"].shape == (C2, {"rand": 833, "lin": 449}[which])
+    for j, g in enumerate(z[f"{which}_cov_idx"][:3]):
+        d = O.delays(r_vec, th_vec, z[f"{which}_doa_list"][g], True)
+        x = np.stack([np.interp(np.maximum(tt - dm, tt.min()), tt, ss) for dm in d], axis=1)
+        v = O.snn_chain(x, ker, b, a, w, False, nir, np.eye(C2), want=("vmem",))["vmem"][len(tt) // 4:]
+        C = v.T @ v / v.shape[0]
+        np.testing.assert_allclose(C, z[f"{which}_cov_sel"][j], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(_secular_vector(C), z[f"{which}_bf_mat"][:, g], rtol=0, atol=1e-7)
