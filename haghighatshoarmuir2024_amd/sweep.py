@@ -108,7 +108,9 @@ def device_localizer(beamf, bf_mat, max_batch=1100):
     def run(sig_batch, time_vec):
         am, pm = [], []
         for s in range(0, len(sig_batch), max_batch):
-            out = beamf.localize_batch(bf_mat, sig_batch[s : s + max_batch], time_vec=time_vec)
+            # (the non-spiking complex Beamformer has no neuron kernel, hence no time axis to pass: ref:paper_plots/target_localization.py)
+            kw = dict(time_vec=time_vec) if hasattr(beamf, "tau_vec") else {}
+            out = beamf.localize_batch(bf_mat, sig_batch[s : s + max_batch], **kw)
             a = out["argmax"].cpu().numpy().astype(np.int64)
             p = out["power"].cpu().numpy()
             am.append(a)

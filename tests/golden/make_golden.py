@@ -860,6 +860,36 @@ def gen_design_other_geometries():
     save("design_other_geometries.npz", **out)
 
 
+def gen_beamformer_sweep():
+    """The accuracy sweep of the NON-spiking complex Beamformer (paper_plots/target_localization.py:400-440: the loop of
+    target_snn_localization.py on Beamformer.apply_to_template, G = 8*7+1 = 57), 3 of the 11 SNRs x 40 trials, np.random.seed(0)."""
+    radius, num_mic, fs = 4.5e-2, 7, 48_000
+    freq_design = 2_000
+    freq_range = [0.5 * freq_design, freq_design]
+    beamf = Beamformer(geometry=CenterCircularArray(radius=radius, num_mic=num_mic), kernel_duration=10.0e-3, freq_range=freq_range, fs=fs)
+    z = np.load(os.path.join(OUT, "beamformer_c128.npz"))
+    bf_mat, doa_list = z["bf_mat"], z["doa_list"]
+    snr_gain = (fs / 2) / (freq_range[1] - freq_range[0])
+    snr_db_vec = np.array([-10.0, 5.0, 20.0])
+    num_sim = 40
+    time_test = np.arange(0, 100e-3, step=1 / fs)
+    sig_test = np.sin(2 * np.pi * freq_design * time_test)
+    np.random.seed(0)
+    shape = (len(snr_db_vec), num_sim)
+    doa, amax, err, pmax = np.zeros(shape), np.zeros(shape, dtype=np.int64), np.zeros(shape), np.zeros(shape)
+    for i, snr_db in enumerate(snr_db_vec):
+        snr_t = snr_db - 10 * np.log10(snr_gain)
+        for sim in range(num_sim):
+            d = np.random.rand(1)[0] * 2 * np.pi
+            y = beamf.apply_to_template(bf_mat=bf_mat, template=(time_test, sig_test, d), snr_db=snr_t)
+            power = np.mean(np.abs(y) ** 2, axis=0)
+            k = int(np.argmax(power))
+            doa[i, sim], amax[i, sim], pmax[i, sim] = d, k, power[k]
+            err[i, sim] = np.arcsin(np.abs(np.sin(doa_list[k] - d)))
+    save("beamformer_sweep_seed0.npz", seed=np.int64(0), snr_db_vec=snr_db_vec, num_sim=np.int64(num_sim), doa=doa, argmax=amax, err=err, pmax=pmax,
+         mae_deg=np.mean(err, axis=1) * 180 / np.pi)
+
+
 GENS = {
     "kat_init": gen_kat_init,
     "bf_mat_chirp": gen_bf_mat_chirp,
@@ -880,6 +910,7 @@ GENS = {
     "beamformer_c128_g449": gen_beamformer_c128_g449,
     "stress_case": gen_stress_case,
     "design_other_geometries": gen_design_other_geometries,
+    "beamformer_sweep": gen_beamformer_sweep,
 }
 
 if __name__ == "__main__":

@@ -221,3 +221,21 @@ def test_designs_on_other_geometries(which, torch):
     sig = np.ascontiguousarray(np.transpose(np.interp(td.ravel(), tt, ss).reshape(td.shape), (0, 2, 1)))
     cov = bf.membrane_covariance_batch(sig, time_vec=tt, t_start=sig.shape[1] // 4).cpu().numpy()
     np.testing.assert_allclose(cov, z[f"{which}_cov_sel"], rtol=0, atol=1e-12)
+
+
+def test_beamformer_sweep_matches_reference(cfg2, torch):
+    """The complex Beamformer through the sweep harness (parity mode: the reference's MT19937 stream replayed on the host) against the
+    reference's own sweep output (ref:paper_plots/target_localization.py:400-440): every arg-max, p_max 1e-10, the MAE curve."""
+    from haghighatshoarmuir2024_amd.sweep import noisy_target_sweep
+    from micloc.array_geometry import CenterCircularArray
+    from micloc.beamformer import Beamformer
+
+    z = golden("beamformer_sweep_seed0.npz")
+    W = golden("beamformer_c128.npz")
+    bf = Beamformer(CenterCircularArray(4.5e-2, 7), 10e-3, [1000.0, 2000.0], fs=48_000)
+    res = noisy_target_sweep(bf, W["bf_mat"], W["doa_list"], snr_db_vec=z["snr_db_vec"], num_sim=int(z["num_sim"]), seed=int(z["seed"]), mode="parity")
+    np.testing.assert_array_equal(res["doa"], z["doa"])
+    np.testing.assert_array_equal(res["argmax"], z["argmax"])
+    np.testing.assert_allclose(res["pmax"], z["pmax"], rtol=1e-10)
+    np.testing.assert_allclose(res["err"], z["err"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(res["mae_deg"], z["mae_deg"], rtol=0, atol=1e-9)

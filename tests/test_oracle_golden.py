@@ -337,3 +337,24 @@ def test_designs_on_other_geometries(which):
         C = v.T @ v / v.shape[0]
         np.testing.assert_allclose(C, z[f"{which}_cov_sel"][j], rtol=0, atol=1e-12)
         np.testing.assert_allclose(_secular_vector(C), z[f"{which}_bf_mat"][:, g], rtol=0, atol=1e-7)
+
+
+def test_beamformer_sweep_first_trials(cfg2):
+    """The complex Beamformer's accuracy sweep (ref:paper_plots/target_localization.py:400-440) on the reference's RNG stream: the
+    oracle's chain gives the reference's arg-max, p_max and error for the first trials of the first SNR."""
+    z = golden("beamformer_sweep_seed0.npz")
+    W = golden("beamformer_c128.npz")
+    fs = 48_000
+    time_test = np.arange(0, 100e-3, step=1 / fs)
+    sig_test = np.sin(2 * np.pi * 2000 * time_test)
+    np.random.seed(int(z["seed"]))
+    snr_t = float(z["snr_db_vec"][0]) - 10 * np.log10((fs / 2) / 1000.0)
+    for sim in range(12):
+        doa = np.random.rand(1)[0] * 2 * np.pi
+        assert doa == z["doa"][0, sim]
+        t, sig = O.synth_template(cfg2["r_vec"], cfg2["theta_vec"], time_test, sig_test, doa, fs)
+        O.add_noise(sig, snr_t)
+        out = O.beamformer_chain(sig, cfg2["kernel"], cfg2["b"], cfg2["a"], W["bf_mat"], want_y=False)
+        assert out["argmax"] == int(z["argmax"][0, sim])
+        np.testing.assert_allclose(out["power"][out["argmax"]], z["pmax"][0, sim], rtol=1e-10)
+        assert abs(O.doa_error(W["doa_list"][out["argmax"]], doa) - z["err"][0, sim]) < 1e-12
