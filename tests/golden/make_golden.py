@@ -890,6 +890,45 @@ def gen_beamformer_sweep():
          mae_deg=np.mean(err, axis=1) * 180 / np.pi)
 
 
+def gen_live_demo_frame():
+    """The body of the live demo's loop (micloc/localization_demo_snn.py:125-193 with test_demo's configuration :196-222: one band
+    [1600, 2400], 112 DoAs, 0.25 s packs, bipolar) restated from the reference's own components -- the module itself needs the sound
+    card's recorder --: design per band, order-1 filterbank, apply_to_signal, power summed over the bands, arg-max.  The pack is a
+    synthetic recording (2 kHz tone from one direction + noise) in the devkit's format: int32, 8 channels, the last one unused."""
+    fs, num_mic = 48_000, 7
+    geometry = CenterCircularArray(radius=4.5e-2, num_mic=num_mic)
+    freq_bands = [[1600, 2400]]
+    doa_list = np.linspace(-np.pi, np.pi, 16 * num_mic)
+    rec = 0.25
+    beamfs, bf_mats = [], []
+    for fr in freq_bands:
+        fm = np.mean(fr)
+        tau = 1 / (2 * np.pi * fm)
+        bfm = SNNBeamformer(geometry=geometry, kernel_duration=10e-3, freq_range=fr, tau_vec=[tau, tau], bipolar_spikes=True, fs=fs)
+        t = np.arange(0, rec, step=1 / fs)
+        bf_mats.append(quiet(bfm.design_from_template, template=(t, np.sin(2 * np.pi * fm * t)), doa_list=doa_list))
+        beamfs.append(bfm)
+    fb = ButterworthFilterbank(freq_bands=freq_bands, order=1, fs=fs)
+    T = int(rec * fs)
+    tt = np.arange(T) / fs
+    rng = np.random.RandomState(21)
+    d = geometry.delays(2.1, normalized=True)
+    sig = np.sin(2 * np.pi * 2000 * (tt.reshape(-1, 1) - d.reshape(1, -1))) + 0.4 * rng.randn(T, num_mic)
+    pack = np.zeros((T, 8), dtype=np.int32)
+    pack[:, :7] = (np.rint(sig * 4096).astype(np.int32)) << 8
+    data = np.asarray(pack[:, :-1], dtype=np.float64)
+    assert np.sqrt(np.mean(data**2)) > 1e-4 * np.iinfo(np.int32).max
+    time_vec = np.arange(0, T) / fs
+    data_filt = fb.evolve(sig_in=data)
+    power_grid = 0
+    for filt, W, bfm in zip(data_filt, bf_mats, beamfs):
+        y = bfm.apply_to_signal(bf_mat=W, sig_in_vec=(time_vec, filt))
+        power_grid = power_grid + np.mean(np.abs(y) ** 2, axis=0)
+    k = int(np.argmax(power_grid))
+    save("live_demo_frame.npz", pack=pack, bf_mat0=bf_mats[0], doa_list=doa_list, freq_bands=np.asarray(freq_bands, dtype=np.float64), power_grid=power_grid,
+         doa_index=np.int64(k), doa_deg=np.float64(doa_list[k] * 180 / np.pi), true_doa=np.float64(2.1))
+
+
 GENS = {
     "kat_init": gen_kat_init,
     "bf_mat_chirp": gen_bf_mat_chirp,
@@ -911,6 +950,7 @@ GENS = {
     "stress_case": gen_stress_case,
     "design_other_geometries": gen_design_other_geometries,
     "beamformer_sweep": gen_beamformer_sweep,
+    "live_demo_frame": gen_live_demo_frame,
 }
 
 if __name__ == "__main__":

@@ -239,3 +239,24 @@ def test_beamformer_sweep_matches_reference(cfg2, torch):
     np.testing.assert_allclose(res["pmax"], z["pmax"], rtol=1e-10)
     np.testing.assert_allclose(res["err"], z["err"], rtol=0, atol=1e-12)
     np.testing.assert_allclose(res["mae_deg"], z["mae_deg"], rtol=0, atol=1e-9)
+
+
+def test_live_demo_frame_matches_reference(torch):
+    """localization_demo_snn.Demo (the reference's live loop without the sound card) on the reference-generated pack: the designed
+    bf_mat, the power pattern and the DoA the reference's own components produced (ref:micloc/localization_demo_snn.py:125-193)."""
+    from micloc.array_geometry import CenterCircularArray
+    from micloc.localization_demo_snn import Demo
+
+    z = golden("live_demo_frame.npz")
+    demo = Demo(geometry=CenterCircularArray(4.5e-2, 7), freq_bands=z["freq_bands"], doa_list=z["doa_list"], recording_duration=0.25,
+                kernel_duration=10e-3, bipolar_spikes=True, fs=48_000)
+    W, R = demo.bf_mats[0], z["bf_mat0"]
+    Wc, Rc = W[:7] + 1j * W[7:], R[:7] + 1j * R[7:]
+    phase = np.sum(np.conj(Wc) * Rc, axis=0)
+    np.testing.assert_allclose(Wc * (phase / np.abs(phase)), Rc, rtol=0, atol=1e-8)  # (up to the unit phase of U[:, 0])
+    demo.bf_mats[0] = R  # the reference's own matrix for the frame itself
+    data = z["pack"][:, :-1].astype(np.float64)
+    np.testing.assert_allclose(demo.power_grid(data), z["power_grid"], rtol=1e-10, atol=0)
+    assert demo.process_frame(z["pack"]) == float(z["doa_deg"])
+    # pi-periodic error against the direction the pack was synthesised from (SURVEY A.8)
+    assert abs(np.degrees(np.arcsin(abs(np.sin(np.radians(float(z["doa_deg"])) - float(z["true_doa"])))))) < 5

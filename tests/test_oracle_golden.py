@@ -358,3 +358,25 @@ def test_beamformer_sweep_first_trials(cfg2):
         assert out["argmax"] == int(z["argmax"][0, sim])
         np.testing.assert_allclose(out["power"][out["argmax"]], z["pmax"][0, sim], rtol=1e-10)
         assert abs(O.doa_error(W["doa_list"][out["argmax"]], doa) - z["err"][0, sim]) < 1e-12
+
+
+def test_live_demo_frame():
+    """The live demo's loop body (ref:micloc/localization_demo_snn.py:125-193) on one synthetic 0.25 s pack, produced by the reference's own
+    filterbank / SNNBeamformer: the oracle composition (order-1 filterbank, chain per band, summed power) gives its power pattern and DoA."""
+    z = golden("live_demo_frame.npz")
+    from scipy.signal import butter
+
+    fs = 48_000
+    data = z["pack"][:, :-1].astype(np.float64)
+    T = data.shape[0]
+    power = 0
+    for fr in z["freq_bands"]:
+        b1, a1 = butter(1, fr, btype="bandpass", analog=False, output="ba", fs=fs)
+        filt = O.iir(b1, a1, data)
+        bb, aa = O.bandpass(fs, fr)
+        tau = 1 / (2 * np.pi * np.mean(fr))
+        nir = O.neuron_kernel(np.arange(T) / fs, [tau, tau])
+        out = O.snn_chain(filt, O.stht_kernel(fs, 10e-3), bb, aa, O.robust_width(fs, fr[1]), True, nir, z["bf_mat0"], want=("power",))
+        power = power + out["power"]
+    np.testing.assert_allclose(power, z["power_grid"], rtol=1e-10, atol=0)
+    assert int(np.argmax(power)) == int(z["doa_index"])
