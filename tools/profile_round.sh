@@ -20,6 +20,8 @@ cmd bench_n1_speech.json "python3 bench.py --config speech --steps 16 --warmup 4
 cmd bench_n1_speech_graphs.json "python3 bench.py --config speech --steps 16 --warmup 4 --schedule graphs --no-cpu-baseline"
 cmd bench_n1_stress.json "python3 bench.py --config stress --steps 9 --warmup 3"
 cmd bench_n1_xylo.json "python3 bench.py --config xylo --steps 12 --warmup 3"
+cmd bench_n1_sustained60.json "python3 bench.py --steps 20 --warmup 5 --sustained-seconds 60 --no-cpu-baseline --no-other-configs"
+cmd bench_n1_stress_sustained20.json "python3 bench.py --config stress --steps 9 --warmup 3 --sustained-seconds 20 --no-cpu-baseline --no-other-configs"
 cmd kernel_trace_summary_by_shape.csv "rocprofv3 --output-format csv --kernel-trace --stats -- python3 bench.py --steps 40 --warmup 4 --no-cpu-baseline --no-other-configs --streams 1 | tools/summarize_profiles.py trace"
 cmd kernel_stats_bench_steps40_streams1.csv "rocprofv3 --kernel-trace --stats (the same run): rocprofv3's own kernel_stats.csv"
 cmd kernel_trace_summary_grid449.csv "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 4 --grid 449 --no-cpu-baseline --no-other-configs --streams 1 | summarize_profiles.py trace"
@@ -47,6 +49,9 @@ python3 bench.py --config speech --steps 16 --warmup 4 > $OUT/bench_n1_speech.js
 python3 bench.py --config speech --steps 16 --warmup 4 --schedule graphs --no-cpu-baseline > $OUT/bench_n1_speech_graphs.json 2> $OUT/bench_n1_speech_graphs.err
 python3 bench.py --config stress --steps 9 --warmup 3 > $OUT/bench_n1_stress.json 2> $OUT/bench_n1_stress.err
 python3 bench.py --config xylo --steps 12 --warmup 3 > $OUT/bench_n1_xylo.json 2> $OUT/bench_n1_xylo.err
+# one minute of headline steps / twenty seconds of the stress step in one uninterrupted region each (clock, power, temperature per segment)
+python3 bench.py --steps 20 --warmup 5 --sustained-seconds 60 --no-cpu-baseline --no-other-configs > $OUT/bench_n1_sustained60.json 2> $OUT/bench_n1_sustained60.err
+python3 bench.py --config stress --steps 9 --warmup 3 --sustained-seconds 20 --no-cpu-baseline --no-other-configs > $OUT/bench_n1_stress_sustained20.json 2> $OUT/bench_n1_stress_sustained20.err
 # per-kernel times: serial steps so that every launch is timed alone
 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace -o run -- python3 bench.py --steps 40 --warmup 4 --no-cpu-baseline --no-other-configs --streams 1 --sustained-seconds 0 > $OUT/trace.log 2>&1
 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace_g449 -o run -- python3 bench.py --steps 20 --warmup 4 --grid 449 --no-cpu-baseline --no-other-configs --streams 1 --sustained-seconds 0 > $OUT/trace_g449.log 2>&1
