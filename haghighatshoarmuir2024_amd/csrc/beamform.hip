@@ -359,6 +359,7 @@ __device__ __forceinline__ void ws_stage2_y(const double *Vl, const double *__re
 // wave; the double-buffered form takes 100 and runs two per CU: 1.13 against 1.07 ms per launch, step 1.63 against 1.59 ms).
 // Four DoA tiles per wave (G > 384) do not fit 80 registers and run as two passes of two.
 constexpr int WS_KV_WAVES = 6;
+constexpr int WS_LIST_CAP = 16;  // entries per unit of the event-driven LIF stage's spike lists
 // SPARSE: the LIF stage event by event on the vector ALU instead of as a dense Toeplitz product on the matrix cores (below).
 template <int NGW, int NT, bool WANT_Y, int KM, int KV, bool SPARSE = false>
 __global__ __launch_bounds__(BF_THREADS, WANT_Y ? 2 : (KV ? WS_KV_WAVES : (NT == 2 ? 6 : 4))) void beamform_ws_kernel(
@@ -451,67 +452,135 @@ __global__ __launch_bounds__(BF_THREADS, WANT_Y ? 2 : (KV ? WS_KV_WAVES : (NT ==
         // table offset (s_lshl), the lanes' address (v_sub), the read, the fma; the read of spike k + 1 is issued before the fma of
         // spike k waits for its own.
         const char *pl = reinterpret_cast<const char *>(Pt) + 8 * (l + H + 63);  // this lane's nir[d = l + H - j] at j = 0
-        for (int u = wv; u < CPAD * NB; u += BF_WAVES) {  // (wave-uniform)
-            const int c = u / NB, blk = u - c * NB;
-            const int f0 = cs + 64 * blk;
-            if (f0 >= T) continue;
-            double acc = 0.0;
-            if (c < C) {
-                const int8_t *row = Sb + c * RS + 64 * blk;
-                const int b0 = row[l];
-                const int b1 = l < H ? row[64 + l] : 0;
-                const unsigned long long m0 = __builtin_amdgcn_ballot_w64(b0 != 0), m1 = __builtin_amdgcn_ballot_w64(b1 != 0);
-                const unsigned long long g0 = __builtin_amdgcn_ballot_w64(b0 < 0), g1 = __builtin_amdgcn_ballot_w64(b1 < 0);
-                const bool ternary = __builtin_amdgcn_ballot_w64((unsigned)(b0 + 1) > 2u || (unsigned)(b1 + 1) > 2u) == 0;
-                if (ternary) {
-                    // spike at bit j of a word: row f0 - H + j (+ 64), distance to this lane's frame d = l + H - j, nir[d] = *(base - 8 j)
-                    const unsigned kneg = 0xbff00000u, kpos = 0x3ff00000u;  // high words of -1.0 / +1.0 (in scalar registers)
-                    auto walk = [&](unsigned long long mm, const unsigned long long gg, const char *base) {
-                        if (!mm) return;
-                        auto pop = [&](unsigned &hi) {
-                            const int j = __builtin_ctzll(mm);
-                            asm("s_bitset0_b64 %0, %1" : "+s"(mm) : "s"(j));
-                            asm("s_bitcmp1_b64 %1, %2\n\ts_cselect_b32 %0, %3, %4" : "=s"(hi) : "s"(gg), "s"(j), "s"(kneg), "s"(kpos) : "scc");
-                            return *reinterpret_cast<const double *>(base - 8 * j);
-                        };
-                        // two spikes per trip, each with its own registers: the read of one is in flight while the other is added
-                        unsigned hiA, hiB;
-                        double nvA = pop(hiA), nvB;
-                        for (;;) {
-                            if (!mm) {
-                                acc = __builtin_fma(__hiloint2double((int)hiA, 0), nvA, acc);
-                                break;
-                            }
-                            nvB = pop(hiB);
-                            acc = __builtin_fma(__hiloint2double((int)hiA, 0), nvA, acc);
-                            if (!mm) {
-                                acc = __builtin_fma(__hiloint2double((int)hiB, 0), nvB, acc);
-                                break;
-                            }
-                            nvA = pop(hiA);
-                            acc = __builtin_fma(__hiloint2double((int)hiB, 0), nvB, acc);
-                        }
-                    };
-                    walk(m0, g0, pl);
-                    walk(m1, g1, pl - 512);
-                } else {
-                    // a raster that is not the encoder's (any int8 value): the value itself, broadcast from its lane
-                    unsigned long long mm = m0;
-                    while (mm) {
-                        const int j = __builtin_ctzll(mm);
-                        mm &= mm - 1;
-                        acc = __builtin_fma(*reinterpret_cast<const double *>(pl - 8 * j), (double)__builtin_amdgcn_readlane(b0, j), acc);
+        // ---- fourth form: NO scalar work per spike, vector work in batches --------------------------------------------------------------
+        // An isolated vector instruction on a SIMD whose other waves keep the matrix pipe full pays the MFMA -> VALU switch every time
+        // (the three forms above: two isolated instructions per spike).  Here the lanes that hold a spike byte COMPACT the unit's spikes
+        // into a wave-private LDS list (rank = mbcnt of the ballot: entry = table offset 8 j and the sign as a double), and the
+        // accumulation walks the lists of four units side by side, two entries per unit and round: eight broadcast reads of the
+        // entries, eight address subtractions, eight table reads, eight fmas (four independent chains, interleaved) -- straight-line
+        // batches, the trip count from the popcounts.  Lists are zero filled: a missing entry adds 0 * nir[.] == nothing.  A unit with
+        // more spikes than a list holds, or with bytes outside {-1, 0, +1}, is walked on the scalar unit afterwards (never on the
+        // encoder's rasters at robust widths >= 6).  MEASURED (tools/dev/bf_bench.py, BF_RASTER): 1006-1012 us on the encoder's raster
+        // against the dense product's 1001; on an all-zero raster (no rounds at all) 910 against 995 -- the stage's fixed part (transposed
+        // staging, masks, compaction) is 58 us above the 852 us of a launch without any LIF, the rounds another 100: the trip count of a
+        // group is its LONGEST list (11 for a mean of 8 spikes per unit), so 78 slots are processed for 47 spikes.  Still not below the
+        // dense product's 140 us.
+        constexpr int NU = (CPAD * NB + BF_WAVES - 1) / BF_WAVES;
+        constexpr int LCAP = WS_LIST_CAP;
+        double *ls = reinterpret_cast<double *>(Sb + 16 * RS) + (size_t)wv * NU * LCAP;                      // signs  [NU][LCAP]
+        int *lo = reinterpret_cast<int *>(reinterpret_cast<double *>(Sb + 16 * RS) + BF_WAVES * NU * LCAP) + wv * NU * LCAP;  // offsets
+        for (int e = l; e < NU * LCAP; e += 64) {
+            ls[e] = 0.0;
+            lo[e] = 0;
+        }
+        unsigned long long m0[NU], m1[NU], g0[NU], g1[NU];
+        int bb0[NU], bb1[NU], cnt[NU];
+        bool slow[NU];
+        {
+            int b0[NU], b1[NU];
+#pragma unroll
+            for (int i = 0; i < NU; ++i) {
+                const int u = wv + BF_WAVES * i;
+                const int c = u / NB, blk = u - c * NB;
+                const bool live = u < CPAD * NB && c < C && cs + 64 * blk < T;  // (wave-uniform)
+                const int8_t *row = Sb + (live ? c : 0) * RS + 64 * blk;
+                b0[i] = live ? row[l] : 0;
+                b1[i] = (live && l < H) ? row[64 + l] : 0;
+            }
+#pragma unroll
+            for (int i = 0; i < NU; ++i) {
+                m0[i] = __builtin_amdgcn_ballot_w64(b0[i] != 0);
+                m1[i] = __builtin_amdgcn_ballot_w64(b1[i] != 0);
+                g0[i] = __builtin_amdgcn_ballot_w64(b0[i] < 0);
+                g1[i] = __builtin_amdgcn_ballot_w64(b1[i] < 0);
+                const unsigned mx = (unsigned)(b0[i] + 1) > (unsigned)(b1[i] + 1) ? (unsigned)(b0[i] + 1) : (unsigned)(b1[i] + 1);
+                const bool tern = __builtin_amdgcn_ballot_w64(mx > 2u) == 0;
+                const int n0 = __builtin_popcountll(m0[i]);
+                cnt[i] = n0 + __builtin_popcountll(m1[i]);
+                slow[i] = !tern || cnt[i] > LCAP;
+                bb0[i] = b0[i];
+                bb1[i] = b1[i];
+                if (!slow[i]) {
+                    const unsigned r0 = __builtin_amdgcn_mbcnt_hi((unsigned)(m0[i] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m0[i], 0u));
+                    const unsigned r1 = n0 + __builtin_amdgcn_mbcnt_hi((unsigned)(m1[i] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m1[i], 0u));
+                    if (b0[i] != 0) {
+                        lo[i * LCAP + r0] = 8 * l;
+                        reinterpret_cast<unsigned *>(ls + i * LCAP + r0)[1] = b0[i] < 0 ? 0xbff00000u : 0x3ff00000u;
                     }
-                    mm = m1;
-                    while (mm) {
-                        const int j = __builtin_ctzll(mm);
-                        mm &= mm - 1;
-                        acc = __builtin_fma(*reinterpret_cast<const double *>(pl - 8 * (64 + j)), (double)__builtin_amdgcn_readlane(b1, j), acc);
+                    if (b1[i] != 0) {
+                        lo[i * LCAP + r1] = 8 * (64 + l);
+                        reinterpret_cast<unsigned *>(ls + i * LCAP + r1)[1] = b1[i] < 0 ? 0xbff00000u : 0x3ff00000u;
                     }
                 }
             }
-            Vl[(4 * blk + q) * 256 + c * 16 + lc] = (f0 + l < T) ? acc : 0.0;  // fragment order: [tile][channel][frame & 15]
         }
+        double accu[NU];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) accu[i] = 0.0;
+        constexpr int GU = 4, RB = 2;
+#pragma unroll
+        for (int gq = 0; gq < NU; gq += GU) {
+            constexpr int dummy = 0;
+            (void)dummy;
+            int nmax = 0;
+#pragma unroll
+            for (int k = 0; k < GU; ++k)
+                if (gq + k < NU) nmax = (!slow[gq + k] && cnt[gq + k] > nmax) ? cnt[gq + k] : nmax;
+            const int rounds = (nmax + RB - 1) / RB;
+            const double *lsg = ls + gq * LCAP;
+            const int *log_ = lo + gq * LCAP;
+            for (int r = 0; r < rounds; ++r) {
+                int off[GU][RB];
+                double sg[GU][RB], nv[GU][RB];
+#pragma unroll
+                for (int k = 0; k < GU; ++k)
+#pragma unroll
+                    for (int e = 0; e < RB; ++e)
+                        if (gq + k < NU) {
+                            off[k][e] = log_[k * LCAP + RB * r + e];
+                            sg[k][e] = lsg[k * LCAP + RB * r + e];
+                        }
+#pragma unroll
+                for (int k = 0; k < GU; ++k)
+#pragma unroll
+                    for (int e = 0; e < RB; ++e)
+                        if (gq + k < NU) nv[k][e] = *reinterpret_cast<const double *>(pl - off[k][e]);
+#pragma unroll
+                for (int e = 0; e < RB; ++e)
+#pragma unroll
+                    for (int k = 0; k < GU; ++k)
+                        if (gq + k < NU) accu[gq + k] = __builtin_fma(sg[k][e], nv[k][e], accu[gq + k]);
+            }
+        }
+        // the rare units the lists do not serve: the scalar walk (any int8 value, any number of spikes)
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+            if (slow[i]) {  // (wave-uniform)
+                double acc = 0.0;
+                unsigned long long mm = m0[i];
+                while (mm) {
+                    const int j = __builtin_ctzll(mm);
+                    mm &= mm - 1;
+                    acc = __builtin_fma(*reinterpret_cast<const double *>(pl - 8 * j), (double)__builtin_amdgcn_readlane(bb0[i], j), acc);
+                }
+                mm = m1[i];
+                while (mm) {
+                    const int j = __builtin_ctzll(mm);
+                    mm &= mm - 1;
+                    acc = __builtin_fma(*reinterpret_cast<const double *>(pl - 8 * (64 + j)), (double)__builtin_amdgcn_readlane(bb1[i], j), acc);
+                }
+                accu[i] = acc;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+            const int u = wv + BF_WAVES * i;
+            const int c = u / NB, blk = u - c * NB;
+            if (u < CPAD * NB && cs + 64 * blk < T)  // fragment order: [tile][channel][frame & 15]
+                Vl[(4 * blk + q) * 256 + c * 16 + lc] = (cs + 64 * blk + l < T) ? accu[i] : 0.0;
+        }
+        (void)g0;
+        (void)g1;
         __syncthreads();
     }
     // [ union{ spike tile as fp64 [R][16] , V fragments [32 tiles][4 k-steps][64 lanes] } ][ nir table ]
@@ -678,7 +747,8 @@ static size_t ws_lds_bytes(const NeuronTab &nt, int NT, int Gy = 0)
 {
     const int R = BF_WAVES * NT * 16 + nt.n - 1;
     const int RS4 = ((R + 3) / 4 + 1) | 1;
-    return (size_t)BF_WAVES * NT * 256 * sizeof(double) + (size_t)(126 + nt.n) * sizeof(double) + (size_t)16 * 4 * RS4;
+    const size_t lists = (size_t)BF_WAVES * 8 * WS_LIST_CAP * (sizeof(double) + sizeof(int));  // (at most 8 units per wave: 16 channels)
+    return (size_t)BF_WAVES * NT * 256 * sizeof(double) + (size_t)(126 + nt.n) * sizeof(double) + (size_t)16 * 4 * RS4 + lists;
 }
 
 // The event-driven LIF stage serves power-only launches whose neuron kernel spans at most 65 frames (two ballot words per unit),

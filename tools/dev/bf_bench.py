@@ -25,6 +25,15 @@ t = np.arange(T) / fs
 x = torch.from_numpy(np.sin(2 * np.pi * 2000 * t)[None, :, None] * np.ones((B, 1, M)) + 0.7 * rng.randn(B, T, M)).cuda()
 out = p.snn_pipeline(x, want_spikes=True, want_power=True)
 torch.cuda.synchronize()
+mode = os.environ.get("BF_RASTER", "encoder")  # encoder | zero | dense | sparse_random: what the stage multiplies (timing against the DATA)
+if mode == "zero":
+    out["spikes"].zero_()
+elif mode == "dense":
+    out["spikes"].copy_(torch.randint(-1, 2, out["spikes"].shape, device="cuda", dtype=torch.int8))
+elif mode == "sparse_random":
+    r = torch.rand(out["spikes"].shape, device="cuda")
+    out["spikes"].copy_(((r < 0.04).to(torch.int8) - (r > 0.96).to(torch.int8)))
+torch.cuda.synchronize()
 dens = float((out["spikes"] != 0).double().mean())
 def run():
     p.snn_pipeline(x, stages=4, out=out)
@@ -38,5 +47,5 @@ for rep in range(3):
     for _ in range(N): run()
     e1.record(); torch.cuda.synchronize()
     ts.append(e0.elapsed_time(e1) / N * 1e3)
-print(os.path.basename(os.environ.get("MICLOC_DEV_LIB", "default")), "lif+beamform+power %.1f / %.1f / %.1f us" % tuple(ts), " G", G, " spike density %.4f" % dens,
+print(os.path.basename(os.environ.get("MICLOC_DEV_LIB", "default")), "lif+beamform+power %.1f / %.1f / %.1f us" % tuple(ts), " G", G, " raster", mode, " spike density %.4f" % float((out["spikes"] != 0).double().mean()),
       " power checksum %.17g" % float(out["power"].sum()), " argmax sum", int(out["argmax"].sum()))
