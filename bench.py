@@ -1289,6 +1289,15 @@ def run(args):
         # every rank runs it (the same load on every GPU of the node); rank 0 reports its own
         barrier()
         sustained = sustained_block(step, pipe, args, dt / args.steps * 1e3, group_size * B * T, local_rank)
+        if use_dist:
+            # like the timed regions: the job's figure is the SLOWEST rank's (every rank ran the same number of steps)
+            ts = torch.tensor([sustained["seconds"]], dtype=torch.float64, device=device)
+            dist.all_reduce(ts, op=dist.ReduceOp.MAX)
+            sustained["seconds_this_rank"] = sustained["seconds"]
+            sustained["seconds"] = float(ts.item())
+            sustained["ms_per_step"] = sustained["seconds"] / sustained["steps"] * 1e3
+            sustained["value"] = group_size * B * T / (sustained["ms_per_step"] * 1e-3)
+            sustained["ratio_to_timed_regions"] = sustained["ms_per_step"] / (dt / args.steps * 1e3)
         barrier()
     # comparisons between the variants and with the CPU baseline use stream 0's batch (wl["x"]): every stream has its own trials
     out, _ = step(index=0)
