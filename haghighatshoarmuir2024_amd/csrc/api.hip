@@ -274,9 +274,6 @@ int micloc_plan_set_neuron_kernel(micloc_plan *p, const double *nir, int n)
     p->ntab.tab = p->d_ntab;
     p->ntab.n = n;
     p->ntab.NK = NK;
-    // a polarity of the encoder keeps at most one frame in `robust_width`: from 4 on the event-driven LIF stage beats the dense product
-    // (a speed hint only: both forms give the same bits for any raster)
-    p->ntab.sparse = p->robust_width >= 4;
     return MICLOC_OK;
 }
 

@@ -359,12 +359,10 @@ __device__ __forceinline__ void ws_stage2_y(const double *Vl, const double *__re
 // wave; the double-buffered form takes 100 and runs two per CU: 1.13 against 1.07 ms per launch, step 1.63 against 1.59 ms).
 // Four DoA tiles per wave (G > 384) do not fit 80 registers and run as two passes of two.
 constexpr int WS_KV_WAVES = 6;
-constexpr int WS_LIST_CAP = 16;  // entries per unit of the event-driven LIF stage's spike lists
-// SPARSE: the LIF stage event by event on the vector ALU instead of as a dense Toeplitz product on the matrix cores (below).
-template <int NGW, int NT, bool WANT_Y, int KM, int KV, bool SPARSE = false>
+template <int NGW, int NT, bool WANT_Y, int KM, int KV>
 __global__ __launch_bounds__(BF_THREADS, WANT_Y ? 2 : (KV ? WS_KV_WAVES : (NT == 2 ? 6 : 4))) void beamform_ws_kernel(
     const int8_t *__restrict__ spikes, const double *__restrict__ ntab_g, int NK, const double *__restrict__ Wp, int GT, int C,
-    int T, double *__restrict__ partial, int G, double *__restrict__ y, const int *__restrict__ chunk_range, int n_nir)
+    int T, double *__restrict__ partial, int G, double *__restrict__ y, const int *__restrict__ chunk_range)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int Gp = 16 * GT;
@@ -382,207 +380,6 @@ __global__ __launch_bounds__(BF_THREADS, WANT_Y ? 2 : (KV ? WS_KV_WAVES : (NT ==
     constexpr int TILES = CH / 16;
     const int cs = chunk * CH;
 
-    if constexpr (SPARSE) {
-        // ---- event-driven LIF (round 5) ----------------------------------------------------------------------------------------------
-        // vmem[t][c] = sum_tau nir[tau] s[t - tau][c] is a sum over the SPIKES of the last n frames: the encoder keeps 7 % of the raster
-        // (two polarities, at least `robust_width` frames apart each), so of the 35 products per output that the Toeplitz form multiplies
-        // on the matrix cores (13 k-steps x 16 channel rows: 0.11 ms of the launch's 0.70 ms of matrix pipe) 2.4 are not zero.  A product
-        // with a zero spike leaves the fma chain's accumulator untouched (acc + (+-0) == acc, and acc is never -0), so skipping them is
-        // exact: the chain below visits the spikes of the window in chronological order -- the order of the oracle's tau-descending
-        // chain -- and adds sign * nir[t - s] with one fma each: the same bits as the dense product.
-        // A unit = one channel x 64 consecutive frames, lane = frame.  The unit's spikes (rows [f0 - H, f0 + 63] of the channel: two
-        // byte loads per lane from the TRANSPOSED int8 tile, two ballots) are walked on the scalar unit; per spike every lane reads
-        // nir[lane + H - j] from a zero-padded table (one LDS read at a per-lane base minus 8 j) and adds it -- two vector
-        // instructions per spike instead of 26 matrix instructions per wave, no int8 -> fp64 conversion while staging, one barrier less.
-        //   LDS: [ V fragments [tiles][256] ][ nir table, 126 + n ][ int8 tile [channel][RS] ]
-        const int H = n_nir - 1;  // frames of history a membrane value depends on (n <= 65: two ballot words cover 64 + H rows)
-        const int R = CH + H;
-        int RS4 = (R + 3) / 4 + 1;
-        RS4 |= 1;  // odd number of dwords per channel row: the 16 channels of a staged frame land in 16 different banks
-        const int RS = 4 * RS4;
-        double *Vl = reinterpret_cast<double *>(smem);
-        double *Pt = Vl + TILES * 256;
-        int8_t *Sb = reinterpret_cast<int8_t *>(Pt + 126 + n_nir);
-        constexpr int CPAD = (KM == 4 && KV == 0) ? 16 : 4 * KM + KV;  // channels stage 2 reads (rows >= C must be zero)
-        for (int e = tid; e < 126 + n_nir; e += BF_THREADS) Pt[e] = (e >= 63 && e < 63 + n_nir) ? ntab_g[e - 48] : 0.0;  // Pt[i] = nir[i - 63]
-        {
-            const int8_t *sb = spikes + (size_t)b * (chunk_range ? chunk_range[3] : T) * C;
-            const int tau0 = cs - H;
-            const int c = tid & 15;
-            constexpr int RP = BF_THREADS / 16;
-            const int rr = tid >> 4;
-            if (c < C) {
-                int8_t *d = Sb + c * RS;
-                if (tau0 >= 0 && tau0 + R <= T) {
-                    const int8_t *p = sb + (size_t)(tau0 + rr) * C + c;
-                    int rho = rr;
-                    for (; rho + 5 * RP < R; rho += 6 * RP) {
-                        int8_t v[6];
-#pragma unroll
-                        for (int i = 0; i < 6; ++i) v[i] = p[(size_t)i * RP * C];
-#pragma unroll
-                        for (int i = 0; i < 6; ++i) d[rho + i * RP] = v[i];
-                        p += (size_t)6 * RP * C;
-                    }
-                    for (; rho < R; rho += RP) {
-                        d[rho] = *p;
-                        p += (size_t)RP * C;
-                    }
-                } else {
-                    for (int rho = rr; rho < R; rho += RP) {
-                        const int tau = tau0 + rho;
-                        d[rho] = (tau >= 0 && tau < T) ? sb[(size_t)tau * C + c] : (int8_t)0;
-                    }
-                }
-            }
-        }
-        __syncthreads();
-        constexpr int NB = CH / 64;
-        static_assert(CH % 64 == 0, "a unit is 64 frames");
-        // MEASURED (profiles/r5/experiments/ws_lif_ablation.txt, same box, stage alone, us per launch): dense product 1004, this form 1004; with the
-        // LIF work removed (wrong results, timing only): dense without its matrix instructions 862, this form without the spike walk
-        // 885, without the whole stage 852.  The walk costs what the 26 matrix instructions per wave cost: it is ~650 instructions per
-        // wave, every vector one of them queues behind the 64-cycle matrix instructions of the co-resident workgroups' stage 2, and a
-        // workgroup's own stage 2 cannot start before its slowest wave is through -- fewer matrix-pipe cycles, but a longer stage.
-        // Hence a variant build (ws_sparse_lif), not the product.
-        // One wave issues one instruction of ANY kind per ~4.4 cycles, and the scalar instructions of the waves of a SIMD queue up
-        // behind each other: what a spike costs is its instruction count (the first form of this loop -- twelve scalar instructions per
-        // spike: 1025 us -- and a form that walked the seven units of a wave side by side -- 130 per round: 1240 us -- were slower
-        // still).  Per spike: find it (s_ff1), clear it (s_bitset0), its sign as the high word of +-1.0 (s_bitcmp1 + s_cselect), the
-        // table offset (s_lshl), the lanes' address (v_sub), the read, the fma; the read of spike k + 1 is issued before the fma of
-        // spike k waits for its own.
-        const char *pl = reinterpret_cast<const char *>(Pt) + 8 * (l + H + 63);  // this lane's nir[d = l + H - j] at j = 0
-        // ---- fourth form: NO scalar work per spike, vector work in batches --------------------------------------------------------------
-        // An isolated vector instruction on a SIMD whose other waves keep the matrix pipe full pays the MFMA -> VALU switch every time
-        // (the three forms above: two isolated instructions per spike).  Here the lanes that hold a spike byte COMPACT the unit's spikes
-        // into a wave-private LDS list (rank = mbcnt of the ballot: entry = table offset 8 j and the sign as a double), and the
-        // accumulation walks the lists of four units side by side, two entries per unit and round: eight broadcast reads of the
-        // entries, eight address subtractions, eight table reads, eight fmas (four independent chains, interleaved) -- straight-line
-        // batches, the trip count from the popcounts.  Lists are zero filled: a missing entry adds 0 * nir[.] == nothing.  A unit with
-        // more spikes than a list holds, or with bytes outside {-1, 0, +1}, is walked on the scalar unit afterwards (never on the
-        // encoder's rasters at robust widths >= 6).  MEASURED (tools/dev/bf_bench.py, BF_RASTER): 1006-1012 us on the encoder's raster
-        // against the dense product's 1001; on an all-zero raster (no rounds at all) 910 against 995 -- the stage's fixed part (transposed
-        // staging, masks, compaction) is 58 us above the 852 us of a launch without any LIF, the rounds another 100: the trip count of a
-        // group is its LONGEST list (11 for a mean of 8 spikes per unit), so 78 slots are processed for 47 spikes.  Still not below the
-        // dense product's 140 us.
-        constexpr int NU = (CPAD * NB + BF_WAVES - 1) / BF_WAVES;
-        constexpr int LCAP = WS_LIST_CAP;
-        double *ls = reinterpret_cast<double *>(Sb + 16 * RS) + (size_t)wv * NU * LCAP;                      // signs  [NU][LCAP]
-        int *lo = reinterpret_cast<int *>(reinterpret_cast<double *>(Sb + 16 * RS) + BF_WAVES * NU * LCAP) + wv * NU * LCAP;  // offsets
-        for (int e = l; e < NU * LCAP; e += 64) {
-            ls[e] = 0.0;
-            lo[e] = 0;
-        }
-        unsigned long long m0[NU], m1[NU], g0[NU], g1[NU];
-        int bb0[NU], bb1[NU], cnt[NU];
-        bool slow[NU];
-        {
-            int b0[NU], b1[NU];
-#pragma unroll
-            for (int i = 0; i < NU; ++i) {
-                const int u = wv + BF_WAVES * i;
-                const int c = u / NB, blk = u - c * NB;
-                const bool live = u < CPAD * NB && c < C && cs + 64 * blk < T;  // (wave-uniform)
-                const int8_t *row = Sb + (live ? c : 0) * RS + 64 * blk;
-                b0[i] = live ? row[l] : 0;
-                b1[i] = (live && l < H) ? row[64 + l] : 0;
-            }
-#pragma unroll
-            for (int i = 0; i < NU; ++i) {
-                m0[i] = __builtin_amdgcn_ballot_w64(b0[i] != 0);
-                m1[i] = __builtin_amdgcn_ballot_w64(b1[i] != 0);
-                g0[i] = __builtin_amdgcn_ballot_w64(b0[i] < 0);
-                g1[i] = __builtin_amdgcn_ballot_w64(b1[i] < 0);
-                const unsigned mx = (unsigned)(b0[i] + 1) > (unsigned)(b1[i] + 1) ? (unsigned)(b0[i] + 1) : (unsigned)(b1[i] + 1);
-                const bool tern = __builtin_amdgcn_ballot_w64(mx > 2u) == 0;
-                const int n0 = __builtin_popcountll(m0[i]);
-                cnt[i] = n0 + __builtin_popcountll(m1[i]);
-                slow[i] = !tern || cnt[i] > LCAP;
-                bb0[i] = b0[i];
-                bb1[i] = b1[i];
-                if (!slow[i]) {
-                    const unsigned r0 = __builtin_amdgcn_mbcnt_hi((unsigned)(m0[i] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m0[i], 0u));
-                    const unsigned r1 = n0 + __builtin_amdgcn_mbcnt_hi((unsigned)(m1[i] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m1[i], 0u));
-                    if (b0[i] != 0) {
-                        lo[i * LCAP + r0] = 8 * l;
-                        reinterpret_cast<unsigned *>(ls + i * LCAP + r0)[1] = b0[i] < 0 ? 0xbff00000u : 0x3ff00000u;
-                    }
-                    if (b1[i] != 0) {
-                        lo[i * LCAP + r1] = 8 * (64 + l);
-                        reinterpret_cast<unsigned *>(ls + i * LCAP + r1)[1] = b1[i] < 0 ? 0xbff00000u : 0x3ff00000u;
-                    }
-                }
-            }
-        }
-        double accu[NU];
-#pragma unroll
-        for (int i = 0; i < NU; ++i) accu[i] = 0.0;
-        constexpr int GU = 4, RB = 2;
-#pragma unroll
-        for (int gq = 0; gq < NU; gq += GU) {
-            constexpr int dummy = 0;
-            (void)dummy;
-            int nmax = 0;
-#pragma unroll
-            for (int k = 0; k < GU; ++k)
-                if (gq + k < NU) nmax = (!slow[gq + k] && cnt[gq + k] > nmax) ? cnt[gq + k] : nmax;
-            const int rounds = (nmax + RB - 1) / RB;
-            const double *lsg = ls + gq * LCAP;
-            const int *log_ = lo + gq * LCAP;
-            for (int r = 0; r < rounds; ++r) {
-                int off[GU][RB];
-                double sg[GU][RB], nv[GU][RB];
-#pragma unroll
-                for (int k = 0; k < GU; ++k)
-#pragma unroll
-                    for (int e = 0; e < RB; ++e)
-                        if (gq + k < NU) {
-                            off[k][e] = log_[k * LCAP + RB * r + e];
-                            sg[k][e] = lsg[k * LCAP + RB * r + e];
-                        }
-#pragma unroll
-                for (int k = 0; k < GU; ++k)
-#pragma unroll
-                    for (int e = 0; e < RB; ++e)
-                        if (gq + k < NU) nv[k][e] = *reinterpret_cast<const double *>(pl - off[k][e]);
-#pragma unroll
-                for (int e = 0; e < RB; ++e)
-#pragma unroll
-                    for (int k = 0; k < GU; ++k)
-                        if (gq + k < NU) accu[gq + k] = __builtin_fma(sg[k][e], nv[k][e], accu[gq + k]);
-            }
-        }
-        // the rare units the lists do not serve: the scalar walk (any int8 value, any number of spikes)
-#pragma unroll
-        for (int i = 0; i < NU; ++i) {
-            if (slow[i]) {  // (wave-uniform)
-                double acc = 0.0;
-                unsigned long long mm = m0[i];
-                while (mm) {
-                    const int j = __builtin_ctzll(mm);
-                    mm &= mm - 1;
-                    acc = __builtin_fma(*reinterpret_cast<const double *>(pl - 8 * j), (double)__builtin_amdgcn_readlane(bb0[i], j), acc);
-                }
-                mm = m1[i];
-                while (mm) {
-                    const int j = __builtin_ctzll(mm);
-                    mm &= mm - 1;
-                    acc = __builtin_fma(*reinterpret_cast<const double *>(pl - 8 * (64 + j)), (double)__builtin_amdgcn_readlane(bb1[i], j), acc);
-                }
-                accu[i] = acc;
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < NU; ++i) {
-            const int u = wv + BF_WAVES * i;
-            const int c = u / NB, blk = u - c * NB;
-            if (u < CPAD * NB && cs + 64 * blk < T)  // fragment order: [tile][channel][frame & 15]
-                Vl[(4 * blk + q) * 256 + c * 16 + lc] = (cs + 64 * blk + l < T) ? accu[i] : 0.0;
-        }
-        (void)g0;
-        (void)g1;
-        __syncthreads();
-    }
     // [ union{ spike tile as fp64 [R][16] , V fragments [32 tiles][4 k-steps][64 lanes] } ][ nir table ]
     // The spikes are converted to fp64 once, while they are staged (each row feeds ~3 time tiles of the Toeplitz
     // product): the LIF loop is then LDS reads + MFMAs only.  VALU instructions do not overlap MFMAs on a gfx950 SIMD
@@ -593,7 +390,6 @@ __global__ __launch_bounds__(BF_THREADS, WANT_Y ? 2 : (KV ? WS_KV_WAVES : (NT ==
     double *ntab = S + (R * 16 > TILES * 256 ? R * 16 : TILES * 256);
     const int ntab_len = 4 * NK + 16;
 
-    if constexpr (!SPARSE) {
     for (int e = tid; e < ntab_len; e += BF_THREADS) ntab[e] = ntab_g[e];
     {
         const int8_t *sb = spikes + (size_t)b * (chunk_range ? chunk_range[3] : T) * C;  // ([3]: frames per trial of a raster window)
@@ -694,7 +490,6 @@ __global__ __launch_bounds__(BF_THREADS, WANT_Y ? 2 : (KV ? WS_KV_WAVES : (NT ==
         }
     }
     __syncthreads();
-    }  // !SPARSE
 
     // ---- stage 2: this wave's DoA tiles against every time tile of the chunk --------------------------------
     int ntile = (T - cs + 15) >> 4;
@@ -742,19 +537,6 @@ static size_t ws_lds_bytes(const NeuronTab &nt, int NT, int Gy = 0)
     return ((tile > vfrag ? tile : vfrag) + (Gy ? ((tab + 1) & ~(size_t)1) + (size_t)16 * Gy : tab)) * sizeof(double);
 }
 
-// LDS of the event-driven LIF form: V fragments, the padded nir table, the transposed int8 tile (16 rows of RS bytes)
-[[maybe_unused]] static size_t ws_sparse_lds_bytes(const NeuronTab &nt, int NT)
-{
-    const int R = BF_WAVES * NT * 16 + nt.n - 1;
-    const int RS4 = ((R + 3) / 4 + 1) | 1;
-    const size_t lists = (size_t)BF_WAVES * 8 * WS_LIST_CAP * (sizeof(double) + sizeof(int));  // (at most 8 units per wave: 16 channels)
-    return (size_t)BF_WAVES * NT * 256 * sizeof(double) + (size_t)(126 + nt.n) * sizeof(double) + (size_t)16 * 4 * RS4 + lists;
-}
-
-// The event-driven LIF stage serves power-only launches whose neuron kernel spans at most 65 frames (two ballot words per unit),
-// unless the plan says the raster is dense (NeuronTab::sparse: robust width >= 4 -- a polarity keeps at most one frame in four).
-[[maybe_unused]] static bool ws_sparse(const NeuronTab &nt) { return VARIANT_WS_SPARSE_LIF && nt.sparse && nt.n >= 1 && nt.n <= 65; }
-
 template <int NGW, int NT, bool WANT_Y, int KM = 4, int KV = 0>
 static hipError_t launch_ws_n(const BeamformW &W, const NeuronTab &nt, const int8_t *spikes, int B, int T,
                               double *partial, double *y, hipStream_t stream)
@@ -777,23 +559,13 @@ static hipError_t launch_ws_n(const BeamformW &W, const NeuronTab &nt, const int
         }
     }
     dim3 grid((T + BF_WAVES * NT * 16 - 1) / (BF_WAVES * NT * 16), B), block(BF_THREADS);
-    if constexpr (VARIANT_WS_SPARSE_LIF && !WANT_Y && NT == 2) {  // (the event-driven instantiations exist in the variant build only)
-        if (ws_sparse(nt)) {
-            const size_t lds = ws_sparse_lds_bytes(nt, NT);
-            auto k = &beamform_ws_kernel<NGW, NT, false, KM, KV, true>;
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(k, grid, block, lds, stream, spikes, nt.tab, nt.NK, W.Wp, W.GT, W.C, T, partial, W.G, y, W.chunk_range, nt.n);
-            return hipGetLastError();
-        }
-    }
     const size_t lds = ws_lds_bytes(nt, NT, WANT_Y ? W.G : 0);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     auto k = &beamform_ws_kernel<NGW, NT, WANT_Y, KM, KV>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        160 * 1024);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k, grid, block, lds, stream, spikes, nt.tab, nt.NK, W.Wp, W.GT, W.C, T, partial, W.G, y, W.chunk_range, nt.n);
+    hipLaunchKernelGGL(k, grid, block, lds, stream, spikes, nt.tab, nt.NK, W.Wp, W.GT, W.C, T, partial, W.G, y, W.chunk_range);
     return hipGetLastError();
 }
 

@@ -15,7 +15,6 @@ namespace micloc {
 constexpr bool VARIANT_WS_FOUR_KSTEPS = false;    // ws_k4: beamform_ws_kernel multiplies four k-steps whatever the channel count
 constexpr bool VARIANT_STHT_VECTOR_FORM = false;  // stht_valu: stride-2 STHT kernels on the vector ALU instead of the matrix cores
 constexpr bool VARIANT_STHT_ONE_TILE = false;     // stht_one_tile: the matrix-core STHT with one time tile per workgroup (round 3's form) instead of the walk
-constexpr bool VARIANT_WS_SPARSE_LIF = false;     // ws_sparse_lif: beamform_ws_kernel's LIF stage event by event on the vector ALU (round 5 experiment) instead of the dense Toeplitz product
 
 // ---- XCD-aware workgroup order (speed only, never correctness) -------------------------------------------------------
 // Workgroup L of a launch runs on XCD L % 8, and every XCD has its own L2.  Kernels whose NEIGHBOURING work items read the same
@@ -113,7 +112,6 @@ struct NeuronTab {
     const double *tab;  // device: zero padded Toeplitz lookup, see beamform.hip
     int n;              // taps
     int NK;             // k-steps of 4 past samples: 4 * NK >= n + 15
-    int sparse;         // the plan's rasters are sparse (robust width >= 4): beamform_ws_kernel may walk the spikes instead of the frames
 };
 
 // partial sums: [B][nchunks][Gp] doubles

@@ -73,6 +73,9 @@ struct Iir {
     // z = +-1, b = g [1, 0, -2, 0, 1]): fma(0, x, z) is z for every finite x -- as a number; only a zero's sign can differ (+-0 + -0)
     // and no comparison, sum or spike ever sees it -- so the term is skipped: 9 instead of 11 operations per step at order 4.  The
     // serial checkpoint scan of long recordings is bound by exactly this count (one wave issues one instruction per ~4.4 cycles).
+    // FINITE INPUT ONLY (include/micloc_hip.h, "PRECONDITION"): for x = +-Inf the skipped product is NaN and the encode kernels, which
+    // use step(), would diverge from the scan's checkpoints; tests/test_hip_chunked.py::test_chunked_signed_zeros_and_subnormals pins
+    // the cases that ARE in the contract (states and samples that are -0, subnormal, exactly cancelling).
     template <unsigned ZMASK>
     __device__ __forceinline__ double step_zb(const IirCoef &coef, double xin)
     {
@@ -546,31 +549,38 @@ __global__ __launch_bounds__(192) void rzcc_scan_kernel(const double *__restrict
     // LDS -> registers, hand-issued: the reads of tile k are in flight while tile k - 1 is computed, and the one wait sits
     // at the end of the iteration (the compiler's own placement waited right behind the reads, once per tile)
     const unsigned lds_lane = (unsigned)(size_t)(&X[0][0][lane]);
-    auto fetch = [&](int kk, double (&x)[RZ_MT]) {
+    // The destination of an asynchronous LDS read is only valid behind the s_waitcnt, and the compiler does not know that the asm is
+    // asynchronous: the very objects the reads write (eight 16-byte register pairs per tile) are the ones `landed` ties to the wait
+    // with "+v", and scalars are taken out of them only behind it -- no copy of a destination can be scheduled in front of the wait
+    // (the first form extracted x[j] = v0[0] right behind the read, and the compiler materialised those copies ahead of
+    // the wait; tests/test_isa_hazards_cpu.py checks the emitted ISA for that pattern).
+    typedef double dbl2 __attribute__((ext_vector_type(2)));
+    constexpr int RZ_MT2 = RZ_MT / 2;
+    auto fetch = [&](int kk, dbl2 (&x2)[RZ_MT2]) {
         const int buf = (kk < m_end ? kk : 0) % 3;  // (past the end: any buffer, the values are not used)
         const unsigned addr = lds_lane + (unsigned)buf * (RZ_MT * RZ_ROW * 8);
         // two steps per LDS instruction (a lone wave issues ONE instruction of any kind per ~4.4 cycles: every read saved is a tenth of
         // a step's arithmetic).  ds_read2_b64 offsets are 8-bit counts of 8 bytes: one base address per four rows of the tile.
         static_assert(RZ_MT % 4 == 0 && 3 * RZ_ROW < 256, "ds_read2_b64 offsets");
-        typedef double dbl2 __attribute__((ext_vector_type(2)));
 #pragma unroll
         for (int j = 0; j < RZ_MT; j += 4) {
             const unsigned a4 = addr + (unsigned)(j * RZ_ROW * 8);
-            dbl2 v0, v1;
-            asm volatile("ds_read2_b64 %0, %1 offset0:%2 offset1:%3" : "=v"(v0) : "v"(a4), "n"(0), "n"(RZ_ROW));
-            asm volatile("ds_read2_b64 %0, %1 offset0:%2 offset1:%3" : "=v"(v1) : "v"(a4), "n"(2 * RZ_ROW), "n"(3 * RZ_ROW));
-            x[j] = v0[0];
-            x[j + 1] = v0[1];
-            x[j + 2] = v1[0];
-            x[j + 3] = v1[1];
+            asm volatile("ds_read2_b64 %0, %1 offset0:%2 offset1:%3" : "=v"(x2[j / 2]) : "v"(a4), "n"(0), "n"(RZ_ROW));
+            asm volatile("ds_read2_b64 %0, %1 offset0:%2 offset1:%3" : "=v"(x2[j / 2 + 1]) : "v"(a4), "n"(2 * RZ_ROW), "n"(3 * RZ_ROW));
         }
     };
-    auto landed = [&](double (&x)[RZ_MT]) {
+    static_assert(RZ_MT2 == 8, "landed() names eight register pairs");
+    auto landed = [&](dbl2 (&x2)[RZ_MT2]) {
         asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]), "+v"(x[8]),
-                       "+v"(x[9]), "+v"(x[10]), "+v"(x[11]), "+v"(x[12]), "+v"(x[13]), "+v"(x[14]), "+v"(x[15]));
+                     : "+v"(x2[0]), "+v"(x2[1]), "+v"(x2[2]), "+v"(x2[3]), "+v"(x2[4]), "+v"(x2[5]), "+v"(x2[6]), "+v"(x2[7]));
     };
-    double xa[RZ_MT], xb[RZ_MT];
+    auto run = [&](int kk, const dbl2 (&x2)[RZ_MT2]) {  // (x2 has passed through landed(): plain values from here on)
+        double x[RZ_MT];
+#pragma unroll
+        for (int j = 0; j < RZ_MT; ++j) x[j] = x2[j >> 1][j & 1];
+        tile(kk, x);
+    };
+    dbl2 xa[RZ_MT2], xb[RZ_MT2];
     pin_coef<N>(coef);
     __syncthreads();
     // iteration k: LDS -> registers for tile k (written before the last barrier), arithmetic on tile k - 1
@@ -580,16 +590,16 @@ __global__ __launch_bounds__(192) void rzcc_scan_kernel(const double *__restrict
     int k = 1;
     for (; k + 1 < nstep; k += 2) {
         fetch(k, xb);
-        tile(k - 1, xa);
+        run(k - 1, xa);
         landed(xb);
         __syncthreads();
         fetch(k + 1, xa);
-        tile(k, xb);
+        run(k, xb);
         landed(xa);
         __syncthreads();
     }
     if (k < nstep) {
-        tile(k - 1, xa);
+        run(k - 1, xa);
         __syncthreads();
     }
 }

@@ -21,6 +21,12 @@
  *     device is (the previous current device is restored before the call returns).
  *   - All arithmetic is IEEE binary64 unless a name says otherwise (float32 before the
  *     encoder flips spikes).
+ *   - PRECONDITION: recordings are FINITE (no Inf / NaN samples).  The bit-exactness contract (time chunking,
+ *     streaming and the one-shot call give the same spikes) rests on it: the checkpoint scan of a chunked encoder
+ *     skips the products with a band-pass numerator coefficient that is exactly zero (fma(0, x, z) == z for finite
+ *     x, up to the sign of a zero that no comparison, sum or spike sees), which the one-pass encoder multiplies --
+ *     0 * Inf would be NaN there.  The reference's own chain is NaN-poisoned from the first non-finite sample on
+ *     (lfilter -> cumsum -> find_peaks), so there is no result to reproduce; signed zeros and subnormals are fine.
  *
  * Device layouts
  *   x        [B][T][M]      row-major: trial b is the reference's `sig_in_vec` (T x num_mic).

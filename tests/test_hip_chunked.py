@@ -133,6 +133,40 @@ def test_long_clusters_across_chunks(torch):
             np.testing.assert_array_equal(got, want, err_msg=f"w={w} bip={bip} chunk={chunk}")
 
 
+def test_chunked_signed_zeros_and_subnormals(cfg2, torch):
+    """The finite-input contract of include/micloc_hip.h at its edges: the checkpoint scan skips the products with an
+    exactly-zero numerator coefficient (`Iir::step_zb`), the encode kernels multiply them -- equal as numbers for finite samples, only
+    the sign of a zero may differ, which nothing downstream sees.  Recordings that drive the filter state through -0, subnormals and
+    exact cancellation (digital silence long enough for the DF2T state to underflow, -0.0 samples, subnormal samples, +a / -a pairs):
+    chunked == un-chunked == oracle, bit for bit, for several chunk lengths."""
+    rng = np.random.RandomState(77)
+    B, T, M = 3, 30000, 7
+    t = np.arange(T)
+    x = np.zeros((B, T, M))
+    x[:, :1500] = np.sin(2 * np.pi * 1500 * t[:1500] / 48000)[None, :, None] + 0.3 * rng.randn(B, 1500, M)
+    x[0, 1500:26000] = -0.0                                  # the state decays through the subnormals to a signed zero
+    x[1, 1500:26000] = 0.0
+    x[1, 9000:9100] = 5e-324 * rng.randint(-3, 4, size=(100, M))   # subnormal samples
+    x[2, 1500:26000] = 1e-310 * rng.randn(24500, M)
+    x[2, 12000:12400:2] = 0.75                               # exact +a / -a pairs
+    x[2, 12001:12401:2] = -0.75
+    x[:, 26000:] = rng.randn(B, T - 26000, M) * np.where(rng.rand(B, T - 26000, M) < 0.2, 0.0, 1.0) * np.where(rng.rand(B, T - 26000, M) < 0.1, -0.0, 1.0)
+    assert np.isfinite(x).all() and np.signbit(x[0, 2000, 0])
+    p = _plan(cfg2)
+    xd = p.to_device(x)
+    p.set_encoder_chunk(-1)
+    ref = p.snn_pipeline(xd, want_spikes=True, want_power=False)["spikes"].cpu().numpy()
+    for b in range(B):
+        want = O.snn_chain(x[b], cfg2["kernel"], cfg2["b"], cfg2["a"], cfg2["robust_width"], True, cfg2["nir"], cfg2["bf_mat"], want=("spikes",))
+        np.testing.assert_array_equal(ref[b], want["spikes"], err_msg=f"un-chunked trial {b}")
+    assert np.abs(ref[:, 26000:]).sum() > 1000
+    for chunk in (64, 1008, 4096, 13000):
+        p.set_encoder_chunk(chunk)
+        assert p.encoder_chunks(B, T) > 1
+        got = p.snn_pipeline(xd, want_spikes=True, want_power=False)["spikes"].cpu().numpy()
+        np.testing.assert_array_equal(got, ref, err_msg=f"chunk={chunk}")
+
+
 def test_automatic_choice(cfg2, torch):
     """Launches that fill the chip stay one exact pass; few long streams are chunked (BASELINE config 3 shape)."""
     p = _plan(cfg2)
