@@ -72,8 +72,15 @@ def parse(argv=None):
     ap.add_argument("--traffic-bytes", type=float, default=None, help="override roofline.traffic (HBM bytes per dominant-kernel launch)")
     ap.add_argument("--sustained-seconds", type=float, default=5.0, help="length of the `sustained` region (one long run of headline steps with the "
                     "shader clock / socket power sampled in-process); 0 disables it")
+    ap.add_argument("--other-sustained-seconds", type=float, default=10.0, help="length of the sustained region of each `other_configs` child run "
+                    "(speech / xylo / stress: their steady-state ms per step with clock and power telemetry); 0 disables it")
     ap.add_argument("--no-live-traffic", action="store_true", help="do not measure roofline.traffic in a rocprofv3 child of this run; read the "
                     "committed profile instead (only if its MANIFEST says it was taken on the current csrc/beamform.hip)")
+    ap.add_argument("--share-device", action="store_true", help="REHEARSAL of the N > 1 launch on a box with ONE GPU: all --gpus ranks use device 0, the "
+                    "process group is gloo (RCCL refuses two ranks on one device) and every collective is staged through host memory; everything "
+                    "else -- the rank launcher, per-rank batches and trial numbering, barriers, per-rank clocks, MAX reduce, the exchange step, the "
+                    "MAE from the gathered trials -- is the code of the real launch.  The ranks time-slice one GPU: `value` is NOT a scaling figure")
+    ap.add_argument("--as-rank", type=int, default=None, help=argparse.SUPPRESS)  # test hook: build rank R's workload in a single process (no group)
     ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)  # the program rocprofv3 runs for the live PMC passes
     ap.add_argument("--pmc-summary", default=None, help="committed rocprofv3 PMC summary to read roofline.traffic from (default: newest profiles/r*/pmc_summary.csv)")
     # test hook (tests/test_bench_launch_cpu.py): exercise the rank launcher and the collective code on CPU with gloo
@@ -112,6 +119,8 @@ def launch_ranks(args, argv):
     n = args.gpus
     if not args.cpu_stub:
         have = visible_gpus()
+        if args.share_device and have >= 1:
+            have = n  # rehearsal: every rank on device 0
         if have < n:
             print(f"bench.py: --gpus {n} requested but only {have} HIP device(s) visible", file=sys.stderr)
             return 2
@@ -406,11 +415,57 @@ def usable_cores():
     return max(1, n)
 
 
-def cpu_baseline(wl, budget_s):
+# ---- the reference-style NumPy chain trial-parallel over the host cores (SURVEY 8d ii) -----------------------------------------
+# Worker PROCESSES (one BLAS / OpenMP thread each), started by `numpy_pool()` BEFORE this process touches the GPU -- a pool forked or
+# spawned from a GPU-initialised process would be the exec the pool forbids -- and idle (blocked on a pipe) until cpu_baseline feeds them.
+_NP_ORACLE = None
+
+
+def _np_worker_init():
+    global _NP_ORACLE
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    try:
+        from threadpoolctl import threadpool_limits
+
+        threadpool_limits(1)
+    except Exception:
+        pass
+    import scipy.signal  # noqa: F401  (snn_chain_numpy imports it on its first call: paid here, not inside the timed leg)
+    from oracle import oracle as O
+
+    _NP_ORACLE = O
+
+
+def _np_worker(task):
+    xs, chain_args = task
+    return [int(_NP_ORACLE.snn_chain_numpy(x, *chain_args)["argmax"]) for x in xs]
+
+
+def numpy_pool(workers):
+    import multiprocessing as mp
+
+    saved = {k: os.environ.get(k) for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS")}
+    os.environ.update({k: "1" for k in saved})  # inherited by the workers only: restored below for this process
+    try:
+        pool = mp.get_context("spawn").Pool(workers, initializer=_np_worker_init)
+        pool.map(_np_worker, [([], ())] * workers)  # every worker is up and has imported NumPy / SciPy / the oracle
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    return pool
+
+
+def cpu_baseline(wl, budget_s, pool=None, pool_workers=0):
     """The CPU restatement of the same hot path on the first trials of the SAME batch, three ways:
       value            the C oracle, trial-parallel over all host cores (one thread per core)
       single_thread    the C oracle on one core
       numpy_ops        the reference's own op sequence (NumPy / SciPy calls, BLAS threads at their default), one process
+      numpy_ops_all_cores   the same op sequence trial-parallel over `pool_workers` worker processes, one BLAS thread each -- north_star's
+                            "reference NumPy CPU path timed on the same box's host cores" (the pool was started before any GPU call)
     Each leg is sized for about `budget_s` seconds from a short calibration run."""
     from oracle import oracle as O
 
@@ -458,14 +513,34 @@ def cpu_baseline(wl, budget_s):
     dtn = time.perf_counter() - t0
     del r0
 
+    np_all = None
+    am_pool = None
+    if pool is not None:
+        # tasks of 2 trials each; sized from the one-process rate (processes rarely scale linearly: the leg reports what it measured)
+        n_all = sized(pool_workers / (dtn / nn), B)
+        n_all = max(2 * pool_workers, n_all - n_all % 2) if B >= 2 * pool_workers else B
+        tasks = [(xa[i : i + 2], args) for i in range(0, n_all, 2)]
+        t0 = time.perf_counter()
+        parts = pool.map(_np_worker, tasks, chunksize=1)
+        dtp = time.perf_counter() - t0
+        am_pool = np.asarray([v for p_ in parts for v in p_])
+        np_all = dict(value=len(am_pool) * T / dtp, unit="frames/s", cores=pool_workers,
+                      sample=f"first {len(am_pool)} trials, {dtp:.1f} s, oracle.snn_chain_numpy (the reference's NumPy/SciPy op sequence) in {pool_workers} "
+                             f"worker processes, one BLAS thread each, trials handed out two at a time; speed-up over one process "
+                             f"{(len(am_pool) / dtp) / (nn / dtn):.1f}x")
+
     shape = f"T={T}, M={M}, G={G}"
-    return dict(value=reps * B * T / dta, unit="frames/s", cores=cores, kind="port", cpu_model=cpu_model(), host_cpus=host_cpus,
+    legs = dict(all=am_all, one=am1, numpy=np.asarray(am_np))
+    if am_pool is not None:
+        legs["numpy_all"] = am_pool
+    extra = dict(numpy_ops_all_cores=np_all) if np_all else {}
+    return dict(**extra, value=reps * B * T / dta, unit="frames/s", cores=cores, kind="port", cpu_model=cpu_model(), host_cpus=host_cpus,
                 sample=f"{reps} x all {B} trials of the same batch ({shape}), {dta:.1f} s, oracle/micloc_oracle.c, trials split over {cores} threads",
                 single_thread=dict(value=n1 * T / dt1, unit="frames/s", cores=1,
                                    sample=f"first {n1} trials, {dt1:.1f} s, oracle/micloc_oracle.c, one thread"),
                 numpy_ops=dict(value=nn * T / dtn, unit="frames/s", cores="BLAS default",
                                sample=f"first {nn} trials, {dtn:.1f} s, oracle.snn_chain_numpy: the reference's NumPy/SciPy op sequence, one process"),
-                ), dict(all=am_all, one=am1, numpy=np.asarray(am_np))
+                ), legs
 
 
 def traffic_from_profiles(symbol, grid_size, path=None):
@@ -611,6 +686,31 @@ def sustained_block(step, pipe, args, ms_region, frames_per_step, device_index):
     return out
 
 
+def memory_gb(device):
+    """Device memory of this rank at the end of the run (what a rank's share of a sweep needs): torch's peak reserved / allocated bytes
+    (workspaces, batches, graph outputs are all torch allocations) and what the driver reports free of the device's total."""
+    import torch
+
+    free, total = torch.cuda.mem_get_info(device)
+    return {"peak_reserved": torch.cuda.max_memory_reserved(device) / 1e9, "peak_allocated": torch.cuda.max_memory_allocated(device) / 1e9,
+            "free_at_end": free / 1e9, "device_total": total / 1e9}
+
+
+def sustained_over_ranks(sustained, grp, device, frames_per_step, ms_region):
+    """Like the timed regions: the job's figure is the SLOWEST rank's (every rank ran the same number of steps)."""
+    import torch
+
+    if grp.on:
+        ts = torch.tensor([sustained["seconds"]], dtype=torch.float64, device=device)
+        grp.max_(ts)
+        sustained["seconds_this_rank"] = sustained["seconds"]
+        sustained["seconds"] = float(ts.item())
+        sustained["ms_per_step"] = sustained["seconds"] / sustained["steps"] * 1e3
+        sustained["value"] = frames_per_step / (sustained["ms_per_step"] * 1e-3)
+        sustained["ratio_to_timed_regions"] = sustained["ms_per_step"] / ms_region
+    return sustained
+
+
 def manifest_entry(relpath):
     """profiles/rNN/MANIFEST.json entry of a committed profile file (tools/make_manifest.py writes them): git SHA, box, command and the
     SHA-256 of the kernel sources the numbers belong to."""
@@ -724,6 +824,77 @@ def live_traffic(symbol, B, T, M, G, fs, timeout=240):
     detail.update(fetch_kib=vals["FETCH_SIZE"], write_kib=vals["WRITE_SIZE"],
                   formula="(2 x FETCH_SIZE + WRITE_SIZE) KiB per launch, FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md")
     return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, detail
+
+
+class Group:
+    """The process group of a run: RCCL (backend "nccl") with one rank per GPU; with --share-device gloo, every collective staged
+    through host memory (two ranks cannot share a device under RCCL).  The same calls either way, so the N > 1 code of `run` is one
+    code path.  world == 1 without MICLOC_FORCE_DIST: no group, every call is the identity."""
+
+    def __init__(self, rank, world, device, share_device=False, force=False):
+        import torch.distributed as dist
+
+        self.dist, self.rank, self.world, self.device = dist, rank, world, device
+        self.on = world > 1 or force
+        self.staged = bool(share_device)
+        self.size = 1
+        self.backend = None
+        if self.on:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29531")
+            if self.staged:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            else:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+            self.size = dist.get_world_size()
+            self.backend = "gloo (host-staged, --share-device rehearsal)" if self.staged else "nccl (RCCL)"
+
+    def barrier(self):
+        if self.on:
+            self.dist.barrier()
+
+    def gather(self, t):
+        """Every rank's `t` (same shape and dtype everywhere), as a list on t's device."""
+        if not self.on:
+            return [t]
+        src = t.cpu() if self.staged else t
+        every = [src.new_empty(src.shape) for _ in range(self.world)]
+        self.dist.all_gather(every, src.contiguous())
+        return [e.to(t.device) for e in every]
+
+    def gather_flat(self, t):
+        """ONE collective: the ranks' equal-sized 1-d records concatenated in rank order (all_gather_into_tensor under RCCL)."""
+        import torch
+
+        if not self.on:
+            return t.clone()
+        if self.staged:
+            return torch.cat(self.gather(t))
+        full = t.new_empty(t.numel() * self.world)
+        self.dist.all_gather_into_tensor(full, t)
+        return full
+
+    def max_(self, t):
+        if self.on:
+            if self.staged:
+                h = t.cpu()
+                self.dist.all_reduce(h, op=self.dist.ReduceOp.MAX)
+                t.copy_(h)
+            else:
+                self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return t
+
+    def gather_object(self, o):
+        if not self.on:
+            return [o]
+        every = [None] * self.world
+        self.dist.all_gather_object(every, o)
+        return every
+
+    def close(self):
+        if self.on:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -982,7 +1153,8 @@ def other_configs_block(args):
     #  finish together, which is not the steady state -- xylo 18.0 ms/step at 3 steps, 17.0 at 12)
     for cfg, steps in (("speech", 16), ("xylo", 12), ("stress", 9)):
         cmd = [sys.executable, os.path.abspath(__file__), "--config", cfg, "--steps", str(steps), "--warmup", "4" if cfg == "speech" else "3", "--repeats", "3",
-               "--no-cpu-baseline", "--no-other-configs", "--sustained-seconds", "0"] + (["--streams", str(args.streams)] if args.streams_given else [])
+               "--no-cpu-baseline", "--no-other-configs", "--sustained-seconds", str(args.other_sustained_seconds)] + \
+              (["--streams", str(args.streams)] if args.streams_given else [])
         t0 = time.perf_counter()
         try:
             p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
@@ -993,6 +1165,13 @@ def other_configs_block(args):
                         "schedule": d["config"].get("schedule"),
                         "roofline": {k: r.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_ms")},
                         "stages_ms": r.get("stages_ms"), "steps": d["steps"], "wall_s": time.perf_counter() - t0}
+            sus = d.get("sustained")
+            if sus:
+                # the steady state of the workload: ONE uninterrupted region (no fill / drain per K steps) with the chip's own telemetry
+                out[cfg]["sustained"] = {k: sus.get(k) for k in ("seconds", "steps", "ms_per_step", "value", "unit", "ms_per_step_first_second",
+                                                                 "ms_per_step_last_second", "ratio_to_timed_regions", "telemetry_source")}
+                out[cfg]["sustained"]["telemetry"] = (sus.get("telemetry") or {}).get("whole")
+                out[cfg]["sustained"]["ms_per_step_segments_min_max"] = [min(sus["ms_per_step_segments"]), max(sus["ms_per_step_segments"])]
             if "parity" in d:
                 out[cfg]["parity"] = "unpinned"
                 out[cfg]["parity_note"] = d["parity"]
@@ -1016,15 +1195,12 @@ def run_xylo(args, rank, local_rank, world):
     from haghighatshoarmuir2024_amd.array_geometry import CenterCircularArray
     from haghighatshoarmuir2024_amd.xylo_snn_localization import Demo
 
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    use_dist = world > 1
-    group_size = 1
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-        group_size = dist.get_world_size()
+    dev_index = 0 if args.share_device else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    grp = Group(rank, world, device, share_device=args.share_device)
+    use_dist = grp.on
+    group_size = grp.size
     fs, M = 48_000, 7
     G = args.grid or 360
     B = args.trials or 1100
@@ -1074,8 +1250,7 @@ def run_xylo(args, rank, local_rank, world):
 
     def barrier():
         pipe.synchronize()
-        if use_dist:
-            dist.barrier()
+        grp.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -1089,20 +1264,18 @@ def run_xylo(args, rank, local_rank, world):
             counts, idx, mae = replay()
         barrier()
         dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
-        if use_dist:
-            every = [torch.empty_like(dt) for _ in range(world)]
-            dist.all_gather(every, dt)
-            per_rank.append([float(v.item()) for v in every])
-            dist.all_reduce(dt, op=dist.ReduceOp.MAX)
-        else:
-            per_rank.append([float(dt.item())])
+        per_rank.append([float(v.item()) for v in grp.gather(dt)])
+        grp.max_(dt)
         dt_all.append(float(dt.item()))
-    if use_dist:
-        gathered = [torch.empty_like(mae) for _ in range(world)]
-        dist.all_gather(gathered, mae)
-        mae = torch.stack(gathered).mean(dim=0)
+    mae = torch.stack(grp.gather(mae)).mean(dim=0)
     dt = float(np.median(dt_all))
     frames = group_size * B * T * args.steps
+    sustained = None
+    if args.sustained_seconds > 0:
+        barrier()
+        sustained = sustained_block(lambda: replay(), pipe, args, dt / args.steps * 1e3, group_size * B * T, dev_index)
+        sustained = sustained_over_ranks(sustained, grp, device, group_size * B * T, dt / args.steps * 1e3)
+        barrier()
     result = None
     if rank == 0:
         def timed(fn, iters=5):
@@ -1153,7 +1326,7 @@ def run_xylo(args, rank, local_rank, world):
         result = {
             "metric": "audio samples/sec through STHT+RZCC+SNN beamform, 7-mic 48kHz 360-DoA; DoA MAE vs ref",
             "value": value, "unit": "frames/s (one frame = one audio sample instant across all mics)",
-            "n_gpus": group_size, "rccl_ranks": group_size if use_dist else 0, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": group_size, "rccl_ranks": group_size if (use_dist and not grp.staged) else 0, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "ms_per_step_repeats": [t / args.steps * 1e3 for t in dt_all],
             "ms_per_step_per_rank": (np.median(np.asarray(per_rank), axis=0) / args.steps * 1e3).tolist(),
             "cpu_cores_per_rank": args.cpu_cores or usable_cores(),
@@ -1168,9 +1341,12 @@ def run_xylo(args, rank, local_rank, world):
             "mae_deg_per_snr": [float(v) for v in (mae * 180 / np.pi).cpu().numpy()],
             "roofline": roof,
         }
-    if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
+        if sustained is not None:
+            result["sustained"] = sustained
+            result["config"]["sustained_ms_per_step"] = sustained["ms_per_step"]
+        if grp.backend:
+            result["backend"] = grp.backend
+    grp.close()
     if rank == 0:
         sys.stdout.flush()
         print(json.dumps(result), flush=True)
@@ -1185,29 +1361,35 @@ def run(args):
         return run_stub(args, rank, world)
     if args.traffic_child:
         return run_traffic_child(args)
+    np_pool, np_workers = None, 0
+    if args.config == "noisy" and world == 1 and rank == 0 and not args.no_cpu_baseline and os.environ.get("MICLOC_FORCE_DIST") != "1":
+        # the NumPy leg's worker processes: started while this process is still GPU-free (nothing above touched HIP)
+        try:
+            np_workers = usable_cores()
+            np_pool = numpy_pool(np_workers)
+        except Exception as e:
+            print(f"bench.py: numpy_ops_all_cores leg unavailable ({type(e).__name__}: {e})", file=sys.stderr)
+            np_pool, np_workers = None, 0
     import torch
     import torch.distributed as dist
 
     if world != args.gpus and world > 1:
         args.gpus = world
     args.world = world
-    if local_rank >= torch.cuda.device_count():
+    dev_index = 0 if args.share_device else local_rank
+    if dev_index >= torch.cuda.device_count():
         print(f"bench.py: rank {rank} has no device (LOCAL_RANK {local_rank}, {torch.cuda.device_count()} visible)", file=sys.stderr)
         return 2
     if args.config == "xylo":
         return run_xylo(args, rank, local_rank, world)
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     # MICLOC_FORCE_DIST=1 runs the collective code path with a 1-rank RCCL group (to exercise it on a 1-GPU box)
-    use_dist = world > 1 or os.environ.get("MICLOC_FORCE_DIST") == "1"
-    group_size = 1
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-        group_size = dist.get_world_size()
+    grp = Group(rank, world, device, share_device=args.share_device, force=os.environ.get("MICLOC_FORCE_DIST") == "1")
+    use_dist = grp.on
+    group_size = grp.size
 
-    wl = build_workload(args, rank, device)
+    wl = build_workload(args, rank if args.as_rank is None else args.as_rank, device)
     noisy = args.config == "noisy"
     # consecutive steps are independent batches: on every workload the serial scan / encoder of one step (few, long
     # latency-bound workgroups) overlaps the throughput-bound STHT and beamforming kernels of its neighbours
@@ -1238,8 +1420,7 @@ def run(args):
 
     def barrier():
         pipe.synchronize()
-        if use_dist:
-            dist.barrier()
+        grp.barrier()
         torch.cuda.synchronize()
 
     per_rank = []  # one list per timed region (headline regions first)
@@ -1258,13 +1439,8 @@ def run(args):
                 res = fn()
             barrier()
             t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
-            if use_dist:
-                every = [torch.empty_like(t) for _ in range(world)]
-                dist.all_gather(every, t)  # every rank's own clock: a straggler shows up by name, not only in the MAX
-                per_rank.append([float(v.item()) for v in every])
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            else:
-                per_rank.append([float(t.item())])
+            per_rank.append([float(v.item()) for v in grp.gather(t)])  # every rank's own clock: a straggler shows up by name, not only in the MAX
+            grp.max_(t)
             times.append(float(t.item()))
         return float(np.median(times)), times, res
 
@@ -1281,7 +1457,6 @@ def run(args):
         mae0 = (mae0 * 180 / np.pi).cpu().numpy()
         doa0 = wl["doa"]
         rec = torch.empty(3 * B, dtype=torch.float64, device=device)
-        full = torch.empty(3 * B * world, dtype=torch.float64, device=device)
         ex_ms = []
         for _ in range(5):
             barrier()
@@ -1289,8 +1464,7 @@ def run(args):
             rec[:B] = doa0
             rec[B : 2 * B] = out0["power"].gather(1, out0["argmax"].long().view(-1, 1)).view(-1)
             rec[2 * B :].view(torch.int32)[:B] = out0["argmax"]
-            dist.all_gather_into_tensor(full, rec)
-            host = full.cpu()
+            host = grp.gather_flat(rec).cpu()  # RCCL: one all_gather_into_tensor + one D2H; rehearsal: D2H, gloo all_gather, concatenate
             ex_ms.append((time.perf_counter() - t0) * 1e3)
         host = host.view(world, 3, B)
         g_doa = host[:, 0, :].numpy()
@@ -1302,30 +1476,21 @@ def run(args):
                     "bytes_per_rank": int(rec.numel() * 8), "record": "{doa f64, p_max f64, argmax i32} x trials, struct of arrays",
                     "mae_deg_per_snr_from_gathered_trials": [float(v) for v in mae_gathered],
                     "mae_deg_per_snr_device_same_batch": [float(v) for v in mae0],  # rank 0's own batch by micloc_doa_error_f64
+                    "transport": grp.backend,
                     "note": "pack on the device + one all_gather_into_tensor + one D2H, between two barriers; not inside the timed steps "
                             "(a sweep exchanges once, at its end)"}
-        every_uuid = [None] * world
-        dist.all_gather_object(every_uuid, uuids[0])
-        uuids = [str(u) for u in every_uuid]
-        gathered = [torch.empty_like(mae) for _ in range(world)]
-        dist.all_gather(gathered, mae)
-        mae = torch.stack(gathered).mean(dim=0)
+        uuids = [str(u) for u in grp.gather_object(uuids[0])]
+        mae = torch.stack(grp.gather(mae)).mean(dim=0)
     frames = group_size * B * T * args.steps
     value = frames / dt
     sustained = None
-    if args.sustained_seconds > 0 and not scan_lane:
-        # every rank runs it (the same load on every GPU of the node); rank 0 reports its own
+    if args.sustained_seconds > 0:
+        # every rank runs it (the same load on every GPU of the node); rank 0 reports its own.  Under the scan-lane schedule (long
+        # recordings) the region is the same eager launches the timed regions make: what it adds is the steady state -- a K-step
+        # region of a four-deep pipeline with an 8 ms serial scan in front is mostly fill and drain
         barrier()
-        sustained = sustained_block(step, pipe, args, dt / args.steps * 1e3, group_size * B * T, local_rank)
-        if use_dist:
-            # like the timed regions: the job's figure is the SLOWEST rank's (every rank ran the same number of steps)
-            ts = torch.tensor([sustained["seconds"]], dtype=torch.float64, device=device)
-            dist.all_reduce(ts, op=dist.ReduceOp.MAX)
-            sustained["seconds_this_rank"] = sustained["seconds"]
-            sustained["seconds"] = float(ts.item())
-            sustained["ms_per_step"] = sustained["seconds"] / sustained["steps"] * 1e3
-            sustained["value"] = group_size * B * T / (sustained["ms_per_step"] * 1e-3)
-            sustained["ratio_to_timed_regions"] = sustained["ms_per_step"] / (dt / args.steps * 1e3)
+        sustained = sustained_block(step, pipe, args, dt / args.steps * 1e3, group_size * B * T, dev_index)
+        sustained = sustained_over_ranks(sustained, grp, device, group_size * B * T, dt / args.steps * 1e3)
         barrier()
     # comparisons between the variants and with the CPU baseline use stream 0's batch (wl["x"]): every stream has its own trials
     out, _ = step(index=0)
@@ -1335,10 +1500,7 @@ def run(args):
 
     # the same K steps with the input side inside the graph (synthesis + noise regenerated every step)
     dte, _, (out_e, mae_e) = timed_steps(lambda: step(cov="e2e"), min(args.repeats, 3))
-    if use_dist:
-        gathered = [torch.empty_like(mae_e) for _ in range(world)]
-        dist.all_gather(gathered, mae_e)
-        mae_e = torch.stack(gathered).mean(dim=0)
+    mae_e = torch.stack(grp.gather(mae_e)).mean(dim=0)
     e2e = {"value": frames / dte, "unit": "frames/s", "ms_per_step": dte / args.steps * 1e3,
            "mae_deg_per_snr": [float(v) for v in (mae_e * 180 / np.pi).cpu().numpy()],
            "note": "per step, inside the same HIP graph: DoA draw (Philox), delayed-template synthesis with in-kernel delays fused with the AWGN "
@@ -1431,7 +1593,8 @@ def run(args):
             "value": value,
             "unit": "frames/s (one frame = one audio sample instant across all mics)",
             "n_gpus": group_size,
-            "rccl_ranks": group_size if use_dist else 0,
+            "rccl_ranks": group_size if (use_dist and not grp.staged) else 0,
+            "backend": grp.backend,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
@@ -1447,7 +1610,9 @@ def run(args):
             "config": {"workload": f"{names[args.config]}: {M}-mic, {wl['fs'] // 1000} kHz, T={T}, {B} trials/GPU/step, "
                                    f"{G}-DoA grid, bipolar RZCC, bf_mat designed on device from the 1 s chirp",
                        "trials_per_gpu": B, "frames_per_trial": T, "num_mic": M, "num_doa": G, "mic_samples_per_s": value * M,
-                       "parallelism": f"trial-sharded x{group_size}", "hip_streams": nstreams, "hip_graphs": not scan_lane,
+                       "parallelism": f"trial-sharded x{group_size}" + (" (REHEARSAL: all ranks time-slice device 0, gloo, host-staged collectives)"
+                                                                          if args.share_device else ""),
+                       "shared_device": bool(args.share_device), "hip_streams": nstreams, "hip_graphs": not scan_lane,
                        "schedule": (f"scan-lane: eager launches on {nstreams} streams restricted to {32 - scan_lane} compute units per XCD, the "
                                     f"serial checkpoint scans of all batches on one stream that owns the other {scan_lane}") if scan_lane
                                    else "one captured hipGraph per stream, replayed round-robin",
@@ -1456,6 +1621,7 @@ def run(args):
                        "value_e2e": e2e["value"], "e2e_ms_per_step": e2e["ms_per_step"],
                        "clocks": "`value` = hot path on batches resident in HBM (the driver's contract); `config.value_e2e` = input side included (SURVEY 8d)",
                        "device_uuid_per_rank": uuids,
+                       "memory_gb": memory_gb(device),
                        "design_from_template_seconds": wl["design_seconds"],
                        "design_note": "bf_mat from the 1 s chirp for all G DoAs, entirely on the device (reference: 24.8 s for 449 DoAs on 8 vCPUs, SURVEY 6)"},
             "mae_deg_per_snr": [float(v) for v in (mae * 180 / np.pi).cpu().numpy()],
@@ -1510,14 +1676,16 @@ def run(args):
             result["api_per_call_ms"] = api_per_call_block(device)
             result["other_configs"] = other_configs_block(args)
         if not args.no_cpu_baseline and group_size == 1 and noisy:
-            cb, am = cpu_baseline(wl, args.cpu_seconds)
+            cb, am = cpu_baseline(wl, args.cpu_seconds, np_pool, np_workers)
             am_gpu = argmax_direct.cpu().numpy()
             cb["argmax_equal_to_gpu"] = bool(np.array_equal(am["all"], am_gpu) and np.array_equal(am["one"], am_gpu[: len(am["one"])])
-                                             and np.array_equal(am["numpy"], am_gpu[: len(am["numpy"])]))
+                                             and np.array_equal(am["numpy"], am_gpu[: len(am["numpy"])])
+                                             and ("numpy_all" not in am or np.array_equal(am["numpy_all"], am_gpu[: len(am["numpy_all"])])))
             result["cpu_baseline"] = cb
-    if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
+    if np_pool is not None:
+        np_pool.close()
+        np_pool.join()
+    grp.close()
     if rank == 0:
         # RCCL prints a version banner through C stdio on stdout; flush it first so the JSON line is the last line
         import ctypes

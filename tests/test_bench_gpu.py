@@ -68,3 +68,31 @@ def test_bench_stress_share_of_baseline_total_under_rccl():
     assert d["roofline"]["kernel"] == "beamform_gen_kernel" and 0.3 < d["roofline"]["frac"] < 1.0
     assert d["exchange"]["collectives"] == 1 and d["exchange_ms"] > 0 and len(d["ms_per_step_per_rank"]) == 1
     assert len(c["device_uuid_per_rank"]) == 1 and "sustained" not in d
+
+
+def test_bench_two_ranks_rehearsed_on_one_device():
+    """The N > 1 launch rehearsed on the one GPU of this box: `bench.py --gpus 2 --share-device` goes through the
+    GPU-free rank launcher (`launch_ranks`), both ranks use device 0, the process group is gloo with every collective staged through
+    host memory (RCCL refuses two ranks on one device) -- and everything else is the real world > 1 code: rank r builds ITS batches
+    (its DoAs, trials numbered from r B), per-rank clocks are gathered, the timing is the MAX over ranks, the exchange step gathers
+    {doa, p_max, argmax} per trial from both ranks and rank 0 recomputes the MAE per SNR from the gathered trials.  Checked against
+    two single-process runs that build rank 0's and rank 1's workload (--as-rank): the 2-rank MAE curves are their means."""
+    d2 = _run(["--gpus", "2", "--share-device"], {})
+    assert d2["n_gpus"] == 2 and d2["rccl_ranks"] == 0 and d2["backend"].startswith("gloo") and d2["config"]["shared_device"] is True
+    assert len(d2["ms_per_step_per_rank"]) == 2 and all(t > 0 for t in d2["ms_per_step_per_rank"])
+    assert d2["ms_per_step"] >= max(d2["ms_per_step_per_rank"]) * 0.999  # the job's time is the slowest rank's (per region: median of maxima)
+    uu = d2["config"]["device_uuid_per_rank"]
+    assert len(uu) == 2 and uu[0] == uu[1]  # the same physical device: a rehearsal, not a scaling measurement
+    frames = d2["config"]["trials_per_gpu"] * d2["config"]["frames_per_trial"]
+    assert abs(d2["value"] - 2 * frames / (d2["ms_per_step"] * 1e-3)) <= 1e-6 * d2["value"]  # whole-job frames: both ranks' batches
+    ex = d2["exchange"]
+    assert ex["collectives"] == 1 and ex["transport"].startswith("gloo") and len(ex["mae_deg_per_snr_from_gathered_trials"]) == 11
+    assert d2["sustained"]["seconds"] >= d2["sustained"]["seconds_this_rank"] * 0.999
+    singles = [_run(["--as-rank", str(r)], {"MICLOC_FORCE_DIST": "1"}) for r in (0, 1)]
+    assert singles[0]["mae_deg_per_snr"] != singles[1]["mae_deg_per_snr"]  # the ranks really hold different trials
+    for key, single_key in (("mae_deg_per_snr", "mae_deg_per_snr"),):
+        want = [(a + b) / 2 for a, b in zip(singles[0][single_key], singles[1][single_key])]
+        assert max(abs(a - b) for a, b in zip(d2[key], want)) < 1e-9, (d2[key], want)
+    want = [(a + b) / 2 for a, b in zip(singles[0]["exchange"]["mae_deg_per_snr_device_same_batch"], singles[1]["exchange"]["mae_deg_per_snr_device_same_batch"])]
+    assert max(abs(a - b) for a, b in zip(ex["mae_deg_per_snr_from_gathered_trials"], want)) < 1e-9
+    assert ex["mae_deg_per_snr_device_same_batch"] == singles[0]["exchange"]["mae_deg_per_snr_device_same_batch"]  # rank 0's own batch
