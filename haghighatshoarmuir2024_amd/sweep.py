@@ -30,6 +30,90 @@ def doa_error(doa_est, doa_true):
     return np.arcsin(np.abs(np.sin(doa_est - doa_true)))
 
 
+class ShardStore:
+    """Per-shard result persistence of a sweep (`out_dir=`): every finished device batch of a rank is written as ONE small `.npy`
+    (a structured array {trial i8, doa f8, index i8, pmax f8}, 32 bytes per trial, written to a temporary name and renamed: a file
+    either exists completely or not at all), under a directory keyed by everything the results depend on -- sweep, seed, mode, the
+    SNR of every trial, the DoA grid, the hash of bf_mat and of the test signal -- so a rerun with the same arguments finds its own
+    results and any change of them starts a fresh directory.  A rerun loads what exists and computes only the trials that are
+    missing; in parity mode the reference's MT19937 stream is still replayed for the skipped trials, so the results are identical to an
+    uninterrupted run -- also when the world size changed in between (coverage is per trial, not per shard).
+    The reference keeps its sweeps' results the same way, at the end of the script (ref:paper_plots/snn_localization_benchmark.py:588-592,
+    ref:paper_plots/target_snn_localization.py:525); a 16 384-trial sweep over 8 ranks should not restart from zero."""
+
+    REC = np.dtype([("trial", "<i8"), ("doa", "<f8"), ("index", "<i8"), ("pmax", "<f8")])
+
+    def __init__(self, out_dir, sweep, total, **key):
+        import hashlib
+        import json
+        import os
+
+        def h(v):
+            if isinstance(v, np.ndarray):
+                a = np.ascontiguousarray(v)
+                return {"sha256": hashlib.sha256(a.tobytes()).hexdigest(), "shape": list(a.shape), "dtype": str(a.dtype)}
+            if isinstance(v, (np.integer, np.floating)):
+                return v.item()
+            return v
+
+        self.meta = {"sweep": sweep, "total": int(total), "format": 1, **{k: h(v) for k, v in sorted(key.items())}}
+        blob = json.dumps(self.meta, sort_keys=True).encode()
+        self.key = hashlib.sha256(blob).hexdigest()[:16]
+        self.dir = os.path.join(str(out_dir), f"{sweep}-{self.key}")
+        os.makedirs(self.dir, exist_ok=True)
+        meta_path = os.path.join(self.dir, "meta.json")
+        if not os.path.exists(meta_path):
+            tmp = f"{meta_path}.tmp-{os.getpid()}"
+            with open(tmp, "wb") as f:
+                f.write(blob)
+            os.replace(tmp, meta_path)  # (several ranks may race: they all write the same bytes)
+        self.total = int(total)
+        self.have = np.zeros(self.total, dtype=bool)
+        self.rec = np.zeros(self.total, dtype=self.REC)
+        self.files_loaded = 0
+        self.trials_loaded = 0
+        self.files_written = 0
+        for name in sorted(os.listdir(self.dir)):
+            if not (name.startswith("trials_") and name.endswith(".npy")):
+                continue
+            try:
+                a = np.load(os.path.join(self.dir, name))
+            except (OSError, ValueError):
+                continue  # (cannot happen with the rename protocol; a damaged file is simply recomputed)
+            if a.dtype != self.REC or a.ndim != 1 or len(a) == 0 or a["trial"].min() < 0 or a["trial"].max() >= self.total:
+                continue
+            self.rec[a["trial"]] = a
+            self.have[a["trial"]] = True
+            self.files_loaded += 1
+        self.trials_loaded = int(self.have.sum())
+
+    def covered(self, lo, hi):
+        return bool(self.have[lo:hi].all())
+
+    def put(self, trials, doa, index, pmax):
+        """Persist one finished batch (any set of trial numbers) and mark it done."""
+        import os
+
+        trials = np.asarray(trials, dtype=np.int64)
+        if len(trials) == 0:
+            return
+        a = np.zeros(len(trials), dtype=self.REC)
+        a["trial"], a["doa"], a["index"], a["pmax"] = trials, doa, index, pmax
+        name = f"trials_{int(trials.min()):08d}_{int(trials.max()) + 1:08d}_{len(trials)}.npy"
+        tmp = os.path.join(self.dir, f".tmp-{os.getpid()}-{name}")
+        with open(tmp, "wb") as f:
+            np.save(f, a)
+            f.flush()
+            os.fsync(f.fileno())
+        os.replace(tmp, os.path.join(self.dir, name))
+        self.rec[trials] = a
+        self.have[trials] = True
+        self.files_written += 1
+
+    def stats(self):
+        return {"dir": self.dir, "files_loaded": self.files_loaded, "trials_loaded": self.trials_loaded, "files_written": self.files_written}
+
+
 def gather_shards(local, total, rank, world_size, group=None, bounds=None, stats=None):
     """The sweep's one exchange step: all-gather the per-trial result arrays of contiguous shards; returns the
     full-length arrays on every rank.  `local` is a dict name -> 1-d numpy array (this rank's shard; any mix of dtypes).
@@ -120,12 +204,16 @@ def device_localizer(beamf, bf_mat, max_batch=1100):
     return run
 
 
-def _throughput_pipelined(beamf, bf_mat, time_test, sig_test, doa_all, snr_db_trial, lo, hi, batch_trials, seed, streams, scan_lane_cus):
+def _throughput_pipelined(beamf, bf_mat, time_test, sig_test, doa_all, snr_db_trial, lo, hi, batch_trials, seed, streams, scan_lane_cus,
+                          ranges=None, on_done=None):
     """Trials [lo, hi) of a throughput-mode sweep with several batches in flight (runtime.StreamPipeline): batch k is synthesised
     (micloc_synth_awgn_f64: delayed template + Philox noise numbered by global trial) and localised on stream k % streams, its
     arg-max / power rows return through page-locked memory, nothing on the host waits before the end.  Long recordings (the encoder
     is time-chunked) run their serial checkpoint scans on the pipeline's scan lane.  The same bits as one batch at a time.
-    Returns (argmax [hi - lo] int64, pmax [hi - lo])."""
+    `ranges`: the batches [(s0, s1), ...] to compute (default: all of [lo, hi) in steps of batch_trials -- a resumed sweep skips the
+    finished ones); `on_done(s0, s1, argmax, pmax)` is called for every batch as soon as its results are known to be on the host (an
+    event behind its copies, polled when the next batch is enqueued -- no extra synchronisation) and for the rest at the end.
+    Returns (argmax [hi - lo] int64, pmax [hi - lo]); rows of batches that were not in `ranges` are zero."""
     import torch
 
     from . import runtime, synthesis
@@ -137,15 +225,16 @@ def _throughput_pipelined(beamf, bf_mat, time_test, sig_test, doa_all, snr_db_tr
     time_in, sig_in = synthesis._resample(time_test, sig_test, fs)
     tpl = runtime.Template(time_in, sig_in, fs, device=beamf.device)
     dev, T = tpl.device, tpl.T
-    starts = list(range(lo, hi, batch_trials))
-    nplans = max(1, min(int(streams), len(starts)))
+    if ranges is None:
+        ranges = [(s0, min(hi, s0 + batch_trials)) for s0 in range(lo, hi, batch_trials)]
+    nplans = max(1, min(int(streams), len(ranges)))
     nir = neuron_impulse_response(time_in, beamf.tau_vec)
     plans = [beamf.plan()] + [beamf.new_plan() for _ in range(nplans - 1)]
     for pl in plans:
         pl.set_neuron_kernel(nir)
         pl.set_bf_mat(np.asarray(bf_mat, dtype=np.float64))
     G = plans[0].G
-    Bmax = min(batch_trials, hi - lo)
+    Bmax = max(s1 - s0 for s0, s1 in ranges)
     chunked = plans[0].encoder_chunks(Bmax, T) > 1
     try:
         pipe = runtime.StreamPipeline(plans, scan_lane=scan_lane_cus if (chunked and nplans > 1) else 0)
@@ -158,8 +247,8 @@ def _throughput_pipelined(beamf, bf_mat, time_test, sig_test, doa_all, snr_db_tr
     wss = [runtime.awgn_workspace(Bmax, T, M, dev) for _ in plans]
     outs = [None] * nplans
     snr_dev = torch.from_numpy(np.ascontiguousarray(snr_db_trial[lo:hi], dtype=np.float64)).to(dev)
-    am_host = torch.empty((hi - lo,), dtype=torch.int32).pin_memory()
-    pw_host = torch.empty((hi - lo, G), dtype=torch.float64).pin_memory()
+    am_host = torch.zeros((hi - lo,), dtype=torch.int32).pin_memory()
+    pw_host = torch.zeros((hi - lo, G), dtype=torch.float64).pin_memory()
     cur = {}
 
     def before(i):
@@ -171,97 +260,131 @@ def _throughput_pipelined(beamf, bf_mat, time_test, sig_test, doa_all, snr_db_tr
         runtime.synth_awgn(tpl, "apply_to_template", snr_dev[s0 - lo : s1 - lo], seed=seed, first_trial=s0, ws=wss[i], delays=d_delays,
                            out=xs[i][: s1 - s0])
 
+    pending = []  # (event behind the batch's device -> host copies, s0, s1)
+
     def after(i, out):
         s0, s1 = cur["range"]
         am_host[s0 - lo : s1 - lo].copy_(out["argmax"], non_blocking=True)
         pw_host[s0 - lo : s1 - lo].copy_(out["power"], non_blocking=True)
+        if on_done is not None:
+            ev = torch.cuda.Event()
+            ev.record()  # (on the batch's stream: StreamPipeline runs `after` under it)
+            pending.append((ev, s0, s1))
 
-    for k, s0 in enumerate(starts):
-        s1 = min(hi, s0 + batch_trials)
+    def report(all_=False):
+        while pending and (all_ or pending[0][0].query()):
+            _, s0, s1 = pending.pop(0)
+            a = am_host[s0 - lo : s1 - lo].numpy().astype(np.int64)
+            on_done(s0, s1, a, pw_host[s0 - lo : s1 - lo].numpy()[np.arange(s1 - s0), a])
+
+    for k, (s0, s1) in enumerate(ranges):
         cur["range"] = (s0, s1)
         i = k % nplans
         if outs[i] is not None and outs[i]["argmax"].shape[0] != s1 - s0:
             outs[i] = None  # (a last, shorter batch: its own result tensors)
         pipe.snn_pipeline(lambda j: xs[j][: cur["range"][1] - cur["range"][0]], before=before, after=after, index=i, out=outs, want_power=True)
+        report()
     pipe.synchronize()
+    report(all_=True)
     am = am_host.numpy().astype(np.int64)
     return am, pw_host.numpy()[np.arange(hi - lo), am]
 
 
 def _template_sweep(beamf, bf_mat, doa_list, time_test, sig_test, snr_db_trial, num_sim, seed, mode, rank, world_size, group,
-                    localizer, batch_trials, streams=4, scan_lane_cus=4):
+                    localizer, batch_trials, streams=4, scan_lane_cus=4, out_dir=None, sweep_name="template"):
     """The Monte-Carlo loop shared by the noisy-target and the speech sweep (target_snn_localization.py:447-467 / :224-245):
     per trial `doa = rand(1)[0] * 2 pi`, apply_to_template at `snr_db_trial[trial]`, power, arg-max, pi-periodic error.
-    Trials are processed in batches of `batch_trials` (host memory: a speech trial is 18.6 MB)."""
+    Trials are processed in batches of `batch_trials` (host memory: a speech trial is 18.6 MB).  out_dir: per-batch result files and
+    resume (ShardStore): finished trials are loaded, only the missing ones are computed, the result is the uninterrupted run's."""
     total = len(snr_db_trial)
     lo, hi = shard_range(total, rank, world_size)
+    store = None
+    if out_dir is not None:
+        store = ShardStore(out_dir, sweep_name, total, seed=int(seed), mode=mode, snr_db_trial=np.asarray(snr_db_trial, dtype=np.float64),
+                           doa_list=np.asarray(doa_list, dtype=np.float64), bf_mat=np.asarray(bf_mat), time_test=np.asarray(time_test, dtype=np.float64),
+                           sig_test=np.asarray(sig_test, dtype=np.float64), fs=float(beamf.fs), num_mic=len(beamf.geometry),
+                           r_vec=np.asarray(beamf.geometry.r_vec, dtype=np.float64), theta_vec=np.asarray(beamf.geometry.theta_vec, dtype=np.float64))
+    done = store.have.copy() if store is not None else np.zeros(total, dtype=bool)
     pipelined = mode == "throughput" and localizer is None and streams > 0 and hi > lo
     localizer = localizer or device_localizer(beamf, bf_mat, max_batch=batch_trials)
     M = len(beamf.geometry)
     doa_all = np.zeros(total)
-    argmax_parts, pmax_parts = [], []
+    argmax = np.zeros(hi - lo, dtype=np.int64)
+    pmax = np.zeros(hi - lo)
+    if store is not None:  # what earlier runs finished of this rank's shard
+        argmax[done[lo:hi]] = store.rec["index"][lo:hi][done[lo:hi]]
+        pmax[done[lo:hi]] = store.rec["pmax"][lo:hi][done[lo:hi]]
 
-    def flush(sig_batch, time_in):
+    def finished(trials, a, p):
+        trials = np.asarray(trials, dtype=np.int64)
+        argmax[trials - lo] = np.asarray(a, dtype=np.int64)
+        pmax[trials - lo] = np.asarray(p, dtype=np.float64)
+        if store is not None:
+            store.put(trials, doa_all[trials], a, p)
+
+    def flush(sig_batch, time_in, trials):
         a, p = localizer(sig_batch, time_in)
-        argmax_parts.append(np.asarray(a, dtype=np.int64))
-        pmax_parts.append(np.asarray(p, dtype=np.float64))
+        finished(trials, a, p)
 
     if mode == "parity":
-        # the reference's global MT19937 stream, replayed on every rank; a rank keeps the trials of its shard
+        # the reference's global MT19937 stream, replayed on every rank; a rank keeps the trials of its shard (a resumed sweep: the
+        # ones of its shard that no earlier run finished -- the stream is drawn for every trial all the same)
         np.random.seed(seed)
         T = len(np.arange(time_test.min(), time_test.max(), step=1 / beamf.fs))
-        sigs, time_in = [], None
+        sigs, ids, time_in = [], [], None
         for trial in range(total):
             doa = np.random.rand(1)[0] * 2 * np.pi
             doa_all[trial] = doa
-            if lo <= trial < hi:
+            if lo <= trial < hi and not done[trial]:
                 time_in, sig = synthesize_array_signal(beamf.geometry, beamf.fs, time_test, sig_test, doa)
                 sig += np.sqrt(np.mean(sig**2)) / np.sqrt(10 ** (snr_db_trial[trial] / 10)) * np.random.randn(*sig.shape)
                 sigs.append(sig)
+                ids.append(trial)
                 if len(sigs) == batch_trials:
-                    flush(np.stack(sigs), time_in)
-                    sigs = []
+                    flush(np.stack(sigs), time_in, ids)
+                    sigs, ids = [], []
             else:
                 np.random.randn(T, M)  # keep the stream aligned: the reference draws T x M normals for every trial
         if sigs:
-            flush(np.stack(sigs), time_in)
+            flush(np.stack(sigs), time_in, ids)
     elif mode == "throughput":
         from . import synthesis
 
         rng = np.random.RandomState(seed)
         doa_all[:] = rng.rand(total) * 2 * np.pi
-        if pipelined:
+        ranges = [(s0, min(hi, s0 + batch_trials)) for s0 in range(lo, hi, batch_trials)]
+        ranges = [(s0, s1) for s0, s1 in ranges if not done[s0:s1].all()]  # (a batch with any trial missing is recomputed whole)
+        if pipelined and ranges:
             # the default localizer: several batches in flight, no host synchronisation between them (same bits)
-            a, p = _throughput_pipelined(beamf, bf_mat, time_test, sig_test, doa_all, snr_db_trial, lo, hi, batch_trials, seed, streams,
-                                         scan_lane_cus)
-            argmax_parts.append(a)
-            pmax_parts.append(p)
-        for s0 in (() if pipelined else range(lo, hi, batch_trials)):
-            s1 = min(hi, s0 + batch_trials)
+            _throughput_pipelined(beamf, bf_mat, time_test, sig_test, doa_all, snr_db_trial, lo, hi, batch_trials, seed, streams, scan_lane_cus,
+                                  ranges=ranges, on_done=lambda s0, s1, a, p: finished(np.arange(s0, s1), a, p))
+        for s0, s1 in (() if pipelined else ranges):
             # noise-free array signals synthesised on the device (bit-exact with the host np.interp path), noise from the
             # Philox kernel, numbered by GLOBAL trial: the same draw for any sharding
             time_in, x = beamf.synthesize_batch((time_test, sig_test), doa_all[s0:s1])
             synthesis.add_noise_(x, snr_db_trial[s0:s1], seed=seed, first_trial=s0)
-            flush(x, time_in)
+            flush(x, time_in, np.arange(s0, s1))
     else:
         raise ValueError("mode must be 'parity' or 'throughput'")
 
-    argmax = np.concatenate(argmax_parts) if argmax_parts else np.zeros(0, dtype=np.int64)
-    pmax = np.concatenate(pmax_parts) if pmax_parts else np.zeros(0)
     # the one exchange step: {argmax i64, pmax f64} per trial in ONE all-gather (the DoAs come from the shared stream: every rank has them)
     exchange = {}
     full = gather_shards({"argmax": argmax, "pmax": pmax}, total, rank, world_size, group, stats=exchange)
     err = doa_error(np.asarray(doa_list)[full["argmax"]], doa_all)
     shape = (total // num_sim, num_sim)
-    return dict(doa=doa_all.reshape(shape), argmax=full["argmax"].reshape(shape), pmax=full["pmax"].reshape(shape), err=err.reshape(shape),
-                mae_deg=np.mean(err.reshape(shape), axis=1) * 180 / np.pi, exchange=exchange)
+    res = dict(doa=doa_all.reshape(shape), argmax=full["argmax"].reshape(shape), pmax=full["pmax"].reshape(shape), err=err.reshape(shape),
+               mae_deg=np.mean(err.reshape(shape), axis=1) * 180 / np.pi, exchange=exchange)
+    if store is not None:
+        res["persistence"] = store.stats()
+    return res
 
 
 def noisy_target_sweep(beamf, bf_mat, doa_list, snr_db_vec=None, num_sim=100, seed=0, mode="parity", rank=0, world_size=1,
                        group=None, freq_design=2000.0, test_duration=100e-3, snr_gain_due_to_bandwidth=None, localizer=None,
-                       batch_trials=1100, streams=4):
+                       batch_trials=1100, streams=4, out_dir=None):
     """paper_plots/target_snn_localization.py:435-467.  Returns dict(doa, argmax, err, pmax: [num_snr, num_sim];
-    mae_deg [num_snr]) on every rank."""
+    mae_deg [num_snr]) on every rank.  out_dir: every finished batch is written there and a rerun with the same arguments resumes
+    (ShardStore; `persistence` in the result says what was loaded and written)."""
     fs = beamf.fs
     snr_db_vec = np.asarray(np.linspace(-10, 20, 11) if snr_db_vec is None else snr_db_vec, dtype=np.float64)
     if snr_gain_due_to_bandwidth is None:
@@ -270,7 +393,7 @@ def noisy_target_sweep(beamf, bf_mat, doa_list, snr_db_vec=None, num_sim=100, se
     sig_test = np.sin(2 * np.pi * freq_design * time_test)
     snr_trial = np.repeat(snr_db_vec - 10 * np.log10(snr_gain_due_to_bandwidth), num_sim)  # :449
     res = _template_sweep(beamf, bf_mat, doa_list, time_test, sig_test, snr_trial, num_sim, seed, mode, rank, world_size, group,
-                          localizer, batch_trials, streams)
+                          localizer, batch_trials, streams, out_dir=out_dir, sweep_name="noisy")
     res["snr_db_vec"] = snr_db_vec
     return res
 
@@ -293,23 +416,25 @@ def speech_source(fs, flac_path=None, pcm16=None, rate=None):
 
 
 def speech_target_sweep(beamf, bf_mat, doa_list, source, snr_db_vec=None, num_sim=20, seed=0, mode="parity", rank=0, world_size=1,
-                        group=None, localizer=None, batch_trials=None, streams=4):
+                        group=None, localizer=None, batch_trials=None, streams=4, out_dir=None):
     """The speech accuracy sweep of paper_plots/target_snn_localization.py:213-245: `source` = (time_fs, sig_test) from
     `speech_source`, 11 SNRs x 20 trials, NO bandwidth correction of the SNR (`snr_db_target = snr_db`, :227).
     batch_trials: trials per device batch (default: 25 in parity mode -- a trial is 18.6 MB on the host --, 125 in throughput mode,
-    where the batches are synthesised on the device and `streams` of them are in flight; streams=0: one batch at a time)."""
+    where the batches are synthesised on the device and `streams` of them are in flight; streams=0: one batch at a time).
+    out_dir: per-batch result files and resume, as in noisy_target_sweep."""
     if batch_trials is None:
         batch_trials = 125 if mode == "throughput" else 25
     snr_db_vec = np.asarray(np.linspace(-10, 20, 11) if snr_db_vec is None else snr_db_vec, dtype=np.float64)
     time_fs, sig_test = source
     res = _template_sweep(beamf, bf_mat, doa_list, np.asarray(time_fs, dtype=np.float64), np.asarray(sig_test, dtype=np.float64),
-                          np.repeat(snr_db_vec, num_sim), num_sim, seed, mode, rank, world_size, group, localizer, batch_trials, streams)
+                          np.repeat(snr_db_vec, num_sim), num_sim, seed, mode, rank, world_size, group, localizer, batch_trials, streams,
+                          out_dir=out_dir, sweep_name="speech")
     res["snr_db_vec"] = snr_db_vec
     return res
 
 
 def xylo_target_sweep(demo, snr_db_vec=None, num_sim=100, seed=0, mode="parity", rank=0, world_size=1, group=None,
-                      test_duration=1000e-3, snr_gain_due_to_bandwidth=None, batch_trials=None, device_delays=None, peak=None):
+                      test_duration=1000e-3, snr_gain_due_to_bandwidth=None, batch_trials=None, device_delays=None, peak=None, out_dir=None):
     """The Xylo accuracy sweep of paper_plots/target_xylo_localization.py:540-608 (and its `_unipolar` twin): chirp test
     signal over the design band (:549-560), per trial `signal_from_template` -> AWGN -> `spike_encoding` -> `xylo_process`
     -> spike rate -> `find_peak_location(win_size)` with win_size = 2 * ((num_grid // 32) // 2) + 1 (:600-603) -> error.
@@ -343,57 +468,78 @@ def xylo_target_sweep(demo, snr_db_vec=None, num_sim=100, seed=0, mode="parity",
     if device_delays is None:
         device_delays = mode == "throughput"
     doa_all = np.zeros(total)
-    idx_parts = []
+    index = np.zeros(hi - lo, dtype=np.int64)
 
     if peak is None:
         peak = "device" if mode == "throughput" else "host"
+    store = None
+    if out_dir is not None:
+        store = ShardStore(out_dir, "xylo", total, seed=int(seed), mode=mode, snr_db_trial=snr_trial, doa_list=np.asarray(doa_list, dtype=np.float64),
+                           bf_mat=np.asarray(demo.bf_mats[0]), fs=float(fs), num_mic=len(geometry), bipolar=bool(demo.bipolar_spikes),
+                           time_test=time_test, sig_test=sig_test, peak=peak, device_delays=bool(device_delays), win_size=int(win_size),
+                           r_vec=np.asarray(geometry.r_vec, dtype=np.float64), theta_vec=np.asarray(geometry.theta_vec, dtype=np.float64))
+    done = store.have.copy() if store is not None else np.zeros(total, dtype=bool)
+    if store is not None:
+        index[done[lo:hi]] = store.rec["index"][lo:hi][done[lo:hi]]
 
-    def flush(x):
+    def flush(x, trials):
+        trials = np.asarray(trials, dtype=np.int64)
         if peak == "device":  # find_peak_location on the device (exact integer window sums): only indices come back
-            idx_parts.extend(int(v) for v in demo.peak_batch(x, win_size).cpu().numpy())
+            idx = demo.peak_batch(x, win_size).cpu().numpy().astype(np.int64)
             demo.network().check()  # (the copy above synchronised: a broken ticket-queue launch raises here)
-            return
-        rate = demo.rate_batch(x).cpu().numpy()  # [B, G]: mean(spikes_out) * fs per DoA
-        demo.network().check()
-        for p in rate:
-            mx = p.max()
-            p = p / mx if mx > 0 else p  # :595 (an all-silent output divides 0 by 0 in the reference)
-            idx_parts.append(int(find_peak_location(sig_in=p, win_size=win_size)))
+        else:
+            rate = demo.rate_batch(x).cpu().numpy()  # [B, G]: mean(spikes_out) * fs per DoA
+            demo.network().check()
+            idx = []
+            for p in rate:
+                mx = p.max()
+                p = p / mx if mx > 0 else p  # :595 (an all-silent output divides 0 by 0 in the reference)
+                idx.append(int(find_peak_location(sig_in=p, win_size=win_size)))
+            idx = np.asarray(idx, dtype=np.int64)
+        index[trials - lo] = idx
+        if store is not None:
+            store.put(trials, doa_all[trials], idx, np.zeros(len(trials)))
 
     if mode == "parity":
         np.random.seed(seed)
         T, M = len(time_test), len(geometry)
-        sigs = []
+        sigs, ids = [], []
         for trial in range(total):
             doa = np.random.rand(1)[0] * 2 * np.pi
             doa_all[trial] = doa
-            if lo <= trial < hi:
+            if lo <= trial < hi and not done[trial]:
                 sig = signal_from_template(geometry, (time_test, sig_test, doa))
                 noise_sigma = np.sqrt(np.mean(sig**2) / 10 ** (snr_trial[trial] / 10))
                 sigs.append(sig + noise_sigma * np.random.randn(*sig.shape))
+                ids.append(trial)
                 if len(sigs) == batch_trials:
-                    flush(np.stack(sigs))
-                    sigs = []
+                    flush(np.stack(sigs), ids)
+                    sigs, ids = [], []
             else:
                 np.random.randn(T, M)
         if sigs:
-            flush(np.stack(sigs))
+            flush(np.stack(sigs), ids)
     elif mode == "throughput":
         rng = np.random.RandomState(seed)
         doa_all[:] = rng.rand(total) * 2 * np.pi
         for s0 in range(lo, hi, batch_trials):
             s1 = min(hi, s0 + batch_trials)
+            if done[s0:s1].all():
+                continue
             x = synthesis.signal_from_template_batch(geometry, (time_test, sig_test), doa_all[s0:s1], device=demo.device, device_delays=device_delays)
             synthesis.add_noise_(x, snr_trial[s0:s1], seed=seed, first_trial=s0)
-            flush(x)
+            flush(x, np.arange(s0, s1))
     else:
         raise ValueError("mode must be 'parity' or 'throughput'")
 
-    full = gather_shards({"index": np.asarray(idx_parts, dtype=np.int64)}, total, rank, world_size, group)
+    full = gather_shards({"index": index}, total, rank, world_size, group)
     err = doa_error(np.asarray(doa_list)[full["index"]], doa_all)
     shape = (len(snr_db_vec), num_sim)
-    return dict(doa=doa_all.reshape(shape), index=full["index"].reshape(shape), err=err.reshape(shape),
-                mae_deg=np.mean(err.reshape(shape), axis=1) * 180 / np.pi, snr_db_vec=snr_db_vec, win_size=win_size, parity="unpinned (integer LIF)")
+    res = dict(doa=doa_all.reshape(shape), index=full["index"].reshape(shape), err=err.reshape(shape),
+               mae_deg=np.mean(err.reshape(shape), axis=1) * 180 / np.pi, snr_db_vec=snr_db_vec, win_size=win_size, parity="unpinned (integer LIF)")
+    if store is not None:
+        res["persistence"] = store.stats()
+    return res
 
 
 def main(argv=None):

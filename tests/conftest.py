@@ -56,3 +56,11 @@ def cfg2():
         r_vec=k["ccirc_r"],
         theta_vec=k["ccirc_theta"],
     )
+
+
+def campaign_seeds(name, default):
+    """Seeds of a random parity campaign as pytest params whose ids carry the seed COUNT (`seed17-of-600`): the driver's `pytest -m gpu`
+    log says how many configurations ran.  `MICLOC_SEEDS_<NAME>` overrides one campaign, `MICLOC_RANDOM_SEEDS` all of them (the
+    builder's long runs: DESIGN.md section 2)."""
+    n = int(os.environ.get(f"MICLOC_SEEDS_{name.upper()}", os.environ.get("MICLOC_RANDOM_SEEDS", str(default))))
+    return [pytest.param(s, id=f"seed{s}-of-{n}") for s in range(n)]

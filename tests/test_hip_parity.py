@@ -9,7 +9,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import golden
+from conftest import campaign_seeds, golden
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -557,29 +557,31 @@ def test_lif_beamform_stage_shapes_vs_oracle(torch, C, G, T, n_nir):
     np.testing.assert_array_equal(out_p["argmax"].cpu().numpy()[clear], out_y["argmax"].cpu().numpy()[clear])
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("MICLOC_RANDOM_SEEDS", "12"))))
-def test_fused_pipeline_random_configurations_vs_oracle(torch, seed):
-    """Randomised configurations (microphones, STHT length and tap pattern, filter order, robust width, polarity,
-    neuron-kernel length, DoA count, trial length, signal character) through the fused pipeline against the oracle:
-    spikes bit-exact, power 1e-12, same arg-max.  Small sizes, fixed seeds."""
-    from haghighatshoarmuir2024_amd.runtime import Plan
+def _draw_fused_configuration(seed):
+    """One random configuration of the fused pipeline.  The channel counts cover all three beamforming forms (C <= 16: bf_mat-stationary;
+    C = 24 / 26: the general kernel with two channel tiles; C = 128: BASELINE config 5's shape), robust widths 1 ... 40, band-pass orders
+    1 ... 3 (order 1 = config 4's filter: dense candidate trains), recordings from one frame to 50 000."""
     from scipy.signal import butter
 
     rng = np.random.default_rng(1000 + seed)
-    M = int(rng.choice([1, 2, 3, 5, 7, 8, 12]))
-    L = int(rng.choice([8, 30, 64, 96, 200]))
+    M = int(rng.choice([1, 2, 3, 5, 7, 8, 12, 13, 64], p=[0.07, 0.07, 0.07, 0.07, 0.32, 0.08, 0.10, 0.12, 0.10]))
+    L = int(rng.choice([8, 30, 64, 96, 200, 480] + ([960] if M == 64 else [])))
     kernel = rng.standard_normal(L)
     if rng.random() < 0.6:
-        kernel[::2] = 0.0  # Hilbert-like stride-2 pattern (compact tap table)
-    order = int(rng.choice([1, 2, 3]))
+        kernel[::2] = 0.0  # Hilbert-like stride-2 pattern (matrix-core STHT)
+    order = int(rng.choice([1, 2, 2, 3]))
     b, a = butter(order, [0.05, 0.2 + 0.1 * rng.random()], btype="bandpass")
-    w = int(rng.choice([1, 2, 5, 12, 24]))
+    w = int(rng.integers(1, 41))
     bipolar = bool(rng.random() < 0.7)
-    n_nir = int(rng.choice([1, 7, 35, 60]))
+    n_nir = int(rng.choice([1, 7, 35, 60, 71]))
     nir = np.abs(rng.standard_normal(n_nir)) + 0.01
-    G = int(rng.choice([3, 16, 17, 100, 200, 361]))
-    T = int(rng.choice([1, 2, 17, 255, 256, 257, 700, 1500]))
-    B = int(rng.choice([1, 2, 5]))
+    G = int(rng.choice([3, 16, 17, 100, 200, 361, 449] + ([1440] if M == 64 else [])))
+    if M == 64:
+        T = int(rng.choice([17, 257, 1500, 4799]))
+        B = int(rng.choice([1, 2]))
+    else:
+        T = int(rng.choice([1, 2, 17, 255, 256, 257, 700, 1500, 4799, 12000, 50000], p=[0.04, 0.04, 0.08, 0.1, 0.1, 0.1, 0.2, 0.2, 0.08, 0.04, 0.02]))
+        B = 1 if T > 5000 else int(rng.choice([1, 2, 5]))
     W = rng.standard_normal((2 * M, G))
     kind = seed % 4
     t = np.arange(T)[None, :, None]
@@ -591,26 +593,41 @@ def test_fused_pipeline_random_configurations_vs_oracle(torch, seed):
         x = np.round(3 * rng.standard_normal((B, T, M)))
     else:  # silent start, then signal: streams without a direction for a while
         x = rng.standard_normal((B, T, M)) * (t >= T // 2)
-    p = Plan(M, kernel, b, a, w, bipolar)
-    p.set_neuron_kernel(nir)
-    p.set_bf_mat(W)
-    out = p.snn_pipeline(p.to_device(x), want_spikes=True, want_power=True)
+    return rng, dict(M=M, L=L, kernel=kernel, order=order, b=b, a=a, w=w, bipolar=bipolar, nir=nir, G=G, T=T, B=B, W=W, x=x)
+
+
+@pytest.mark.parametrize("seed", campaign_seeds("fused", 600))
+def test_fused_pipeline_random_configurations_vs_oracle(torch, seed):
+    """Randomised configurations (microphones 1 ... 64, STHT length and tap pattern, filter order, robust width 1 ... 40, polarity,
+    neuron-kernel length, DoA count, trial length up to 50 000, signal character) through the fused pipeline against the oracle:
+    spikes bit-exact, power 1e-12, same arg-max; then the same batch with a random time chunking of the encoder: identical bits.
+    600 seeds in the driver's run (the id says so); the builder's campaigns set MICLOC_RANDOM_SEEDS."""
+    from haghighatshoarmuir2024_amd.runtime import Plan
+
+    rng, c = _draw_fused_configuration(seed)
+    M, w, bipolar, T, B, G, x = c["M"], c["w"], c["bipolar"], c["T"], c["B"], c["G"], c["x"]
+    tag = f"seed={seed} M={M} L={c['L']} order={c['order']} w={w} bip={bipolar} n_nir={len(c['nir'])} G={G} T={T} B={B}"
+    p = Plan(M, c["kernel"], c["b"], c["a"], w, bipolar)
+    p.set_neuron_kernel(c["nir"])
+    p.set_bf_mat(c["W"])
+    xd = p.to_device(x)
+    out = p.snn_pipeline(xd, want_spikes=True, want_power=True)
+    spikes, power, argmax = out["spikes"].cpu().numpy(), out["power"].cpu().numpy(), out["argmax"].cpu().numpy()
     for i in range(B):
-        ref = O.snn_chain(x[i], kernel, b, a, w, bipolar, nir, W, want=("spikes", "power"))
-        np.testing.assert_array_equal(out["spikes"][i].cpu().numpy(), ref["spikes"], err_msg=f"M={M} L={L} w={w} bip={bipolar} T={T}")
-        np.testing.assert_allclose(out["power"][i].cpu().numpy(), ref["power"], rtol=1e-12, atol=1e-300)
-        pw = out["power"][i].cpu().numpy()
-        top = np.sort(pw)[-2:] if G > 1 else np.array([0.0, pw[0]])
+        ref = O.snn_chain(x[i], c["kernel"], c["b"], c["a"], w, bipolar, c["nir"], c["W"], want=("spikes", "power"))
+        np.testing.assert_array_equal(spikes[i], ref["spikes"], err_msg=tag)
+        np.testing.assert_allclose(power[i], ref["power"], rtol=1e-12, atol=1e-300, err_msg=tag)
+        top = np.sort(power[i])[-2:] if G > 1 else np.array([0.0, power[i][0]])
         if top[1] - top[0] > 1e-9 * abs(top[1]):
-            assert int(out["argmax"][i]) == ref["argmax"]
+            assert int(argmax[i]) == ref["argmax"], tag
     # the same batch with the time axis cut into chunks (scan checkpoints + one workgroup per chunk): identical spikes
     if T >= 64:
         lo = 16 * (-(-w // 16) + 1)
-        chunk = int(rng.integers(lo, max(lo + 1, T)))
+        chunk = int(rng.integers(lo, max(lo + 1, min(T, 6000))))
         p.set_encoder_chunk(chunk)
-        out2 = p.snn_pipeline(p.to_device(x), want_spikes=True, want_power=True)
-        np.testing.assert_array_equal(out2["spikes"].cpu().numpy(), out["spikes"].cpu().numpy(), err_msg=f"chunk={chunk} T={T} w={w}")
-        np.testing.assert_array_equal(out2["power"].cpu().numpy(), out["power"].cpu().numpy())
+        out2 = p.snn_pipeline(xd, want_spikes=True, want_power=True)
+        np.testing.assert_array_equal(out2["spikes"].cpu().numpy(), spikes, err_msg=f"chunk={chunk} " + tag)
+        np.testing.assert_array_equal(out2["power"].cpu().numpy(), power, err_msg=f"chunk={chunk} " + tag)
 
 
 def test_planar_gram_against_numpy(torch):

@@ -6,7 +6,7 @@ import hashlib
 import numpy as np
 import pytest
 
-from conftest import golden
+from conftest import campaign_seeds, golden
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -262,18 +262,19 @@ def test_stream_push_replay_is_one_graph_per_tile(cfg2):
     np.testing.assert_array_equal(h.finish()["power"].cpu().numpy(), ref["power"].cpu().numpy())
 
 
-@pytest.mark.parametrize("seed", range(4))
+@pytest.mark.parametrize("seed", campaign_seeds("streaming", 200))
 def test_stream_random_tilings_eager_and_replayed(cfg2, seed):
     """Random tile sequences (lengths from a small set, so that several lengths get their own captured graph), every tile randomly
     pushed eagerly or replayed, a window small enough to slide many times: the device clock, the in-graph slide and the wrap-around
-    rows must give the one-shot result bit for bit whatever the mix."""
+    rows must give the one-shot result bit for bit whatever the mix.  200 seeds in the driver's run (the id says so); seeds >= 4 draw
+    shorter recordings (3 000 ... 9 000 frames) so that the campaign fits the run."""
     import torch
 
     from haghighatshoarmuir2024_amd.streaming import StreamingLocalizer
 
     rng = np.random.RandomState(100 + seed)
     sizes = [int(v) for v in rng.choice([64, 160, 256, 400, 1024, 1600], size=3, replace=False)]
-    T = int(rng.randint(9000, 16000))
+    T = int(rng.randint(9000, 16000)) if seed < 4 else int(rng.randint(3000, 9000))
     x = rng.randn(2, T, 7)
     x[:, : min(T, 4799), :] += golden("trials_cfg2.npz")["sig_in"][:2][:, : min(T, 4799), :]
     bf = _beamformer()

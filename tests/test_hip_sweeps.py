@@ -196,3 +196,50 @@ def test_xylo_two_band_demo_against_oracle_chain():
         assert idx_dev[i] == idx == find_peak_location(r_host / r_host.max(), win_size=win)
     with pytest.raises(ValueError):
         runtime.peak_location(torch.zeros((1, 2 * G + 1), dtype=torch.int32, device="cuda"), G, win)
+
+
+def test_sweeps_persist_and_resume_on_the_device(cfg2, tmp_path):
+    """`out_dir=` on the device paths (sweep.ShardStore): the pipelined throughput sweep (several batches in flight: a batch is written
+    when the event behind its device -> host copies has fired), the parity sweep and the Xylo sweep each leave one file per batch;
+    with some of the files removed ("the job died there") a rerun recomputes exactly those batches and ends on the bits of the
+    uninterrupted run.  ref:paper_plots/target_snn_localization.py:447-467, :525."""
+    import os
+
+    from haghighatshoarmuir2024_amd.sweep import noisy_target_sweep, xylo_target_sweep
+
+    bf = _beamformer()
+    kw = dict(snr_db_vec=[-5.0, 5.0, 15.0], num_sim=20, seed=3, batch_trials=8)
+    for mode in ("throughput", "parity"):
+        ref = noisy_target_sweep(bf, cfg2["bf_mat"], cfg2["doa_list"], mode=mode, **kw)
+        d = tmp_path / mode
+        one = noisy_target_sweep(bf, cfg2["bf_mat"], cfg2["doa_list"], mode=mode, out_dir=d, **kw)
+        assert one["persistence"]["files_written"] == 8 and one["persistence"]["trials_loaded"] == 0  # 60 trials in batches of 8
+        sub = one["persistence"]["dir"]
+        files = sorted(f for f in os.listdir(sub) if f.startswith("trials_"))
+        assert len(files) == 8
+        for f in (files[1], files[5], files[7]):
+            os.remove(os.path.join(sub, f))
+        two = noisy_target_sweep(bf, cfg2["bf_mat"], cfg2["doa_list"], mode=mode, out_dir=d, **kw)
+        assert two["persistence"]["files_written"] == 3 and two["persistence"]["trials_loaded"] == 60 - 8 - 8 - 4
+        three = noisy_target_sweep(bf, cfg2["bf_mat"], cfg2["doa_list"], mode=mode, out_dir=d, **kw)
+        assert three["persistence"]["files_written"] == 0 and three["persistence"]["trials_loaded"] == 60
+        for res in (one, two, three):
+            for key in ("doa", "argmax", "pmax", "err", "mae_deg"):
+                np.testing.assert_array_equal(res[key], ref[key], err_msg=f"{mode} {key}")
+    # the Xylo sweep (integer-LIF stage parity-unpinned; what is checked here is the resume, against its own uninterrupted run)
+    from micloc.array_geometry import CenterCircularArray
+    from micloc.xylo_snn_localization import Demo
+
+    demo = Demo(geometry=CenterCircularArray(4.5e-2, 7), freq_bands=[[1000.0, 2000.0]], doa_list=np.linspace(-np.pi, np.pi, 65), recording_duration=0.25,
+                bipolar_spikes=True, fs=48_000)
+    xkw = dict(snr_db_vec=[0.0, 20.0], num_sim=6, seed=4, mode="throughput", test_duration=50e-3, batch_trials=4)
+    xref = xylo_target_sweep(demo, **xkw)
+    x1 = xylo_target_sweep(demo, out_dir=tmp_path / "xylo", **xkw)
+    files = sorted(f for f in os.listdir(x1["persistence"]["dir"]) if f.startswith("trials_"))
+    assert len(files) == 3
+    os.remove(os.path.join(x1["persistence"]["dir"], files[1]))
+    x2 = xylo_target_sweep(demo, out_dir=tmp_path / "xylo", **xkw)
+    assert x2["persistence"]["files_written"] == 1 and x2["persistence"]["trials_loaded"] == 8
+    for res in (x1, x2):
+        np.testing.assert_array_equal(res["index"], xref["index"])
+        np.testing.assert_array_equal(res["doa"], xref["doa"])
