@@ -106,6 +106,96 @@ hipError_t launch_peak_location(const int32_t *rate, int B, int G, int F, int wi
     return hipGetLastError();
 }
 
+// ---- moving-target tracking: Envelope.evolve + arg-max over the DoA grid per time step ---------------------------------------------
+// micloc/utils.py:36-81 (the rise / fall envelope of every beamformer output column) and
+// paper_plots/target_snn_localization.py:599-622 (`doa_index = np.argmax(sig_bf_env, axis=1)`): G independent serial chains over T.
+//   state_0 = |y_0|;   rise_t = |y_t| >= state_{t-1};
+//   state_t = (1 - 1/w) * state_{t-1} + 1/w * |y_t| * rise_t,   w = rise_t ? int(fs rise_time) : int(fs fall_time);   env[t] = state_t
+// in NumPy's order of operations: two roundings of products, one of the sum, nothing fused (`__dmul_rn` / `__dadd_rn`); with rise_t = 0
+// the second term is +0 and the sum is the first product.  a_* = 1 - 1/w and i_rise = 1/w_rise are computed on the host by NumPy itself.
+// One wave = 64 DoA columns of one trial (a row segment of 512 contiguous bytes per step); the |y| values and the products 1/w |y| of
+// the NEXT 32 rows are requested / computed off the chain while the current 32 are walked: per step the chain is two multiplies side by
+// side, one add, one select.
+constexpr int ENV_U = 32;
+
+__global__ __launch_bounds__(64) void envelope_kernel(const double *__restrict__ y, int T, int G, double a_rise, double i_rise, double a_fall,
+                                                      double *__restrict__ env)
+{
+    const int g = blockIdx.x * 64 + threadIdx.x;
+    if (g >= G) return;
+    const double *p = y + (size_t)blockIdx.y * T * G + g;
+    double *o = env + (size_t)blockIdx.y * T * G + g;
+    double state = fabs(p[0]);
+    o[0] = state;
+    double cur[ENV_U], nxt[ENV_U];
+#pragma unroll
+    for (int j = 0; j < ENV_U; ++j) cur[j] = (1 + j < T) ? p[(size_t)(1 + j) * G] : 0.0;
+    for (int t0 = 1; t0 < T; t0 += ENV_U) {
+        const int t1 = t0 + ENV_U;
+#pragma unroll
+        for (int j = 0; j < ENV_U; ++j) nxt[j] = (t1 + j < T) ? p[(size_t)(t1 + j) * G] : 0.0;
+        if (t1 <= T) {
+#pragma unroll
+            for (int j = 0; j < ENV_U; ++j) {
+                const double m = fabs(cur[j]);
+                const double up = __dadd_rn(__dmul_rn(a_rise, state), __dmul_rn(i_rise, m));
+                const double down = __dmul_rn(a_fall, state);
+                state = (m >= state) ? up : down;
+                o[(size_t)(t0 + j) * G] = state;
+            }
+        } else {
+            for (int j = 0; t0 + j < T; ++j) {
+                const double m = fabs(cur[j]);
+                const double up = __dadd_rn(__dmul_rn(a_rise, state), __dmul_rn(i_rise, m));
+                const double down = __dmul_rn(a_fall, state);
+                state = (m >= state) ? up : down;
+                o[(size_t)(t0 + j) * G] = state;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < ENV_U; ++j) cur[j] = nxt[j];
+    }
+}
+
+// index[row] = np.argmax(env[row, :]): the FIRST maximum (one wave per row; env >= 0, NaN never wins)
+__global__ __launch_bounds__(256) void rows_argmax_kernel(const double *__restrict__ env, size_t rows, int G, int32_t *__restrict__ index)
+{
+    const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int l = threadIdx.x & 63;
+    const double *r = env + row * G;
+    double best = -1.0;
+    int bi = 0x7fffffff;
+    for (int g = l; g < G; g += 64) {  // ascending per lane: its first maximum
+        const double v = r[g];
+        if (v > best) {
+            best = v;
+            bi = g;
+        }
+    }
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) {
+        const double ov = __shfl_xor(best, s, 64);
+        const int oi = __shfl_xor(bi, s, 64);
+        if (ov > best || (ov == best && oi < bi)) {
+            best = ov;
+            bi = oi;
+        }
+    }
+    if (l == 0) index[row] = bi == 0x7fffffff ? 0 : bi;
+}
+
+hipError_t launch_envelope_track(const double *y, int B, int T, int G, double a_rise, double i_rise, double a_fall, double *env,
+                                 int32_t *index, hipStream_t stream)
+{
+    hipLaunchKernelGGL(envelope_kernel, dim3((G + 63) / 64, B), dim3(64), 0, stream, y, T, G, a_rise, i_rise, a_fall, env);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || !index) return e;
+    const size_t rows = (size_t)B * T;
+    hipLaunchKernelGGL(rows_argmax_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, env, rows, G, index);
+    return hipGetLastError();
+}
+
 // ---- Demo.spike_encoding's channel bookkeeping (xylo_snn_localization.py:339-354) and extract_rate (:379-398) -----------------
 // One band's int8 raster [rows][C] -> its channel block of the assembled tensor [rows][stride]:
 //   mode 0  the ternary value itself          out[row][pos_off + c] = s            (bands concatenated on the channel axis)

@@ -604,6 +604,27 @@ def peak_location(counts, G, win_size, out=None):
     return idx
 
 
+def envelope_track(y, win_fall, win_rise, want_index=True, env_out=None):
+    """micloc_envelope_track_f64: y [T, G] or [B, T, G] float64 device tensor -> (env like y, index int32 [T] / [B, T] or None).
+    Envelope.evolve (micloc/utils.py:36-81) + np.argmax(axis=1) (paper_plots/target_snn_localization.py:599-622) on the device."""
+    torch = _torch()
+    if y.dtype != torch.float64 or y.dim() not in (2, 3) or not y.is_cuda:
+        raise ValueError("envelope_track: a float64 device tensor [T, G] or [B, T, G] is required")
+    if int(win_fall) < 1 or int(win_rise) < 1:
+        raise ValueError("envelope windows must hold at least one sample (int(fs * time) >= 1)")
+    yc = y.contiguous()
+    B, T, G = (1, *yc.shape) if yc.dim() == 2 else yc.shape
+    # NumPy's own arithmetic for the two filter constants (utils.py:70-76: `1 / win_len_state`, `1 - 1 / win_len_state`)
+    wl = np.asarray([int(win_fall), int(win_rise)])
+    inv = 1 / wl
+    a = 1 - inv
+    env = env_out if env_out is not None else torch.empty_like(yc)
+    idx = torch.empty(yc.shape[:-1], dtype=torch.int32, device=yc.device) if want_index else None
+    _lib.check(_lib.load().micloc_envelope_track_f64(_ptr(yc), int(B), int(T), int(G), float(a[1]), float(inv[1]), float(a[0]), _ptr(env),
+                                                     _ptr(idx) if idx is not None else None, _stream(yc.device)), "envelope_track")
+    return env, idx
+
+
 def counter_add_(counter, inc=1):
     """*counter += inc on the device (counter: uint32/int32 device tensor of one element): the `epoch` of the generators."""
     _lib.check(_lib.load().micloc_counter_add_u32(_ptr(counter), int(inc), _stream(counter.device)), "counter_add")

@@ -114,7 +114,9 @@ class SNNBeamformer:
         return time_new, sig
 
     # ---- reference call surface ---------------------------------------------------------------------------
-    def apply_to_signal(self, bf_mat, sig_in_vec):
+    def apply_to_signal(self, bf_mat, sig_in_vec, to_host=True):
+        """Reference :283-370.  to_host=False (not in the reference): the T x G result stays on the device (a torch tensor), e.g. for
+        utils.Envelope.track -- the moving-target read-out without the T x G device -> host copy."""
         time_vec, sig_in_vec = sig_in_vec
         twice_num_mic, num_grid = bf_mat.shape
         num_mic = twice_num_mic // 2
@@ -127,9 +129,9 @@ class SNNBeamformer:
         plan.set_bf_mat(np.asarray(bf_mat, dtype=np.float64))
         x = plan.to_device(np.asarray(sig_in_vec, dtype=np.float64)[None])
         out = plan.snn_pipeline(x, want_y=True, want_power=False)
-        return runtime.to_host(out["y"][0])
+        return runtime.to_host(out["y"][0]) if to_host else out["y"][0]
 
-    def apply_to_template(self, bf_mat, template, snr_db):
+    def apply_to_template(self, bf_mat, template, snr_db, to_host=True):
         try:
             time_temp, sig_temp, doa_temp = template
         except Exception:
@@ -139,7 +141,7 @@ class SNNBeamformer:
         # same draw from the global legacy stream as the reference (:270-275)
         noise = np.sqrt(np.mean(sig_in_vec**2)) / np.sqrt(snr) * np.random.randn(*sig_in_vec.shape)
         sig_in_vec += noise
-        return self.apply_to_signal(bf_mat=bf_mat, sig_in_vec=(time_in, sig_in_vec))
+        return self.apply_to_signal(bf_mat=bf_mat, sig_in_vec=(time_in, sig_in_vec), to_host=to_host)
 
     def synthesize_batch(self, template, doas, device_delays=False):
         """Noise-free array signals for a batch of trials, synthesised on the device (synthesis.apply_to_template_batch).

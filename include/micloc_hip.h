@@ -403,6 +403,16 @@ int micloc_rate_from_counts_f64(const int32_t *counts, int B, int G, int bands, 
  * maximum, minus win_size // 2, modulo G.  Exact integer window sums.  rate [B][bands * G] int32, index [B] (device). */
 int micloc_peak_location_i32(const int32_t *rate, int B, int G, int bands, int win_size, int32_t *index, void *stream);
 
+/* Moving-target tracking: Envelope.evolve (micloc/utils.py:36-81) on the beamformer output and the per-time-step arg-max over the DoA
+ * grid, `doa_index = np.argmax(sig_bf_env, axis=1)` (paper_plots/target_snn_localization.py:599-622), without the T x G array ever
+ * leaving the device.  y [B][T][G] (apply_to_signal's result, real);  env [B][T][G]: env[t] = the envelope state after sample t,
+ * state_0 = |y_0|, state_t = (1 - 1/w) state_{t-1} + 1/w |y_t| [|y_t| >= state_{t-1}] with w = the rise window when the bracket holds,
+ * the fall window otherwise -- NumPy's order of operations, nothing fused: bit-identical to the reference class.  The caller passes
+ * a_rise = 1 - 1/w_rise, i_rise = 1/w_rise, a_fall = 1 - 1/w_fall as NumPy computes them (w = int(fs * time) >= 1).  env is always
+ * written (a caller that only wants the indices passes scratch); index [B][T] int32 (may be NULL) = first maximum of every row. */
+int micloc_envelope_track_f64(const double *y, int B, int T, int G, double a_rise, double i_rise, double a_fall, double *env, int32_t *index,
+                              void *stream);
+
 /* ---- misc ------------------------------------------------------------------------------------- */
 int micloc_abi_version(void);
 const char *micloc_status_string(int status);

@@ -221,6 +221,23 @@ def snn_chain_numpy(x, kernel, b, a, robust_width, bipolar, nir, W):
     return dict(spikes=spikes.astype(np.int8), power=power, argmax=int(np.argmax(power)))
 
 
+def envelope(y, win_fall, win_rise):
+    """Envelope.evolve (ref:micloc/utils.py:36-81) restated: state_0 = |y_0|; per step `rise = |y_t| >= state`,
+    `state = (1 - 1/w) * state + 1/w * |y_t| * rise` with w = win_rise if rise else win_fall, in NumPy's order of operations;
+    out[t] = state after sample t.  y [T, G] -> [T, G].  Checker of micloc_envelope_track_f64 (tests only)."""
+    mag = np.abs(np.asarray(y, dtype=np.float64))
+    wl = np.asarray([int(win_fall), int(win_rise)])
+    state = mag[0].copy()
+    out = np.empty_like(mag)
+    out[0] = state
+    for t in range(1, len(mag)):
+        rise = (mag[t] >= state).astype(int)
+        w = wl[rise]
+        state = (1 - 1 / w) * state + 1 / w * mag[t] * rise
+        out[t] = state
+    return out
+
+
 def snn_chain_batch_parallel(x, kernel, b, a, robust_width, bipolar, nir, W, threads):
     """snn_chain_batch with the trials split over `threads` host threads (the C call releases the GIL): the
     trial-parallel leg of bench.py's cpu_baseline (target_snn_localization.py:447-467 has no cross-trial state)."""

@@ -929,6 +929,68 @@ def gen_live_demo_frame():
          doa_index=np.int64(k), doa_deg=np.float64(doa_list[k] * 180 / np.pi), true_doa=np.float64(2.1))
 
 
+def moving_target_synthetic(seed, T, G):
+    """A beamformer-output stand-in the tests rebuild bit for bit from the seed (legacy MT19937 normals, products and comparisons
+    only -- no libm): bursts over a quiet floor, a block of exact zeros (|y| == state ties), a dead column."""
+    rng = np.random.RandomState(seed)
+    y = rng.randn(T, G) * (0.2 + (np.arange(T)[:, None] % 1500 < 400) * 2.0)
+    y[100:140] = 0.0
+    y[:, 7] = 0.0
+    return y
+
+
+def gen_moving_target():
+    """micloc/utils.py:36-81 (Envelope.evolve) and the moving-target experiment of paper_plots/target_snn_localization.py:585-622:
+    (a) the reference class on seeded inputs (three window settings incl. a one-sample rise window): SHA-256 of the envelope array,
+    sampled columns, the last row, the per-step arg-max; (b) a moving-DoA trial (chirp, doa(t) = pi/2 sin(pi t / 2 d), 0.5 s instead of
+    the script's 5 s, quantised like a 16-bit converter) through the reference's apply_to_signal -> Envelope -> argmax."""
+    import hashlib
+
+    out = {}
+    for k, (seed, T, G, rise, fall, fs) in enumerate([(11, 6000, 449, 10e-3, 100e-3, 48_000), (12, 3000, 130, 1e-3, 5e-3, 1_000), (13, 2000, 64, 2e-3, 2e-3, 8_000)]):
+        y = moving_target_synthetic(seed, T, G)
+        env = quiet(Envelope(rise_time=rise, fall_time=fall, fs=fs).evolve, y)
+        cols = np.asarray([0, 7, G // 3, G - 1])
+        out.update({f"syn{k}_params": np.asarray([seed, T, G, rise, fall, fs], dtype=np.float64), f"syn{k}_cols": cols, f"syn{k}_env_cols": env[:, cols],
+                    f"syn{k}_env_last": env[-1], f"syn{k}_index": np.argmax(env, axis=1).astype(np.int16),
+                    f"syn{k}_env_sha256": np.frombuffer(hashlib.sha256(np.ascontiguousarray(env).tobytes()).digest(), dtype=np.uint8)})
+    beamf, geometry, fs, fd, fr = cfg2_beamformer(True)
+    bfz = np.load(os.path.join(OUT, "bf_mat_chirp449_bipolar.npz"))
+    bf_mat, doa_list = bfz["bf_mat"], bfz["doa_list"]
+    duration = 500e-3
+    time_test = np.arange(0, duration, step=1 / fs)
+    period = time_test[-1]
+    freq_inst = fr[0] + (fr[1] - fr[0]) * (time_test % period) / period
+    sig_test = np.sin(2 * np.pi * np.cumsum(freq_inst) * 1 / fs)
+    doa_test = 0.5 * np.pi * np.sin(0.5 * np.pi / duration * time_test)  # :596-598
+    cap = {}
+    orig = beamf.apply_to_signal
+
+    def spy(bf_mat, sig_in_vec):
+        cap["time"] = np.array(sig_in_vec[0], copy=True)
+        cap["sig"] = np.array(sig_in_vec[1], copy=True)
+        return np.zeros((1, 1))
+
+    beamf.apply_to_signal = spy
+    try:
+        np.random.seed(21)
+        snr_db = 20.0 - 10 * np.log10(24.0)
+        quiet(beamf.apply_to_template, bf_mat=bf_mat, template=(time_test, sig_test, doa_test), snr_db=snr_db)
+    finally:
+        beamf.apply_to_signal = orig
+    q = np.clip(np.round(cap["sig"] * 4096.0), -32768, 32767).astype(np.int16)  # a 16-bit converter: steps of 2^-12
+    sig_q = q.astype(np.float64) / 4096.0
+    sig_bf = quiet(beamf.apply_to_signal, bf_mat=bf_mat, sig_in_vec=(cap["time"], sig_q))
+    env = quiet(Envelope(rise_time=10e-3, fall_time=100e-3, fs=fs).evolve, sig_bf)
+    index = np.argmax(env, axis=1)
+    top2 = np.partition(env, -2, axis=1)[:, -2:]
+    margin = (top2[:, 1] - top2[:, 0]) / np.maximum(top2[:, 1], 1e-300)
+    out.update(trial_sig_q=q, trial_time=cap["time"], trial_doa=doa_test, trial_index=index.astype(np.int16), trial_margin=margin.astype(np.float32),
+               trial_env_last=env[-1], trial_env_cols=env[:, [0, 224, 448]], trial_y_rows=sig_bf[[0, 1, 5000, 23998]], trial_rows=np.asarray([0, 1, 5000, 23998]),
+               trial_doa_est_deg_rms=np.asarray(np.sqrt(np.mean((doa_list[index] - doa_test[: len(index)]) ** 2)) * 180 / np.pi))
+    save("moving_target.npz", **out)
+
+
 GENS = {
     "kat_init": gen_kat_init,
     "bf_mat_chirp": gen_bf_mat_chirp,
@@ -951,6 +1013,7 @@ GENS = {
     "design_other_geometries": gen_design_other_geometries,
     "beamformer_sweep": gen_beamformer_sweep,
     "live_demo_frame": gen_live_demo_frame,
+    "moving_target": gen_moving_target,
 }
 
 if __name__ == "__main__":

@@ -274,7 +274,7 @@ def test_chunked_random_configurations_vs_oracle(torch, seed):
         T = int(rng.choice([700, 1500, 3001, 12000, 50000], p=[0.3, 0.3, 0.3, 0.07, 0.03]))
         B = 1 if T > 5000 else int(rng.choice([1, 3, 6]))
     lo = 16 * (-(-w // 16) + 1)
-    chunk = int(rng.choice([lo, 96, 160, 400, 1008] + ([4096] if T > 5000 else [])))
+    chunk = int(rng.choice([c for c in [lo, 96, 160, 400, 1008] if c <= T // 2] + ([4096] if T > 5000 else [])))  # (at least two chunks)
     chunk = max(chunk, lo)
     t = np.arange(T)[None, :, None]
     kind = seed % 4

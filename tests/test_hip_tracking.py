@@ -1,0 +1,98 @@
+"""Moving-target tracking on the device: `micloc_envelope_track_f64` = Envelope.evolve
+(ref:micloc/utils.py:36-81) over the T x G beamformer output + the per-time-step arg-max of
+ref:paper_plots/target_snn_localization.py:599-622, against the reference's own class on seeded inputs (bit for bit) and on a
+moving-DoA trial run by the reference (tests/golden/moving_target.npz)."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from conftest import golden
+from oracle import oracle as O
+from test_oracle_golden import _moving_target_synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch
+
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch
+
+
+@pytest.mark.parametrize("k", [0, 1, 2])
+def test_device_envelope_is_the_reference_class_bit_for_bit(torch, k):
+    from haghighatshoarmuir2024_amd.utils import Envelope
+
+    z = golden("moving_target.npz")
+    seed, T, G, rise, fall, fs = z[f"syn{k}_params"]
+    y = _moving_target_synthetic(int(seed), int(T), int(G))
+    e = Envelope(rise_time=rise, fall_time=fall, fs=fs)
+    yd = torch.from_numpy(y).cuda()
+    env = e.evolve(yd)  # a device tensor in: the kernel, a device tensor out
+    assert env.is_cuda and env.shape == yd.shape
+    got = env.cpu().numpy()
+    assert hashlib.sha256(np.ascontiguousarray(got).tobytes()).digest() == bytes(z[f"syn{k}_env_sha256"])  # all T x G values
+    np.testing.assert_array_equal(got[:, z[f"syn{k}_cols"]], z[f"syn{k}_env_cols"])
+    idx, env2 = e.track(yd, want_envelope=True)
+    assert idx.dtype == torch.int32 and idx.shape == (int(T),) and torch.equal(env2, env)
+    np.testing.assert_array_equal(idx.cpu().numpy(), z[f"syn{k}_index"])
+    # a batch: trials are independent chains; ragged shapes (T not a multiple of the 32-row prefetch, G not a multiple of 64)
+    yb = np.stack([y[: int(T) - 7, : int(G) - 3], -y[7:, 3:], y[3 : int(T) - 4, 1 : int(G) - 2] * 0.5])
+    ib, eb = e.track(torch.from_numpy(yb).cuda(), want_envelope=True)
+    for b in range(3):
+        want = O.envelope(yb[b], e.win_lens[0], e.win_lens[1])
+        np.testing.assert_array_equal(eb[b].cpu().numpy(), want)
+        np.testing.assert_array_equal(ib[b].cpu().numpy(), np.argmax(want, axis=1))
+
+
+def test_short_recordings_and_argument_checks(torch):
+    from haghighatshoarmuir2024_amd import runtime
+    from haghighatshoarmuir2024_amd.utils import Envelope
+
+    e = Envelope(rise_time=10e-3, fall_time=100e-3, fs=48_000)
+    rng = np.random.RandomState(0)
+    for T, G in ((1, 5), (2, 64), (31, 65), (32, 1), (33, 449), (65, 1440)):
+        y = rng.randn(T, G)
+        import warnings
+
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")  # (the reference's own "more channels than samples" warning)
+            idx, env = e.track(torch.from_numpy(y).cuda(), want_envelope=True)
+        want = O.envelope(y, e.win_lens[0], e.win_lens[1])
+        np.testing.assert_array_equal(env.cpu().numpy(), want, err_msg=f"T={T} G={G}")
+        np.testing.assert_array_equal(idx.cpu().numpy(), np.argmax(want, axis=1))
+    with pytest.raises(ValueError):
+        runtime.envelope_track(torch.zeros((4, 4), dtype=torch.float32, device="cuda"), 10, 5)
+    with pytest.raises(ValueError):
+        runtime.envelope_track(torch.zeros((4, 4), dtype=torch.float64, device="cuda"), 0, 5)  # int(fs * time) == 0: no window
+
+
+def test_moving_target_trial_against_the_reference(cfg2, torch):
+    """The experiment of ref:paper_plots/target_snn_localization.py:585-622 (0.5 s of it): a chirp whose DoA moves, through
+    apply_to_signal with the T x G result LEFT ON THE DEVICE, Envelope.track there -- only T int32 indices come back.  The reference ran
+    the same quantised recording: its rows of y to 1e-12, its envelope columns to 1e-11 (the recurrence carries y's 1e-13 differences),
+    its DoA index for every time step whose two best envelopes are not tied to rounding."""
+    from micloc.array_geometry import CenterCircularArray
+    from micloc.snn_beamformer import SNNBeamformer
+    from micloc.utils import Envelope
+
+    z = golden("moving_target.npz")
+    tau = 1 / (2 * np.pi * 2000)
+    bf = SNNBeamformer(CenterCircularArray(4.5e-2, 7), 10e-3, [1000.0, 2000.0], np.asarray([tau, tau]), bipolar_spikes=True, fs=48_000)
+    sig = z["trial_sig_q"].astype(np.float64) / 4096.0
+    y = bf.apply_to_signal(cfg2["bf_mat"], (z["trial_time"], sig), to_host=False)
+    assert y.is_cuda and tuple(y.shape) == (sig.shape[0], 449)
+    np.testing.assert_allclose(y[torch.from_numpy(z["trial_rows"]).cuda()].cpu().numpy(), z["trial_y_rows"], rtol=0, atol=1e-12)
+    env = Envelope(rise_time=10e-3, fall_time=100e-3, fs=48_000)
+    idx, e = env.track(y, want_envelope=True)
+    assert idx.is_cuda and idx.shape == (sig.shape[0],)
+    np.testing.assert_allclose(e[:, [0, 224, 448]].cpu().numpy(), z["trial_env_cols"], rtol=1e-9, atol=1e-13)
+    np.testing.assert_allclose(e[-1].cpu().numpy(), z["trial_env_last"], rtol=1e-9, atol=1e-13)
+    clear = z["trial_margin"] > 1e-7
+    assert clear.mean() > 0.99
+    np.testing.assert_array_equal(idx.cpu().numpy()[clear], z["trial_index"][clear])
+    # and the host route an unchanged script takes gives the same indices from the same y
+    np.testing.assert_array_equal(env.track(y.cpu().numpy()), idx.cpu().numpy())

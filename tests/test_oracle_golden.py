@@ -380,3 +380,34 @@ def test_live_demo_frame():
         power = power + out["power"]
     np.testing.assert_allclose(power, z["power_grid"], rtol=1e-10, atol=0)
     assert int(np.argmax(power)) == int(z["doa_index"])
+
+
+def _moving_target_synthetic(seed, T, G):
+    """tests/golden/make_golden.py::moving_target_synthetic, rebuilt from the seed (legacy MT19937 normals, no libm)."""
+    rng = np.random.RandomState(seed)
+    y = rng.randn(T, G) * (0.2 + (np.arange(T)[:, None] % 1500 < 400) * 2.0)
+    y[100:140] = 0.0
+    y[:, 7] = 0.0
+    return y
+
+
+@pytest.mark.parametrize("k", [0, 1, 2])
+def test_envelope_restatement_and_host_class_equal_the_reference(k):
+    """Envelope.evolve (ref:micloc/utils.py:36-81) on the seeded inputs of moving_target.npz: the oracle restatement and the package's
+    host class reproduce the reference's array BIT FOR BIT (SHA-256 of all T x G values), its per-step arg-max and its sampled columns
+    -- incl. a one-sample rise window (1 - 1/1 = 0) and equal rise / fall windows."""
+    import hashlib
+
+    from haghighatshoarmuir2024_amd.utils import Envelope
+
+    z = golden("moving_target.npz")
+    seed, T, G, rise, fall, fs = z[f"syn{k}_params"]
+    y = _moving_target_synthetic(int(seed), int(T), int(G))
+    e = Envelope(rise_time=rise, fall_time=fall, fs=fs)
+    want_sha = bytes(z[f"syn{k}_env_sha256"])
+    for env in (O.envelope(y, e.win_lens[0], e.win_lens[1]), e.evolve(y)):
+        assert hashlib.sha256(np.ascontiguousarray(env).tobytes()).digest() == want_sha
+        np.testing.assert_array_equal(env[:, z[f"syn{k}_cols"]], z[f"syn{k}_env_cols"])
+        np.testing.assert_array_equal(env[-1], z[f"syn{k}_env_last"])
+        np.testing.assert_array_equal(np.argmax(env, axis=1), z[f"syn{k}_index"])
+    np.testing.assert_array_equal(e.track(y), z[f"syn{k}_index"])
