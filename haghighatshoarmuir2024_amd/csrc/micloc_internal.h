@@ -14,6 +14,7 @@ namespace micloc {
 // tests/test_hip_parity.py::test_stht_vector_form_still_exact); results are identical in every variant.
 constexpr bool VARIANT_WS_FOUR_KSTEPS = false;    // ws_k4: beamform_ws_kernel multiplies four k-steps whatever the channel count
 constexpr bool VARIANT_STHT_VECTOR_FORM = false;  // stht_valu: stride-2 STHT kernels on the vector ALU instead of the matrix cores
+constexpr bool VARIANT_STHT_WIDE_TWO_TILES = false;  // stht_wide2: the 480-tap walking STHT (96 kHz) with two time tiles per wave and ONE workgroup per CU (98 KB) instead of one tile / two workgroups
 constexpr bool VARIANT_STHT_ONE_TILE = false;     // stht_one_tile: the matrix-core STHT with one time tile per workgroup (round 3's form) instead of the walk
 
 // ---- XCD-aware workgroup order (speed only, never correctness) -------------------------------------------------------

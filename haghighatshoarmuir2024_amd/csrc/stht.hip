@@ -678,7 +678,8 @@ hipError_t launch_stht(const SthtTaps &tp, const double *x, double *h, int B, in
         const int J = tp.ngroups * (STHT_R / tp.kstep);  // compact taps incl. the zero padding of the last group
         const int NK = (J + 15 + 3) / 4;
         // two workgroups per CU if the tile allows it
-        const int ntw = stht_mfma_lds(J, 2) <= 80 * 1024 ? 2 : (stht_mfma_lds(J, 1) <= 80 * 1024 ? 1 : (stht_mfma_lds(J, 2) <= 160 * 1024 ? 2 : (stht_mfma_lds(J, 1) <= 160 * 1024 ? 1 : 0)));
+        const int ntw = (VARIANT_STHT_WIDE_TWO_TILES && stht_mfma_lds(J, 2) > 80 * 1024 && stht_mfma_lds(J, 2) <= 160 * 1024) ? 2 :
+                        stht_mfma_lds(J, 2) <= 80 * 1024 ? 2 : (stht_mfma_lds(J, 1) <= 80 * 1024 ? 1 : (stht_mfma_lds(J, 2) <= 160 * 1024 ? 2 : (stht_mfma_lds(J, 1) <= 160 * 1024 ? 1 : 0)));
         if (ntw) {
             const int TI = SM_WAVES * ntw * 16;
             const int nstreams = B * M;

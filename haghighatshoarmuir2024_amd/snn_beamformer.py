@@ -141,7 +141,9 @@ class SNNBeamformer:
         # same draw from the global legacy stream as the reference (:270-275)
         noise = np.sqrt(np.mean(sig_in_vec**2)) / np.sqrt(snr) * np.random.randn(*sig_in_vec.shape)
         sig_in_vec += noise
-        return self.apply_to_signal(bf_mat=bf_mat, sig_in_vec=(time_in, sig_in_vec), to_host=to_host)
+        if to_host:  # (the reference's own call, with the reference's signature: an `apply_to_signal` replaced by a caller keeps working)
+            return self.apply_to_signal(bf_mat=bf_mat, sig_in_vec=(time_in, sig_in_vec))
+        return self.apply_to_signal(bf_mat=bf_mat, sig_in_vec=(time_in, sig_in_vec), to_host=False)
 
     def synthesize_batch(self, template, doas, device_delays=False):
         """Noise-free array signals for a batch of trials, synthesised on the device (synthesis.apply_to_template_batch).

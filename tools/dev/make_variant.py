@@ -4,6 +4,7 @@
     python tools/dev/make_variant.py stht_valu      stride-2 STHT kernels on the vector ALU (VARIANT_STHT_VECTOR_FORM)
     python tools/dev/make_variant.py ws_k4          beamform_ws_kernel with four k-steps whatever the channel count (VARIANT_WS_FOUR_KSTEPS)
     python tools/dev/make_variant.py stht_one_tile  the matrix-core STHT with one time tile per workgroup instead of the walk (VARIANT_STHT_ONE_TILE)
+    python tools/dev/make_variant.py stht_wide2     the 480-tap walking STHT with two time tiles per wave, one workgroup per CU (VARIANT_STHT_WIDE_TWO_TILES)
     python tools/dev/make_variant.py ws_sparse_lif  beamform_ws_kernel's LIF stage event by event on the vector ALU instead of the dense Toeplitz product
                                                     (round 5's rejected experiment: NOT in the product sources -- tools/experiments/ws_sparse_lif/ws_sparse_lif.patch
                                                     is applied to a copy of csrc/beamform.hip)
@@ -20,7 +21,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 CS = os.path.join(ROOT, "haghighatshoarmuir2024_amd", "csrc")
-VARIANTS = {"stht_valu": ("VARIANT_STHT_VECTOR_FORM", "stht"), "ws_k4": ("VARIANT_WS_FOUR_KSTEPS", "beamform"), "stht_one_tile": ("VARIANT_STHT_ONE_TILE", "stht"),
+VARIANTS = {"stht_wide2": ("VARIANT_STHT_WIDE_TWO_TILES", "stht"), "stht_valu": ("VARIANT_STHT_VECTOR_FORM", "stht"), "ws_k4": ("VARIANT_WS_FOUR_KSTEPS", "beamform"), "stht_one_tile": ("VARIANT_STHT_ONE_TILE", "stht"),
             "ws_sparse_lif": (os.path.join(ROOT, "tools", "experiments", "ws_sparse_lif", "ws_sparse_lif.patch"), "beamform")}
 FLAGS = "-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -Wall -Wno-unused-result".split()
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
