@@ -452,15 +452,24 @@ __global__ __launch_bounds__(SM_THREADS, 4) void stht_walk_kernel(const double *
     const int irel = wv * NTW * 16;
     auto multiply = [&](double4_t *acc, int lq, int llc) {  // (lane coordinates passed in: see the opaque move in the tile loop)
         constexpr int GK = 2;
-        const double *ap0 = XS + (size_t)(irel + 4 * NK - 1 - lq) * 16 + llc;
+        // (the index of the LOWEST operand row passes through an opaque move: the compiler otherwise re-bases every read on the newest
+        //  row and the immediate offsets become negative, i.e. one vector add per read)
+        int aoff = (irel + 4 * NK - 1 - lq) * 16 + llc - 64 * ((NKT ? NKT : 1) - 1);
+        if (NKT) asm volatile("" : "+v"(aoff));
+        const double *alo = XS + aoff;
+        const double *ap0 = alo + 64 * ((NKT ? NKT : 1) - 1);
         const double *bp0 = G + llc + lq;
+        // (compile-time trip count: the operand rows are addressed upwards from the LOWEST one -- LDS instructions take unsigned
+        //  immediate offsets only, and a pointer that walks down from the newest row cost one vector add per read: 1.3 vector
+        //  instructions per matrix instruction in the 124-k-step form, every one of them an interruption of the matrix pipe)
         auto fetch = [&](int g, double (&av)[GK][NTW], double (&bv)[GK]) {
             const double *pa = ap0 - (size_t)(64 * GK) * (g + 1), *pb = bp0 + 4 * GK * g;
 #pragma unroll
             for (int u = 0; u < GK; ++u) {
                 bv[u] = pb[4 * u];
 #pragma unroll
-                for (int tt = 0; tt < NTW; ++tt) av[u][tt] = pa[(GK - u) * 64 + tt * 256];
+                for (int tt = 0; tt < NTW; ++tt)
+                    av[u][tt] = NKT ? alo[64 * (NKT - 1 - (GK * g + u)) + tt * 256] : pa[(GK - u) * 64 + tt * 256];
             }
         };
         auto mult = [&](const double (&av)[GK][NTW], const double (&bv)[GK]) {
@@ -699,7 +708,7 @@ hipError_t launch_stht(const SthtTaps &tp, const double *x, double *h, int B, in
                 // the slide copies the halo through registers, NCP 16-byte pairs per thread: every pair needs a thread
                 if ((4 * NK - 16) * 8 > (wide ? 8 : 4) * SM_THREADS) return hipErrorInvalidValue;
                 auto kw = ntw == 2 ? (NK == 64 ? &stht_walk_kernel<2, 64, 4> : (wide ? &stht_walk_kernel<2, 0, 8> : &stht_walk_kernel<2, 0, 4>))
-                                   : (wide ? &stht_walk_kernel<1, 0, 8> : &stht_walk_kernel<1, 0, 4>);
+                                   : (wide ? (NK == 124 ? &stht_walk_kernel<1, 124, 8> : &stht_walk_kernel<1, 0, 8>) : &stht_walk_kernel<1, 0, 4>);
                 hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kw), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 if (e != hipSuccess) return e;
                 hipLaunchKernelGGL(kw, dim3((ntile + tpw - 1) / tpw, ngrp8), dim3(SM_THREADS), lds, stream, x, h, tp.taps, J, tp.klo, NK, T, M,
