@@ -68,3 +68,36 @@ def test_every_profile_file_is_tied_to_a_commit(mpath):
             for rel, h in e["sources_sha256"].items():
                 blob = subprocess.run(["git", "-C", ROOT, "show", f"{e['git_sha']}:{rel}"], stdout=subprocess.PIPE).stdout
                 assert hashlib.sha256(blob).hexdigest() == h, (f, rel)
+
+
+HOT_SOURCES = tuple(f"haghighatshoarmuir2024_amd/csrc/{f}" for f in ("beamform.hip", "stht.hip", "rzcc.hip"))
+
+
+def _round_of(mpath):
+    name = os.path.basename(os.path.dirname(mpath))
+    return int("".join(c for c in name if c.isdigit()) or 0)
+
+
+def test_newest_profiles_belong_to_the_kernels_in_the_tree():
+    """From round 6 on: the NEWEST round's committed profiles were taken on exactly the hot-path kernel sources of the
+    working tree -- csrc/beamform.hip, stht.hip, rzcc.hip hash to what every entry of that round's MANIFEST recorded on the GPU box.
+    Touching one of them after the profiles were taken fails this test until the profiles are re-taken (tools/profile_round.sh).
+    Consequence checked too: bench.py's committed fallback for `roofline.traffic` accepts the newest pmc_summary.csv."""
+    import sys
+
+    ms = [m for m in _manifests() if _round_of(m) >= 6]
+    if not ms:
+        pytest.skip("no manifest of round 6 or later yet")
+    mpath = max(ms, key=_round_of)
+    man = json.load(open(mpath))
+    now = {rel: hashlib.sha256(open(os.path.join(ROOT, rel), "rb").read()).hexdigest() for rel in HOT_SOURCES}
+    stale = sorted({(f, rel) for f, e in man["files"].items() for rel in HOT_SOURCES if e["sources_sha256"].get(rel) != now[rel]})
+    assert not stale, f"{os.path.relpath(mpath, ROOT)}: taken on other kernel sources than the tree's: {stale[:6]}"
+    sys.path.insert(0, ROOT)
+    import bench
+
+    rel = os.path.relpath(os.path.join(os.path.dirname(mpath), "pmc_summary.csv"), ROOT)
+    ent = bench.manifest_entry(rel)
+    assert ent and ent["sources_sha256"]["haghighatshoarmuir2024_amd/csrc/beamform.hip"] == bench.source_sha256("haghighatshoarmuir2024_amd/csrc/beamform.hip")
+    t, src = bench.traffic_from_profiles("beamform_ws_kernel", -(-4799 // 256) * 512 * 1100)
+    assert src == rel and t and 1.0e8 < t < 2.0e8  # 2 x FETCH_SIZE + WRITE_SIZE of the headline's launch: about 136 MB

@@ -1,9 +1,9 @@
 #!/bin/bash
 # Round profiling recipe (run on the GPU box from the repo root: gpurun -- 'bash tools/profile_round.sh r4').
 # Writes raw rocprofv3 output and bench JSONs under gpurun_out/<tag>/; copy the summaries into profiles/<tag>/.
-# usage: bash tools/profile_round.sh <tag> [bench|pmc|all]   (two gpurun calls of <= 20 minutes: `bench`, then `pmc`)
+# usage: bash tools/profile_round.sh <tag> [bench|extra|pmc|all]   (three gpurun calls of <= 20 minutes: `bench`, `extra`, `pmc`)
 set -u
-TAG=${1:-r5}
+TAG=${1:-r6}
 PART=${2:-all}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
@@ -13,6 +13,7 @@ export TMPDIR=/tmp
 python3 tools/make_manifest.py --record $OUT
 cmd() { printf '%s\t%s\n' "$1" "$2" >> $OUT/COMMANDS.tsv; }
 : > $OUT/COMMANDS.tsv
+want() { [ $PART = all ] || [ $PART = $1 ]; }
 cmd bench_n1.json "python3 bench.py --steps 20 --warmup 5"
 cmd bench_n1_streams1.json "python3 bench.py --steps 40 --warmup 4 --streams 1 --no-cpu-baseline --no-other-configs"
 cmd bench_n1_grid449.json "python3 bench.py --steps 40 --warmup 4 --grid 449 --no-cpu-baseline --no-other-configs"
@@ -40,8 +41,13 @@ cmd product_sweeps.txt "python3 tools/dev/speech_sweep_time.py 91; python3 tools
 cmd speech_lanes.txt "bash tools/dev/speech_lanes.sh 2 4"
 cmd stht_fetch.txt "bash tools/dev/stht_fetch_ab.sh; STHT_T=48000 bash tools/dev/stht_fetch_ab.sh"
 cmd clock_sources.txt "python3 tools/dev/clock_sources.py"
+cmd bench_n2_share_device.json "python3 bench.py --gpus 2 --share-device --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs  (REHEARSAL of the N > 1 launch: both ranks on device 0, gloo)"
+cmd bench_share_stress2048.json "python3 bench.py --config stress --baseline-total --trials 2048 --steps 6 --warmup 2 --repeats 3 --sustained-seconds 10 --no-cpu-baseline --no-other-configs  (a rank's share of the 16 384-trial sweep at 8 ranks)"
+cmd bench_share_speech125.json "python3 bench.py --config speech --baseline-total --trials 125 --steps 16 --warmup 4 --repeats 3 --sustained-seconds 10 --no-cpu-baseline --no-other-configs  (a rank's share of the 1000-trial sweep at 8 ranks)"
+cmd ablation_stht_wide2.txt "bash tools/dev/ab_stress_stht.sh"
+cmd track_time.txt "python3 tools/dev/track_time.py"
 for c in "" _stress _speech _xylo; do cmd pmc_summary$c.csv "rocprofv3 --kernel-trace --pmc <FETCH_SIZE | WRITE_SIZE | SQ_* ...> (one pass each) -- python3 bench.py --config <cfg> --steps <n> --warmup 1 --repeats 1 --no-cpu-baseline --no-other-configs --streams 1 --sustained-seconds 0 | summarize_profiles.py pmc"; done
-if [ $PART != pmc ]; then
+if want bench; then
 python3 bench.py --steps 20 --warmup 5 > $OUT/bench_n1.json 2> $OUT/bench_n1.err   # the driver's command: all blocks (other configs as child runs)
 python3 bench.py --steps 40 --warmup 4 --streams 1 --no-cpu-baseline --no-other-configs > $OUT/bench_n1_streams1.json 2> $OUT/bench_n1_streams1.err
 python3 bench.py --steps 40 --warmup 4 --grid 449 --no-cpu-baseline --no-other-configs > $OUT/bench_n1_grid449.json 2> $OUT/bench_n1_grid449.err
@@ -58,6 +64,15 @@ rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace_g449 -o run -
 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace_speech -o run -- python3 bench.py --config speech --steps 3 --warmup 1 --streams 1 --sustained-seconds 0 --no-cpu-baseline --no-other-configs > $OUT/trace_speech.log 2>&1
 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace_stress -o run -- python3 bench.py --config stress --steps 3 --warmup 1 --streams 1 --sustained-seconds 0 --no-cpu-baseline --no-other-configs > $OUT/trace_stress.log 2>&1
 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace_xylo -o run -- python3 bench.py --config xylo --steps 2 --warmup 1 --streams 1 --sustained-seconds 0 --no-cpu-baseline --no-other-configs > $OUT/trace_xylo.log 2>&1
+python3 tools/summarize_profiles.py trace $OUT/trace $OUT/kernel_trace_summary_by_shape.csv
+python3 tools/summarize_profiles.py trace $OUT/trace_g449 $OUT/kernel_trace_summary_grid449.csv
+python3 tools/summarize_profiles.py trace $OUT/trace_speech $OUT/kernel_trace_summary_speech.csv
+python3 tools/summarize_profiles.py trace $OUT/trace_stress $OUT/kernel_trace_summary_stress.csv
+python3 tools/summarize_profiles.py trace $OUT/trace_xylo $OUT/kernel_trace_summary_xylo.csv
+find $OUT/trace -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats_bench_steps40_streams1.csv \;
+rm -rf $OUT/trace $OUT/trace_g449 $OUT/trace_speech $OUT/trace_stress $OUT/trace_xylo
+fi
+if want extra; then
 # API-faithful mode (y stored) and the store-pattern microbenchmark behind its design
 (python3 tools/k3_time.py 360 1100 1; python3 tools/k3_time.py 449 1100 1; python3 tools/k3_time.py 360 1100 0; python3 tools/k3_time.py 449 1100 0) > $OUT/y_store.txt 2>/dev/null
 hipcc -O3 --offload-arch=gfx950 -o /tmp/store_bw tools/store_bw.hip > /dev/null 2>&1 && /tmp/store_bw > $OUT/store_bw.txt 2>&1
@@ -71,6 +86,13 @@ bash tools/dev/ab_lib.sh tools/_variants/libmicloc_hip_stht_one_tile.so "--steps
 #   ws_sparse_lif  beamform_ws_kernel's LIF stage event by event (round 5) instead of the dense product; the stage alone, checksums of the power
 bash tools/dev/ab_bf.sh default tools/_variants/libmicloc_hip_ws_sparse_lif.so > $OUT/ablation_sparse_lif.txt 2>&1
 python3 tools/dev/clock_sources.py > $OUT/clock_sources.txt 2>&1
+# round 6: the N > 1 launch rehearsed on this one GPU, the strong-scaling shares an 8-rank run gives every rank, the rejected two-tile form of
+# the 480-tap STHT, the moving-target read-out at the script's shape
+python3 bench.py --gpus 2 --share-device --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs > $OUT/bench_n2_share_device.json 2> $OUT/bench_n2_share_device.err
+python3 bench.py --config stress --baseline-total --trials 2048 --steps 6 --warmup 2 --repeats 3 --sustained-seconds 10 --no-cpu-baseline --no-other-configs > $OUT/bench_share_stress2048.json 2> $OUT/bench_share_stress2048.err
+python3 bench.py --config speech --baseline-total --trials 125 --steps 16 --warmup 4 --repeats 3 --sustained-seconds 10 --no-cpu-baseline --no-other-configs > $OUT/bench_share_speech125.json 2> $OUT/bench_share_speech125.err
+bash tools/dev/ab_stress_stht.sh 2>&1 | grep -v amdgpu.ids > $OUT/ablation_stht_wide2.txt
+python3 tools/dev/track_time.py 2>&1 | grep -v amdgpu.ids > $OUT/track_time.txt
 # round 4: the complex Beamformer's contraction alone, the Xylo LIF launch forms, config 5's design
 (python3 tools/c128_time.py 360 1100 0; python3 tools/c128_time.py 449 1100 0; python3 tools/c128_time.py 360 1100 1; python3 tools/c128_time.py 57 1100 1) > $OUT/c128_time.txt 2>/dev/null
 python3 tools/dev/design_cfg5_time.py 48 240 > $OUT/design_config5.txt 2>/dev/null
@@ -79,15 +101,8 @@ python3 tools/dev/design_cfg5_time.py 48 240 > $OUT/design_config5.txt 2>/dev/nu
 (python3 tools/dev/speech_sweep_time.py 91; python3 tools/dev/xylo_sweep_time.py) 2>/dev/null | grep -v amdgpu.ids > $OUT/product_sweeps.txt
 bash tools/dev/speech_lanes.sh 2 4 > $OUT/speech_lanes.txt 2>&1
 (bash tools/dev/stht_fetch_ab.sh; STHT_T=48000 bash tools/dev/stht_fetch_ab.sh) 2>/dev/null | grep -v amdgpu.ids > $OUT/stht_fetch.txt
-python3 tools/summarize_profiles.py trace $OUT/trace $OUT/kernel_trace_summary_by_shape.csv
-python3 tools/summarize_profiles.py trace $OUT/trace_g449 $OUT/kernel_trace_summary_grid449.csv
-python3 tools/summarize_profiles.py trace $OUT/trace_speech $OUT/kernel_trace_summary_speech.csv
-python3 tools/summarize_profiles.py trace $OUT/trace_stress $OUT/kernel_trace_summary_stress.csv
-python3 tools/summarize_profiles.py trace $OUT/trace_xylo $OUT/kernel_trace_summary_xylo.csv
-find $OUT/trace -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats_bench_steps40_streams1.csv \;
-rm -rf $OUT/trace $OUT/trace_g449 $OUT/trace_speech $OUT/trace_stress $OUT/trace_xylo
 fi
-if [ $PART != bench ]; then
+if want pmc; then
 # counters: separate passes, nothing but --pmc (+ kernel trace)
 for cfg in noisy stress speech xylo; do
   steps=6; [ $cfg = speech ] && steps=2; [ $cfg = xylo ] && steps=2
