@@ -52,6 +52,22 @@ __device__ __forceinline__ double row_sum4(double x)
     return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
 }
 
+// The same sums for TWO values at once (the two 16-column tiles of a slab): rows 0 / 1 of the result hold the row sums of a / of b (rows 2 / 3
+// repeat them).  The first exchange pairs a with b instead of a value with a copy of itself, so one add serves both: 2 + 1 + (2 + 2 + 1) = 8
+// vector instructions for two sums instead of 2 x 10 -- and the additions are the ones of row_sum4 in the same pairing, (r0 + r1) + (r2 + r3):
+// the same bits.
+__device__ __forceinline__ double row_sum4_pair(double a, double b)
+{
+    uint2_t lo = __builtin_amdgcn_permlane16_swap(__double2loint(a), __double2loint(b), false, false);
+    uint2_t hi = __builtin_amdgcn_permlane16_swap(__double2hiint(a), __double2hiint(b), false, false);
+    // first operand: rows (a0, b0, a2, b2); second: rows (a1, b1, a3, b3)
+    const double s = __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);  // rows (a0+a1, b0+b1, a2+a3, b2+b3)
+    const unsigned sl = __double2loint(s), sh = __double2hiint(s);
+    lo = __builtin_amdgcn_permlane32_swap(sl, sl, false, false);
+    hi = __builtin_amdgcn_permlane32_swap(sh, sh, false, false);
+    return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
+
 // XCD-aware placement (speed only, never correctness): workgroups are dealt round-robin over the 8 XCDs (4 MB of L2
 // each); consecutive chunks of a trial share the LIF halo rows, so an XCD is given a whole trial at a time and the halo
 // becomes an L2 hit instead of a second HBM fetch.  Grid (nchunks, B), linear id L = chunk + nchunks * b -> XCD L % 8.
@@ -992,25 +1008,40 @@ __global__ __launch_bounds__(BF_THREADS, 4) void beamform_gen_kernel(const int8_
 #pragma unroll
                 for (int tt = 0; tt < NT; ++tt) acc[tt] = double4_t{0.0, 0.0, 0.0, 0.0};
                 if (tb0 < T) {  // wave-uniform
-                    const int8_t *sp = spk + (size_t)(tb0 - cs + q) * Cs + 16 * ct + lc;
-                    const double *np_ = ntab + (lc - q + 4 * NK - 16 + 15);
-                    double bn_n = np_[0];
-                    int an[NT];
+                    // two k-steps per trip, the operands of k-step k + 1 / k + 2 requested in front of the matrix instruction of k-step
+                    // k / k + 1 into the OTHER register set (no copies), both pointers stepping once per trip with non-negative immediate
+                    // offsets: 1 conversion + ~1.5 address instructions per k-step (the one-step loop with its carried copies: 5 -- and
+                    // every vector instruction between two matrix instructions costs the pipe its switch, tools/mfma_valu_overlap.hip).
+                    // The same products in the same order.
+                    const int8_t *sp = spk + (size_t)(tb0 - cs + q) * Cs + 16 * ct + lc;  // row of k-step 0 (walks up, 8 rows per trip)
+                    const double *nq = ntab + (lc - q + 4 * NK - 16 + 15) - 8;            // tap of k-step 2 (walks down, 8 taps per trip)
+                    int a0[NT], a1[NT];
+                    double b0 = nq[8], b1;
 #pragma unroll
-                    for (int tt = 0; tt < NT; ++tt) an[tt] = sp[(size_t)(16 * tt) * Cs];
-                    for (int ks = 0; ks < NK; ++ks) {
-                        const double bn = bn_n;
-                        double a[NT];
+                    for (int tt = 0; tt < NT; ++tt) a0[tt] = sp[(size_t)(16 * tt) * Cs];
+                    int ks = 0;
+                    for (; ks + 2 <= NK; ks += 2) {
+                        b1 = nq[4];
 #pragma unroll
-                        for (int tt = 0; tt < NT; ++tt) a[tt] = (double)an[tt];
-                        if (ks + 1 < NK) {
-                            bn_n = np_[-4 * (ks + 1)];
+                        for (int tt = 0; tt < NT; ++tt) a1[tt] = sp[(size_t)(16 * tt + 4) * Cs];
 #pragma unroll
-                            for (int tt = 0; tt < NT; ++tt) an[tt] = sp[(size_t)(16 * tt + 4 * (ks + 1)) * Cs];
+                        for (int tt = 0; tt < NT; ++tt)
+                            acc[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a0[tt], b0, acc[tt], 0, 0, 0);
+                        if (ks + 2 < NK) {
+                            b0 = nq[0];
+#pragma unroll
+                            for (int tt = 0; tt < NT; ++tt) a0[tt] = sp[(size_t)(16 * tt + 8) * Cs];
                         }
 #pragma unroll
                         for (int tt = 0; tt < NT; ++tt)
-                            acc[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tt], bn, acc[tt], 0, 0, 0);
+                            acc[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a1[tt], b1, acc[tt], 0, 0, 0);
+                        sp += (size_t)8 * Cs;
+                        nq -= 8;
+                    }
+                    if (ks < NK) {  // (an odd number of k-steps: the last one's operands are in set 0)
+#pragma unroll
+                        for (int tt = 0; tt < NT; ++tt)
+                            acc[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a0[tt], b0, acc[tt], 0, 0, 0);
                     }
                 }
 #pragma unroll
@@ -1054,14 +1085,16 @@ __global__ __launch_bounds__(BF_THREADS, 4) void beamform_gen_kernel(const int8_
             const int buf = sl & 1;
             const double *sbuf = buf ? U : slab0;
             if (sl + 1 < NSL) stage_slab(sl + 1, buf ^ 1);  // in flight behind this slab's MFMAs (the other buffer was released by the last barrier)
+            double sq2[2];
 #pragma unroll
             for (int gl = 0; gl < 2; ++gl) {
                 // one 16-column tile at a time: one accumulator set and one stream of B fragments (both tiles at once cost 16 more
                 // registers than the 128-channel instantiation has: scratch in the slab loop's prologue)
-                double4_t acc[NT];
+                double sq = 0.0;
+                if (tb0 < T) {  // (wave-uniform; a wave beyond the end of the trial contributes nothing and stores nothing)
+                    double4_t acc[NT];
 #pragma unroll
-                for (int tt = 0; tt < NT; ++tt) acc[tt] = double4_t{0.0, 0.0, 0.0, 0.0};
-                if (tb0 < T) {
+                    for (int tt = 0; tt < NT; ++tt) acc[tt] = double4_t{0.0, 0.0, 0.0, 0.0};  // (folds into the first MFMA's zero C operand)
                     // B fragments D k-steps ahead of their MFMAs, the order pinned: left alone the scheduler hoists as many of the
                     // KS reads as the register budget holds -- and at 128 channels (64 VGPRs of membrane fragments) then spills
                     const double *w0 = sbuf + (gl ? (boff0 ^ 16) : boff0);
@@ -1081,8 +1114,6 @@ __global__ __launch_bounds__(BF_THREADS, 4) void beamform_gen_kernel(const int8_
                             acc[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(Vf[tt][k >> 2][k & 3], wk[k], acc[tt], 0, 0, 0);
                         __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);
                     }
-                }
-                double sq = 0.0;
 #pragma unroll
                 for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
@@ -1107,8 +1138,13 @@ __global__ __launch_bounds__(BF_THREADS, 4) void beamform_gen_kernel(const int8_
                         }
                     }
                 }
-                sq = row_sum4(sq);
-                if (l < 16) red[(buf * BF_WAVES + wv) * GEN_COLS + 16 * gl + l] = sq;
+                }
+                sq2[gl] = sq;
+            }
+            {
+                // the column sums of both tiles over the wave's rows in one paired exchange: lanes 0-15 tile 0, lanes 16-31 tile 1
+                const double cs2 = row_sum4_pair(sq2[0], sq2[1]);
+                if (l < GEN_COLS) red[(buf * BF_WAVES + wv) * GEN_COLS + l] = cs2;
             }
             slabs_landed();
             __syncthreads();
