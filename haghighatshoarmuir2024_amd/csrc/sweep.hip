@@ -113,47 +113,107 @@ hipError_t launch_peak_location(const int32_t *rate, int B, int G, int F, int wi
 //   state_t = (1 - 1/w) * state_{t-1} + 1/w * |y_t| * rise_t,   w = rise_t ? int(fs rise_time) : int(fs fall_time);   env[t] = state_t
 // in NumPy's order of operations: two roundings of products, one of the sum, nothing fused (`__dmul_rn` / `__dadd_rn`); with rise_t = 0
 // the second term is +0 and the sum is the first product.  a_* = 1 - 1/w and i_rise = 1/w_rise are computed on the host by NumPy itself.
-// One wave = 64 DoA columns of one trial (a row segment of 512 contiguous bytes per step); the |y| values and the products 1/w |y| of
-// the NEXT 32 rows are requested / computed off the chain while the current 32 are walked: per step the chain is two multiplies side by
+// A lane = one DoA column of one trial (a wave's row segment: 512 contiguous bytes per step); per step the chain is two multiplies side by
 // side, one add, one select.
-constexpr int ENV_U = 32;
+// Round 6, second form: the chain is latency, so the rows must be waiting in LDS when the chain gets to them.  A workgroup = 64 DoA columns
+// of one trial = FOUR waves: wave 0 walks the recurrence, waves 1-3 are loaders that take the 32-row tiles in turn -- a loader requests its
+// tile (one 8-byte load per lane and row: 32 in flight), lets two iterations of the chain pass, writes the tile into a four-slot LDS ring and
+// requests its next one; one barrier per 32 rows, every wave runs the same number of iterations.  Tile k: loads issued in iteration k, LDS
+// write in iteration k + 2, walked in iteration k + 3; slot k % 4 is rewritten in iteration k + 6.  (The first form -- one wave per workgroup,
+// the next 32 rows prefetched into registers while the current 32 are walked -- ran at 73 ns per step on the script's 240 000 x 449 array:
+// a row load's latency is longer than 32 steps of the chain.)
+constexpr int ENV_TILE = 32;
+constexpr int ENV_SLOTS = 4;
+constexpr int ENV_LOADERS = 3;
 
-__global__ __launch_bounds__(64) void envelope_kernel(const double *__restrict__ y, int T, int G, double a_rise, double i_rise, double a_fall,
-                                                      double *__restrict__ env)
+__global__ __launch_bounds__(64 * (1 + ENV_LOADERS)) void envelope_kernel(const double *__restrict__ y, int T, int G, double a_rise, double i_rise,
+                                                                          double a_fall, double *__restrict__ env)
 {
-    const int g = blockIdx.x * 64 + threadIdx.x;
-    if (g >= G) return;
-    const double *p = y + (size_t)blockIdx.y * T * G + g;
-    double *o = env + (size_t)blockIdx.y * T * G + g;
-    double state = fabs(p[0]);
-    o[0] = state;
-    double cur[ENV_U], nxt[ENV_U];
+    extern __shared__ __attribute__((aligned(16))) double env_ring[];  // [ENV_SLOTS][ENV_TILE][64]
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.x * 64 + lane;
+    const bool live = g < G;
+    const double *p = y + (size_t)blockIdx.y * T * G + (live ? g : 0);
+    double *o = env + (size_t)blockIdx.y * T * G + (live ? g : 0);
+    const int nt = (T - 1 + ENV_TILE - 1) / ENV_TILE;  // tiles of rows 1 .. T - 1 (row 0 is the initial state)
+    double state = 0.0;
+    if (wave == 0) {
+        state = live ? fabs(p[0]) : 0.0;
+        if (live) o[0] = state;
+    }
+    // a barrier WITHOUT __syncthreads()'s memory fence: the fence would wait for every outstanding global load and store (vmcnt(0)) -- the
+    // loaders' rows in flight, the chain's 32 stores -- in every iteration; only the LDS traffic has to be complete at the barrier.
+    // The two roles run SEPARATE loops with the same trip count (nt + 3 barriers each): their register sets never meet in a phi.
+    auto tile_barrier = [] {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+    if (wave == 0) {
+        for (int it = 0; it < nt + 3; ++it) {
+            const int k = it - 3;
+            if (k >= 0) {
+                double v[ENV_TILE];
+                const double *slot = env_ring + ((size_t)(k % ENV_SLOTS) * ENV_TILE) * 64 + lane;
 #pragma unroll
-    for (int j = 0; j < ENV_U; ++j) cur[j] = (1 + j < T) ? p[(size_t)(1 + j) * G] : 0.0;
-    for (int t0 = 1; t0 < T; t0 += ENV_U) {
-        const int t1 = t0 + ENV_U;
+                for (int j = 0; j < ENV_TILE; ++j) v[j] = slot[j * 64];
+                const int t0 = 1 + k * ENV_TILE;
+                const int nrow = T - t0 < ENV_TILE ? T - t0 : ENV_TILE;  // (uniform; only a trial's last tile is ragged)
+                // a lone wave issues one instruction of any kind per ~4.4 cycles, so a step costs its instruction COUNT: the lanes beyond
+                // the grid are masked once per tile (not a branch around every store), the row's address is a scalar base that steps by
+                // one row + this lane's 32-bit column offset, and the full tile carries no per-step row test
+                if (live) {
+                    const char *rowbase = reinterpret_cast<const char *>(env + ((size_t)blockIdx.y * T + t0) * G);  // (uniform)
+                    const size_t rowbytes = (size_t)G * sizeof(double);
+                    const unsigned voff = (unsigned)g * (unsigned)sizeof(double);
+                    auto step = [&](int j) {
+                        const double m = fabs(v[j]);
+                        const double up = __dadd_rn(__dmul_rn(a_rise, state), __dmul_rn(i_rise, m));
+                        const double down = __dmul_rn(a_fall, state);
+                        state = (m >= state) ? up : down;
+                        *reinterpret_cast<double *>(const_cast<char *>(rowbase + (size_t)j * rowbytes) + voff) = state;
+                    };
+                    if (nrow == ENV_TILE) {
 #pragma unroll
-        for (int j = 0; j < ENV_U; ++j) nxt[j] = (t1 + j < T) ? p[(size_t)(t1 + j) * G] : 0.0;
-        if (t1 <= T) {
+                        for (int j = 0; j < ENV_TILE; ++j) step(j);  // (compile-time indices: the tile stays in registers)
+                    } else {
 #pragma unroll
-            for (int j = 0; j < ENV_U; ++j) {
-                const double m = fabs(cur[j]);
-                const double up = __dadd_rn(__dmul_rn(a_rise, state), __dmul_rn(i_rise, m));
-                const double down = __dmul_rn(a_fall, state);
-                state = (m >= state) ? up : down;
-                o[(size_t)(t0 + j) * G] = state;
+                        for (int j = 0; j < ENV_TILE; ++j)
+                            if (j < nrow) step(j);
+                    }
+                }
             }
-        } else {
-            for (int j = 0; t0 + j < T; ++j) {
-                const double m = fabs(cur[j]);
-                const double up = __dadd_rn(__dmul_rn(a_rise, state), __dmul_rn(i_rise, m));
-                const double down = __dmul_rn(a_fall, state);
-                state = (m >= state) ? up : down;
-                o[(size_t)(t0 + j) * G] = state;
-            }
+            tile_barrier();
         }
+    } else {
+        // this loader's tiles are k % 3 == wave - 1; an iteration is in exactly ONE of three phases (exclusive branches: the rows requested
+        // two iterations ago stay in the registers they were loaded into -- no copies, no wait before they are written)
+        double v[ENV_TILE];
 #pragma unroll
-        for (int j = 0; j < ENV_U; ++j) cur[j] = nxt[j];
+        for (int j = 0; j < ENV_TILE; ++j) v[j] = 0.0;
+        for (int it = 0; it < nt + 3; ++it) {
+            const int ph = (it + ENV_LOADERS - (wave - 1)) % ENV_LOADERS;
+            if (ph == 0) {
+                if (it < nt) {  // request tile `it`: UNCONDITIONAL loads (a predicated load is a branch around it and a wait for everything
+                    // in flight in front of the zero that replaces it): rows beyond the recording read row T - 1 again, lanes beyond the
+                    // grid read column 0 (`p`) -- valid memory, values nobody uses
+                    const int t0 = 1 + it * ENV_TILE;
+#pragma unroll
+                    for (int j = 0; j < ENV_TILE; ++j) {
+                        const int row = t0 + j < T ? t0 + j : T - 1;  // (uniform)
+                        v[j] = p[(size_t)row * G];
+                    }
+                }
+            } else if (ph == 2) {
+                const int ks = it - 2;  // the tile requested two iterations ago
+                if (ks >= 0 && ks < nt) {
+                    double *slot = env_ring + ((size_t)(ks % ENV_SLOTS) * ENV_TILE) * 64 + lane;
+#pragma unroll
+                    for (int j = 0; j < ENV_TILE; ++j) slot[j * 64] = v[j];
+                }
+            }
+            tile_barrier();
+        }
     }
 }
 
@@ -188,8 +248,11 @@ __global__ __launch_bounds__(256) void rows_argmax_kernel(const double *__restri
 hipError_t launch_envelope_track(const double *y, int B, int T, int G, double a_rise, double i_rise, double a_fall, double *env,
                                  int32_t *index, hipStream_t stream)
 {
-    hipLaunchKernelGGL(envelope_kernel, dim3((G + 63) / 64, B), dim3(64), 0, stream, y, T, G, a_rise, i_rise, a_fall, env);
-    hipError_t e = hipGetLastError();
+    const size_t ring = (size_t)ENV_SLOTS * ENV_TILE * 64 * sizeof(double);  // 64 KB
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(envelope_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(envelope_kernel, dim3((G + 63) / 64, B), dim3(64 * (1 + ENV_LOADERS)), ring, stream, y, T, G, a_rise, i_rise, a_fall, env);
+    e = hipGetLastError();
     if (e != hipSuccess || !index) return e;
     const size_t rows = (size_t)B * T;
     hipLaunchKernelGGL(rows_argmax_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, env, rows, G, index);
