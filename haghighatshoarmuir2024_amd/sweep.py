@@ -99,7 +99,11 @@ class ShardStore:
             return
         a = np.zeros(len(trials), dtype=self.REC)
         a["trial"], a["doa"], a["index"], a["pmax"] = trials, doa, index, pmax
-        name = f"trials_{int(trials.min()):08d}_{int(trials.max()) + 1:08d}_{len(trials)}.npy"
+        # (the name carries a checksum of the trial numbers: two different sets with the same bounds and size -- resumed runs under
+        #  different world sizes -- never overwrite each other's records)
+        import zlib
+
+        name = f"trials_{int(trials.min()):08d}_{int(trials.max()) + 1:08d}_{len(trials)}_{zlib.crc32(np.ascontiguousarray(trials).tobytes()):08x}.npy"
         tmp = os.path.join(self.dir, f".tmp-{os.getpid()}-{name}")
         with open(tmp, "wb") as f:
             np.save(f, a)
