@@ -123,6 +123,7 @@ SYMBOLS = {
     "micloc_design_vectors_f64": (c_int, [c_void_p, c_int, c_int, c_int, ctypes.c_double, c_void_p, c_int, c_int, c_void_p]),
     "micloc_peak_location_i32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "micloc_envelope_track_f64": (c_int, [c_void_p, c_int, c_int, c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double, c_void_p, c_void_p, c_void_p]),
+    "micloc_envelope_track_any": (c_int, [c_void_p, c_int, c_int, c_int, c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double, c_void_p, c_void_p, c_void_p]),
     "micloc_abi_version": (c_int, []),
     "micloc_status_string": (ctypes.c_char_p, [c_int]),
     "micloc_last_hip_error": (c_int, []),

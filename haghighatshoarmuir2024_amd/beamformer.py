@@ -51,7 +51,9 @@ class Beamformer:
             self._plan_key = key
         return self._plan
 
-    def apply_to_signal(self, bf_mat, sig_in):
+    def apply_to_signal(self, bf_mat, sig_in, to_host=True):
+        """Reference :260-292.  to_host=False (not in the reference): the complex T x G result stays on the device (a complex128 torch
+        tensor), e.g. for utils.Envelope.track -- the moving-target read-out of paper_plots/target_localization.py:597-600."""
         num_mic, num_grid = bf_mat.shape
         T, num_chan = sig_in.shape
         if num_chan != num_mic:
@@ -59,7 +61,8 @@ class Beamformer:
         plan = self.plan()
         plan.set_bf_mat(np.asarray(bf_mat, dtype=np.complex128))
         x = plan.to_device(np.asarray(sig_in, dtype=np.float64)[None])
-        return runtime.to_host(plan.beamformer_pipeline(x, want_y=True, want_power=False)["y"][0])
+        y = plan.beamformer_pipeline(x, want_y=True, want_power=False)["y"][0]
+        return runtime.to_host(y) if to_host else y
 
     def localize_batch(self, bf_mat, sig_batch):
         B, T, M = sig_batch.shape
@@ -69,7 +72,7 @@ class Beamformer:
         plan.set_bf_mat(np.asarray(bf_mat, dtype=np.complex128))
         return plan.beamformer_pipeline(plan.to_device(sig_batch), want_y=False, want_power=True)
 
-    def apply_to_template(self, bf_mat, template, snr_db):
+    def apply_to_template(self, bf_mat, template, snr_db, to_host=True):
         try:
             time_temp, sig_temp, doa_temp = template
         except Exception:
@@ -78,7 +81,9 @@ class Beamformer:
         _, sig_in_vec = synthesize_array_signal(self.geometry, self.fs, time_temp, sig_temp, doa_temp)
         noise = np.sqrt(np.mean(sig_in_vec**2)) / np.sqrt(snr) * np.random.randn(*sig_in_vec.shape)
         sig_in_vec += noise
-        return self.apply_to_signal(bf_mat=bf_mat, sig_in=sig_in_vec)
+        if to_host:  # (the reference's own call with its signature)
+            return self.apply_to_signal(bf_mat=bf_mat, sig_in=sig_in_vec)
+        return self.apply_to_signal(bf_mat=bf_mat, sig_in=sig_in_vec, to_host=False)
 
     def design_from_template(self, template, doa_list, interference_removal=False, doa_batch=32, svd="host"):
         """Reference :73-192.  svd="host" (default): the M x M decompositions by LAPACK like the reference (its singular-vector

@@ -1053,7 +1053,18 @@ int micloc_envelope_track_f64(const double *y, int B, int T, int G, double a_ris
     // 1 - 1/w and 1/w of window lengths w >= 1 (utils.py:34): finite, in [0, 1]
     if (!(a_rise >= 0.0 && a_rise <= 1.0 && i_rise >= 0.0 && i_rise <= 1.0 && a_fall >= 0.0 && a_fall <= 1.0)) return MICLOC_ERR_INVALID;
     DeviceGuard guard(device_of(env));
-    HIP_TRY(launch_envelope_track(y, B, T, G, a_rise, i_rise, a_fall, env, index, (hipStream_t)stream));
+    HIP_TRY(launch_envelope_track(y, MICLOC_ENV_F64, B, T, G, a_rise, i_rise, a_fall, env, index, (hipStream_t)stream));
+    return MICLOC_OK;
+}
+
+int micloc_envelope_track_any(const void *y, int kind, int B, int T, int G, double a_rise, double i_rise, double a_fall, double *env, int32_t *index,
+                              void *stream)
+{
+    if (!y || !env || bad_batch(B) || T < 1 || G < 1 || (long long)B * T > 0x7fffffffll * 4) return MICLOC_ERR_INVALID;
+    if (kind < MICLOC_ENV_F64 || kind > MICLOC_ENV_I64) return MICLOC_ERR_INVALID;
+    if (!(a_rise >= 0.0 && a_rise <= 1.0 && i_rise >= 0.0 && i_rise <= 1.0 && a_fall >= 0.0 && a_fall <= 1.0)) return MICLOC_ERR_INVALID;
+    DeviceGuard guard(device_of(env));
+    HIP_TRY(launch_envelope_track(y, kind, B, T, G, a_rise, i_rise, a_fall, env, index, (hipStream_t)stream));
     return MICLOC_OK;
 }
 

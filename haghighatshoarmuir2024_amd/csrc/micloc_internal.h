@@ -204,7 +204,7 @@ hipError_t launch_design_vec(const double *cov, int n_doa, int C, int bipolar, d
 hipError_t launch_pack_events(const int8_t *raster, size_t rows, int C, uint8_t *out, int stride, int pos_off, int neg_off, int mode,
                               hipStream_t stream);
 hipError_t launch_rate_from_counts(const int32_t *counts, int B, int G, int F, int T, double fs, double *rate, hipStream_t stream);
-hipError_t launch_envelope_track(const double *y, int B, int T, int G, double a_rise, double i_rise, double a_fall, double *env,
+hipError_t launch_envelope_track(const void *y, int kind, int B, int T, int G, double a_rise, double i_rise, double a_fall, double *env,
                                  int32_t *index, hipStream_t stream);
 hipError_t launch_peak_location(const int32_t *rate, int B, int G, int F, int win, int32_t *index, hipStream_t stream);
 

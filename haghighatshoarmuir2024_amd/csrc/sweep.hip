@@ -126,20 +126,55 @@ constexpr int ENV_TILE = 32;
 constexpr int ENV_SLOTS = 4;
 constexpr int ENV_LOADERS = 3;
 
-__global__ __launch_bounds__(64 * (1 + ENV_LOADERS)) void envelope_kernel(const double *__restrict__ y, int T, int G, double a_rise, double i_rise,
+// What the envelope is taken of (np.abs of the caller's array): the real SNN beamformer output, the complex Beamformer's output
+// (ref:paper_plots/target_localization.py:597-600: |z| = hypot(re, im), NumPy's npy_cabs), or an integer spike raster
+// (ref:paper_plots/target_xylo_localization.py:757-768: `sig_bf = spikes_out`).  Integers and real doubles are exact; hypot is the device
+// library's (< 1 ulp; the host libm's last bit is not a contract either).
+template <int KIND>
+struct EnvIn;
+template <>
+struct EnvIn<MICLOC_ENV_F64> {
+    typedef double T;
+    static __device__ __forceinline__ double mag(double v) { return fabs(v); }
+};
+template <>
+struct EnvIn<MICLOC_ENV_C128> {
+    typedef double2 T;
+    static __device__ __forceinline__ double mag(double2 v) { return hypot(v.x, v.y); }
+};
+template <>
+struct EnvIn<MICLOC_ENV_U8> {
+    typedef uint8_t T;
+    static __device__ __forceinline__ double mag(uint8_t v) { return (double)v; }
+};
+template <>
+struct EnvIn<MICLOC_ENV_I32> {
+    typedef int32_t T;
+    static __device__ __forceinline__ double mag(int32_t v) { return fabs((double)v); }
+};
+template <>
+struct EnvIn<MICLOC_ENV_I64> {
+    typedef long long T;
+    static __device__ __forceinline__ double mag(long long v) { return fabs((double)v); }
+};
+
+template <int KIND>
+__global__ __launch_bounds__(64 * (1 + ENV_LOADERS)) void envelope_kernel(const void *__restrict__ y_, int T, int G, double a_rise, double i_rise,
                                                                           double a_fall, double *__restrict__ env)
 {
-    extern __shared__ __attribute__((aligned(16))) double env_ring[];  // [ENV_SLOTS][ENV_TILE][64]
+    typedef typename EnvIn<KIND>::T In;
+    const In *__restrict__ y = static_cast<const In *>(y_);
+    extern __shared__ __attribute__((aligned(16))) double env_ring[];  // [ENV_SLOTS][ENV_TILE][64]: the MAGNITUDES of a tile's rows
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int g = blockIdx.x * 64 + lane;
     const bool live = g < G;
-    const double *p = y + (size_t)blockIdx.y * T * G + (live ? g : 0);
+    const In *p = y + (size_t)blockIdx.y * T * G + (live ? g : 0);
     double *o = env + (size_t)blockIdx.y * T * G + (live ? g : 0);
     const int nt = (T - 1 + ENV_TILE - 1) / ENV_TILE;  // tiles of rows 1 .. T - 1 (row 0 is the initial state)
     double state = 0.0;
     if (wave == 0) {
-        state = live ? fabs(p[0]) : 0.0;
+        state = live ? EnvIn<KIND>::mag(p[0]) : 0.0;
         if (live) o[0] = state;
     }
     // a barrier WITHOUT __syncthreads()'s memory fence: the fence would wait for every outstanding global load and store (vmcnt(0)) -- the
@@ -167,7 +202,7 @@ __global__ __launch_bounds__(64 * (1 + ENV_LOADERS)) void envelope_kernel(const 
                     const size_t rowbytes = (size_t)G * sizeof(double);
                     const unsigned voff = (unsigned)g * (unsigned)sizeof(double);
                     auto step = [&](int j) {
-                        const double m = fabs(v[j]);
+                        const double m = v[j];  // (a magnitude: the loaders took |.| of what they read)
                         const double up = __dadd_rn(__dmul_rn(a_rise, state), __dmul_rn(i_rise, m));
                         const double down = __dmul_rn(a_fall, state);
                         state = (m >= state) ? up : down;
@@ -188,9 +223,9 @@ __global__ __launch_bounds__(64 * (1 + ENV_LOADERS)) void envelope_kernel(const 
     } else {
         // this loader's tiles are k % 3 == wave - 1; an iteration is in exactly ONE of three phases (exclusive branches: the rows requested
         // two iterations ago stay in the registers they were loaded into -- no copies, no wait before they are written)
-        double v[ENV_TILE];
+        In v[ENV_TILE];
 #pragma unroll
-        for (int j = 0; j < ENV_TILE; ++j) v[j] = 0.0;
+        for (int j = 0; j < ENV_TILE; ++j) v[j] = In{};
         for (int it = 0; it < nt + 3; ++it) {
             const int ph = (it + ENV_LOADERS - (wave - 1)) % ENV_LOADERS;
             if (ph == 0) {
@@ -209,7 +244,7 @@ __global__ __launch_bounds__(64 * (1 + ENV_LOADERS)) void envelope_kernel(const 
                 if (ks >= 0 && ks < nt) {
                     double *slot = env_ring + ((size_t)(ks % ENV_SLOTS) * ENV_TILE) * 64 + lane;
 #pragma unroll
-                    for (int j = 0; j < ENV_TILE; ++j) slot[j * 64] = v[j];
+                    for (int j = 0; j < ENV_TILE; ++j) slot[j * 64] = EnvIn<KIND>::mag(v[j]);
                 }
             }
             tile_barrier();
@@ -245,14 +280,29 @@ __global__ __launch_bounds__(256) void rows_argmax_kernel(const double *__restri
     if (l == 0) index[row] = bi == 0x7fffffff ? 0 : bi;
 }
 
-hipError_t launch_envelope_track(const double *y, int B, int T, int G, double a_rise, double i_rise, double a_fall, double *env,
-                                 int32_t *index, hipStream_t stream)
+template <int KIND>
+static hipError_t launch_envelope_kind(const void *y, int B, int T, int G, double a_rise, double i_rise, double a_fall, double *env, hipStream_t stream)
 {
     const size_t ring = (size_t)ENV_SLOTS * ENV_TILE * 64 * sizeof(double);  // 64 KB
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(envelope_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring);
+    auto k = &envelope_kernel<KIND>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(envelope_kernel, dim3((G + 63) / 64, B), dim3(64 * (1 + ENV_LOADERS)), ring, stream, y, T, G, a_rise, i_rise, a_fall, env);
-    e = hipGetLastError();
+    hipLaunchKernelGGL(k, dim3((G + 63) / 64, B), dim3(64 * (1 + ENV_LOADERS)), ring, stream, y, T, G, a_rise, i_rise, a_fall, env);
+    return hipGetLastError();
+}
+
+hipError_t launch_envelope_track(const void *y, int kind, int B, int T, int G, double a_rise, double i_rise, double a_fall, double *env,
+                                 int32_t *index, hipStream_t stream)
+{
+    hipError_t e;
+    switch (kind) {
+        case MICLOC_ENV_F64: e = launch_envelope_kind<MICLOC_ENV_F64>(y, B, T, G, a_rise, i_rise, a_fall, env, stream); break;
+        case MICLOC_ENV_C128: e = launch_envelope_kind<MICLOC_ENV_C128>(y, B, T, G, a_rise, i_rise, a_fall, env, stream); break;
+        case MICLOC_ENV_U8: e = launch_envelope_kind<MICLOC_ENV_U8>(y, B, T, G, a_rise, i_rise, a_fall, env, stream); break;
+        case MICLOC_ENV_I32: e = launch_envelope_kind<MICLOC_ENV_I32>(y, B, T, G, a_rise, i_rise, a_fall, env, stream); break;
+        case MICLOC_ENV_I64: e = launch_envelope_kind<MICLOC_ENV_I64>(y, B, T, G, a_rise, i_rise, a_fall, env, stream); break;
+        default: return hipErrorInvalidValue;
+    }
     if (e != hipSuccess || !index) return e;
     const size_t rows = (size_t)B * T;
     hipLaunchKernelGGL(rows_argmax_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, env, rows, G, index);

@@ -605,11 +605,14 @@ def peak_location(counts, G, win_size, out=None):
 
 
 def envelope_track(y, win_fall, win_rise, want_index=True, env_out=None):
-    """micloc_envelope_track_f64: y [T, G] or [B, T, G] float64 device tensor -> (env like y, index int32 [T] / [B, T] or None).
+    """micloc_envelope_track_any: y [T, G] or [B, T, G] device tensor (float64: the SNN beamformer's output; complex128: the complex
+    Beamformer's, paper_plots/target_localization.py:597-600; uint8 / int32 / int64: a spike raster, paper_plots/target_xylo_localization.py:757-768)
+    -> (env float64 of y's shape, index int32 [T] / [B, T] or None).
     Envelope.evolve (micloc/utils.py:36-81) + np.argmax(axis=1) (paper_plots/target_snn_localization.py:599-622) on the device."""
     torch = _torch()
-    if y.dtype != torch.float64 or y.dim() not in (2, 3) or not y.is_cuda:
-        raise ValueError("envelope_track: a float64 device tensor [T, G] or [B, T, G] is required")
+    kinds = {torch.float64: 0, torch.complex128: 1, torch.uint8: 2, torch.int32: 3, torch.int64: 4}  # MICLOC_ENV_*
+    if y.dtype not in kinds or y.dim() not in (2, 3) or not y.is_cuda:
+        raise ValueError("envelope_track: a device tensor [T, G] or [B, T, G] of float64 / complex128 / uint8 / int32 / int64 is required")
     if int(win_fall) < 1 or int(win_rise) < 1:
         raise ValueError("envelope windows must hold at least one sample (int(fs * time) >= 1)")
     yc = y.contiguous()
@@ -618,10 +621,10 @@ def envelope_track(y, win_fall, win_rise, want_index=True, env_out=None):
     wl = np.asarray([int(win_fall), int(win_rise)])
     inv = 1 / wl
     a = 1 - inv
-    env = env_out if env_out is not None else torch.empty_like(yc)
+    env = env_out if env_out is not None else torch.empty(yc.shape, dtype=torch.float64, device=yc.device)
     idx = torch.empty(yc.shape[:-1], dtype=torch.int32, device=yc.device) if want_index else None
-    _lib.check(_lib.load().micloc_envelope_track_f64(_ptr(yc), int(B), int(T), int(G), float(a[1]), float(inv[1]), float(a[0]), _ptr(env),
-                                                     _ptr(idx) if idx is not None else None, _stream(yc.device)), "envelope_track")
+    _lib.check(_lib.load().micloc_envelope_track_any(_ptr(yc), kinds[y.dtype], int(B), int(T), int(G), float(a[1]), float(inv[1]), float(a[0]),
+                                                     _ptr(env), _ptr(idx) if idx is not None else None, _stream(yc.device)), "envelope_track")
     return env, idx
 
 

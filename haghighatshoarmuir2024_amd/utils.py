@@ -31,7 +31,9 @@ class Envelope:
         T, channel = sig_in.shape
         if T < channel:
             warnings.warn("number of channels in the input signal is larger than number of samples in each channel!")
-        mag = np.abs(sig_in)
+        # (float64 from the start: what the reference's list of rows becomes in `np.asarray` -- an integer raster, target_xylo_localization.py:
+        #  757-768, stays exact; a complex array gives its modulus)
+        mag = np.abs(sig_in).astype(np.float64)
         state = np.array(mag[0], copy=True)
         out = np.empty_like(mag)
         for t in range(1, T):

@@ -412,6 +412,16 @@ int micloc_peak_location_i32(const int32_t *rate, int B, int G, int bands, int w
  * written (a caller that only wants the indices passes scratch); index [B][T] int32 (may be NULL) = first maximum of every row. */
 int micloc_envelope_track_f64(const double *y, int B, int T, int G, double a_rise, double i_rise, double a_fall, double *env, int32_t *index,
                               void *stream);
+/* The same for the other arrays the reference's scripts hand to Envelope.evolve: the complex Beamformer's output
+ * (paper_plots/target_localization.py:597-600; y [B][T][G][2] = numpy complex128, |z| = hypot(re, im) -- the device library's, < 1 ulp) and
+ * integer spike rasters (paper_plots/target_xylo_localization.py:757-768: `sig_bf = spikes_out`; exact).  env stays double [B][T][G]. */
+#define MICLOC_ENV_F64 0
+#define MICLOC_ENV_C128 1
+#define MICLOC_ENV_U8 2
+#define MICLOC_ENV_I32 3
+#define MICLOC_ENV_I64 4
+int micloc_envelope_track_any(const void *y, int kind, int B, int T, int G, double a_rise, double i_rise, double a_fall, double *env, int32_t *index,
+                              void *stream);
 
 /* ---- misc ------------------------------------------------------------------------------------- */
 int micloc_abi_version(void);

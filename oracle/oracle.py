@@ -225,7 +225,7 @@ def envelope(y, win_fall, win_rise):
     """Envelope.evolve (ref:micloc/utils.py:36-81) restated: state_0 = |y_0|; per step `rise = |y_t| >= state`,
     `state = (1 - 1/w) * state + 1/w * |y_t| * rise` with w = win_rise if rise else win_fall, in NumPy's order of operations;
     out[t] = state after sample t.  y [T, G] -> [T, G].  Checker of micloc_envelope_track_f64 (tests only)."""
-    mag = np.abs(np.asarray(y, dtype=np.float64))
+    mag = np.abs(np.asarray(y)).astype(np.float64)  # (complex: the modulus; integers: exact -- the reference's mixed list ends as float64)
     wl = np.asarray([int(win_fall), int(win_rise)])
     state = mag[0].copy()
     out = np.empty_like(mag)

@@ -954,6 +954,20 @@ def gen_moving_target():
         out.update({f"syn{k}_params": np.asarray([seed, T, G, rise, fall, fs], dtype=np.float64), f"syn{k}_cols": cols, f"syn{k}_env_cols": env[:, cols],
                     f"syn{k}_env_last": env[-1], f"syn{k}_index": np.argmax(env, axis=1).astype(np.int16),
                     f"syn{k}_env_sha256": np.frombuffer(hashlib.sha256(np.ascontiguousarray(env).tobytes()).digest(), dtype=np.uint8)})
+    # the other arrays the scripts hand to Envelope.evolve: a complex beamformer output (target_localization.py:597-600: np.abs = hypot, whose
+    # last bit belongs to the host's libm: compared with a tolerance) and an integer spike raster (target_xylo_localization.py:757-768: exact)
+    zc = moving_target_synthetic(31, 3000, 200) + 1j * moving_target_synthetic(32, 3000, 200)
+    env = quiet(Envelope(rise_time=10e-3, fall_time=100e-3, fs=48_000).evolve, zc)
+    top2 = np.partition(env, -2, axis=1)[:, -2:]
+    out.update(cplx_params=np.asarray([31, 32, 3000, 200, 10e-3, 100e-3, 48_000]), cplx_env_cols=env[:, [0, 7, 66, 199]], cplx_env_last=env[-1],
+               cplx_index=np.argmax(env, axis=1).astype(np.int16), cplx_margin=((top2[:, 1] - top2[:, 0]) / np.maximum(top2[:, 1], 1e-300)).astype(np.float32))
+    rng = np.random.RandomState(41)
+    spk = (rng.rand(4000, 449) < 0.05).astype(np.int64) * rng.randint(1, 4, size=(4000, 449))
+    spk[:, 7] = 0
+    env = quiet(Envelope(rise_time=40e-3, fall_time=200e-3, fs=48_000).evolve, spk)  # target_xylo_localization.py:759-762
+    out.update(spk_params=np.asarray([41, 4000, 449, 40e-3, 200e-3, 48_000]), spk_env_cols=env[:, [0, 7, 100, 448]], spk_env_last=env[-1],
+               spk_index=np.argmax(env, axis=1).astype(np.int16),
+               spk_env_sha256=np.frombuffer(hashlib.sha256(np.ascontiguousarray(env).tobytes()).digest(), dtype=np.uint8))
     beamf, geometry, fs, fd, fr = cfg2_beamformer(True)
     bfz = np.load(os.path.join(OUT, "bf_mat_chirp449_bipolar.npz"))
     bf_mat, doa_list = bfz["bf_mat"], bfz["doa_list"]

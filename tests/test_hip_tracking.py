@@ -96,3 +96,56 @@ def test_moving_target_trial_against_the_reference(cfg2, torch):
     np.testing.assert_array_equal(idx.cpu().numpy()[clear], z["trial_index"][clear])
     # and the host route an unchanged script takes gives the same indices from the same y
     np.testing.assert_array_equal(env.track(y.cpu().numpy()), idx.cpu().numpy())
+
+
+def test_device_envelope_of_complex_and_integer_arrays(torch):
+    """micloc_envelope_track_any: the complex Beamformer's output (ref:paper_plots/target_localization.py:597-600: |z| = hypot, the device
+    library's: 1e-14 against the reference's envelope, its arg-max wherever the two best are not tied) and integer spike rasters as uint8 /
+    int32 / int64 (ref:paper_plots/target_xylo_localization.py:757-768: the reference's envelope bit for bit)."""
+    from haghighatshoarmuir2024_amd.utils import Envelope
+    from test_oracle_golden import _moving_target_spikes
+
+    z = golden("moving_target.npz")
+    zc = _moving_target_synthetic(31, 3000, 200) + 1j * _moving_target_synthetic(32, 3000, 200)
+    e = Envelope(rise_time=10e-3, fall_time=100e-3, fs=48_000)
+    idx, env = e.track(torch.from_numpy(zc).cuda(), want_envelope=True)
+    assert env.dtype == torch.float64 and tuple(env.shape) == zc.shape
+    np.testing.assert_allclose(env[:, [0, 7, 66, 199]].cpu().numpy(), z["cplx_env_cols"], rtol=1e-14, atol=0)
+    np.testing.assert_allclose(env[-1].cpu().numpy(), z["cplx_env_last"], rtol=1e-14, atol=0)
+    clear = z["cplx_margin"] > 1e-9
+    np.testing.assert_array_equal(idx.cpu().numpy()[clear], z["cplx_index"][clear])
+    spk = _moving_target_spikes()
+    e = Envelope(rise_time=40e-3, fall_time=200e-3, fs=48_000)
+    for dt in (torch.uint8, torch.int32, torch.int64):
+        idx, env = e.track(torch.from_numpy(spk).to(dt).cuda(), want_envelope=True)
+        got = env.cpu().numpy()
+        assert hashlib.sha256(np.ascontiguousarray(got).tobytes()).digest() == bytes(z["spk_env_sha256"]), dt
+        np.testing.assert_array_equal(idx.cpu().numpy(), z["spk_index"])
+    # negative integers: |.| like np.abs
+    neg = -spk
+    idx2, env2 = e.track(torch.from_numpy(neg).to(torch.int32).cuda(), want_envelope=True)
+    assert torch.equal(env2, env.to(env2.device)) and torch.equal(idx2, idx)
+
+
+def test_complex_beamformer_output_stays_on_the_device(cfg2, torch):
+    """Beamformer.apply_to_signal(to_host=False) -> complex128 device tensor == the host array; Envelope.track on it == the host route."""
+    from micloc.array_geometry import CenterCircularArray
+    from micloc.beamformer import Beamformer
+    from micloc.utils import Envelope
+
+    z = golden("beamformer_c128.npz")
+    names = set(z.files)
+    bm = Beamformer(CenterCircularArray(4.5e-2, 7), 10e-3, [1000.0, 2000.0], fs=48_000)
+    rng = np.random.RandomState(3)
+    sig = rng.randn(2400, 7)
+    W = (rng.randn(7, 57) + 1j * rng.randn(7, 57)) / np.sqrt(14)
+    y_host = bm.apply_to_signal(W, sig)
+    y_dev = bm.apply_to_signal(W, sig, to_host=False)
+    assert y_dev.is_cuda and y_dev.dtype == torch.complex128 and names
+    np.testing.assert_array_equal(y_dev.cpu().numpy(), y_host)
+    env = Envelope(rise_time=10e-3, fall_time=100e-3, fs=48_000)
+    idx = env.track(y_dev)
+    ih, eh = env.track(y_host, want_envelope=True)
+    top2 = np.partition(eh, -2, axis=1)[:, -2:]
+    clear = (top2[:, 1] - top2[:, 0]) > 1e-9 * top2[:, 1]
+    np.testing.assert_array_equal(idx.cpu().numpy()[clear], ih[clear])

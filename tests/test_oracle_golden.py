@@ -411,3 +411,32 @@ def test_envelope_restatement_and_host_class_equal_the_reference(k):
         np.testing.assert_array_equal(env[-1], z[f"syn{k}_env_last"])
         np.testing.assert_array_equal(np.argmax(env, axis=1), z[f"syn{k}_index"])
     np.testing.assert_array_equal(e.track(y), z[f"syn{k}_index"])
+
+
+def _moving_target_spikes():
+    rng = np.random.RandomState(41)
+    spk = (rng.rand(4000, 449) < 0.05).astype(np.int64) * rng.randint(1, 4, size=(4000, 449))
+    spk[:, 7] = 0
+    return spk
+
+
+def test_envelope_of_complex_and_integer_arrays():
+    """The other arrays the reference's scripts hand to Envelope.evolve (moving_target.npz): the complex Beamformer's output
+    (ref:paper_plots/target_localization.py:597-600; np.abs = hypot: 1e-15) and an integer spike raster
+    (ref:paper_plots/target_xylo_localization.py:757-768; bit for bit) -- oracle restatement and the package's host class."""
+    import hashlib
+
+    from haghighatshoarmuir2024_amd.utils import Envelope
+
+    z = golden("moving_target.npz")
+    zc = _moving_target_synthetic(31, 3000, 200) + 1j * _moving_target_synthetic(32, 3000, 200)
+    e = Envelope(rise_time=10e-3, fall_time=100e-3, fs=48_000)
+    for env in (O.envelope(zc, e.win_lens[0], e.win_lens[1]), e.evolve(zc)):
+        np.testing.assert_allclose(env[:, [0, 7, 66, 199]], z["cplx_env_cols"], rtol=1e-14, atol=0)
+        clear = z["cplx_margin"] > 1e-9
+        np.testing.assert_array_equal(np.argmax(env, axis=1)[clear], z["cplx_index"][clear])
+    spk = _moving_target_spikes()
+    e = Envelope(rise_time=40e-3, fall_time=200e-3, fs=48_000)
+    for env in (O.envelope(spk, e.win_lens[0], e.win_lens[1]), e.evolve(spk)):
+        assert hashlib.sha256(np.ascontiguousarray(env).tobytes()).digest() == bytes(z["spk_env_sha256"])
+        np.testing.assert_array_equal(np.argmax(env, axis=1), z["spk_index"])
