@@ -43,12 +43,15 @@ def synthesize_array_signal(geometry, fs, time_temp, sig_temp, doa_temp):
     Returns (time_in [T], sig_in_vec [T, M])."""
     time_temp = np.asarray(time_temp, dtype=np.float64)
     sig_temp = np.asarray(sig_temp, dtype=np.float64)
-    if isinstance(doa_temp, Number):
-        doa_temp = doa_temp * np.ones_like(sig_temp)
     time_in = np.arange(time_temp.min(), time_temp.max(), step=1 / fs)
     sig_in = np.interp(time_in, time_temp, sig_temp)
-    doa_in = np.interp(time_in, time_temp, doa_temp)
-    delays = geometry.delays(doa_in, normalized=False).T  # [M, T]
+    if isinstance(doa_temp, Number):
+        # a constant DoA: the reference interpolates a constant series (np.interp returns the constant itself) and calls `delays` with
+        # that scalar once per time step (:254-256) -- the same seven numbers every time: computed once, as that very scalar call
+        delays = geometry.delays(float(doa_temp), normalized=False).reshape(-1, 1)  # [M, 1]
+    else:
+        doa_in = np.interp(time_in, time_temp, doa_temp)
+        delays = geometry.delays(doa_in, normalized=False).T  # [M, T]
     delays = delays - delays.min()
     time_delayed = time_in.reshape(1, -1) - delays
     np.maximum(time_delayed, time_in.min(), out=time_delayed)
