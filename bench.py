@@ -449,7 +449,13 @@ def numpy_pool(workers):
     os.environ.update({k: "1" for k in saved})  # inherited by the workers only: restored below for this process
     try:
         pool = mp.get_context("spawn").Pool(workers, initializer=_np_worker_init)
-        pool.map(_np_worker, [([], ())] * workers)  # every worker is up and has imported NumPy / SciPy / the oracle
+        try:
+            # every worker is up and has imported NumPy / SciPy / the oracle -- or the leg is dropped (a worker that dies in its
+            # initialiser is respawned for ever: never wait for that without a limit)
+            pool.map_async(_np_worker, [([], ())] * workers).get(timeout=180)
+        except Exception:
+            pool.terminate()
+            raise
     finally:
         for k, v in saved.items():
             if v is None:
@@ -522,7 +528,7 @@ def cpu_baseline(wl, budget_s, pool=None, pool_workers=0):
         n_all = B if passes > 1 else (max(2 * pool_workers, n_all - n_all % 2) if B >= 2 * pool_workers else B)
         tasks = [(xa[i : i + 2], args) for _ in range(passes) for i in range(0, n_all, 2)]
         t0 = time.perf_counter()
-        parts = pool.map(_np_worker, tasks, chunksize=1)
+        parts = pool.map_async(_np_worker, tasks, chunksize=1).get(timeout=max(120.0, 20.0 * budget_s))
         dtp = time.perf_counter() - t0
         am_pool = np.asarray([v for p_ in parts for v in p_])
         done_trials = len(am_pool)
@@ -1679,14 +1685,21 @@ def run(args):
             result["api_per_call_ms"] = api_per_call_block(device)
             result["other_configs"] = other_configs_block(args)
         if not args.no_cpu_baseline and group_size == 1 and noisy:
-            cb, am = cpu_baseline(wl, args.cpu_seconds, np_pool, np_workers)
+            try:
+                cb, am = cpu_baseline(wl, args.cpu_seconds, np_pool, np_workers)
+            except Exception as e:  # (a stuck worker pool must not take the line down: the other legs are repeated without it)
+                print(f"bench.py: numpy_ops_all_cores leg failed ({type(e).__name__}: {e}); cpu_baseline without it", file=sys.stderr)
+                if np_pool is not None:
+                    np_pool.terminate()
+                    np_pool = None
+                cb, am = cpu_baseline(wl, args.cpu_seconds, None, 0)
             am_gpu = argmax_direct.cpu().numpy()
             cb["argmax_equal_to_gpu"] = bool(np.array_equal(am["all"], am_gpu) and np.array_equal(am["one"], am_gpu[: len(am["one"])])
                                              and np.array_equal(am["numpy"], am_gpu[: len(am["numpy"])])
                                              and ("numpy_all" not in am or np.array_equal(am["numpy_all"], am_gpu[: len(am["numpy_all"])])))
             result["cpu_baseline"] = cb
     if np_pool is not None:
-        np_pool.close()
+        np_pool.terminate()  # (idle workers: nothing to wait for)
         np_pool.join()
     grp.close()
     if rank == 0:
