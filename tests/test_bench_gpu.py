@@ -96,3 +96,17 @@ def test_bench_two_ranks_rehearsed_on_one_device():
     want = [(a + b) / 2 for a, b in zip(singles[0]["exchange"]["mae_deg_per_snr_device_same_batch"], singles[1]["exchange"]["mae_deg_per_snr_device_same_batch"])]
     assert max(abs(a - b) for a, b in zip(ex["mae_deg_per_snr_from_gathered_trials"], want)) < 1e-9
     assert ex["mae_deg_per_snr_device_same_batch"] == singles[0]["exchange"]["mae_deg_per_snr_device_same_batch"]  # rank 0's own batch
+
+
+def test_other_workloads_report_a_sustained_region():
+    """the speech workload (scan-lane schedule: eager launches, the serial checkpoint scans on a stream of their own) and
+    the Xylo workload carry a `sustained` block too -- one uninterrupted region beside the K-step regions, with the chip's telemetry."""
+    d = _run(["--config", "speech", "--trials", "6", "--sustained-seconds", "0.6"], {})
+    assert d["config"]["schedule"].startswith("scan-lane") and d["config"]["hip_graphs"] is False
+    sus = d["sustained"]
+    assert sus["seconds"] >= 0.6 and sus["steps"] >= 4 and sus["telemetry_source"].startswith("amdsmi")
+    assert 0.3 < sus["ratio_to_timed_regions"] < 1.5 and d["config"]["sustained_ms_per_step"] == sus["ms_per_step"]
+    assert d["config"]["memory_gb"]["peak_reserved"] > 0.1
+    x = _run(["--config", "xylo", "--trials", "110", "--sustained-seconds", "0.6"], {})
+    assert x["sustained"]["seconds"] >= 0.6 and x["config"]["sustained_ms_per_step"] == x["sustained"]["ms_per_step"]
+    assert x["parity"].startswith("UNPINNED")
